@@ -1,0 +1,187 @@
+"""lammps_le_amd — MI355X-native engine for the bead-spring + loop-extrusion hot path of
+polly-code/lammps_le, behind the reference's own interfaces.
+
+`lammps` mirrors the subset of the reference's ctypes wrapper (python/lammps.py) that drives this
+path: same method names and argument meaning, on top of the C-ABI in include/lammps_le.h
+(liblammps_le.so, hand-written HIP for gfx950).  There is NO CPU fallback: `run` fails loudly
+without a HIP device, and importing fails loudly if the shared library has not been built.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblammps_le.so")
+
+__all__ = ["lammps", "LammpsError", "library_path"]
+
+
+class LammpsError(Exception):
+    pass
+
+
+def library_path():
+    return _SO
+
+
+def _load():
+    if not os.path.exists(_SO):
+        raise ImportError(
+            "lammps_le_amd: %s is missing — build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C lammps_le_amd/csrc)" % _SO)
+    lib = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+    lib.lammps_open_no_mpi.restype = C.c_void_p
+    lib.lammps_open_no_mpi.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p]
+    lib.lammps_close.argtypes = [C.c_void_p]
+    lib.lammps_file.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_command.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_command.restype = C.c_char_p
+    lib.lammps_commands_string.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_get_natoms.argtypes = [C.c_void_p]
+    lib.lammps_get_natoms.restype = C.c_double
+    lib.lammps_get_thermo.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_get_thermo.restype = C.c_double
+    lib.lammps_extract_setting.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_extract_setting.restype = C.c_int
+    lib.lammps_extract_global.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_extract_global.restype = C.c_void_p
+    lib.lammps_extract_atom.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_extract_atom.restype = C.c_void_p
+    lib.lammps_extract_fix.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.lammps_extract_fix.restype = C.c_void_p
+    lib.lammps_gather_atoms.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    lib.lammps_scatter_atoms.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+    lib.lammps_extract_box.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+    lib.lammps_free.argtypes = [C.c_void_p]
+    lib.lammps_has_error.argtypes = [C.c_void_p]
+    lib.lammps_get_last_error_message.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.lammps_has_style.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    lib.lammps_le_stat.argtypes = [C.c_void_p, C.c_char_p]
+    lib.lammps_le_stat.restype = C.c_double
+    return lib
+
+
+class lammps(object):
+    """Counterpart of python/lammps.py `lammps` for this path (1 rank per process, one GPU per rank)."""
+
+    def __init__(self, name="", cmdargs=None, ptr=None, comm=None):
+        self.lib = _load()
+        args = ["lammps"] + list(cmdargs or [])
+        argv = (C.c_char_p * len(args))(*[a.encode() for a in args])
+        self.lmp = C.c_void_p(self.lib.lammps_open_no_mpi(len(args), argv, None))
+        if not self.lmp:
+            raise LammpsError("could not create engine instance")
+        self.opened = 1
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "opened", 0):
+            self.lib.lammps_close(self.lmp)
+            self.opened = 0
+            self.lmp = None
+
+    # -- error plumbing: python/lammps.py raises on lammps_has_error when built with exceptions --
+    def _check(self):
+        if self.lib.lammps_has_error(self.lmp):
+            buf = C.create_string_buffer(512)
+            self.lib.lammps_get_last_error_message(self.lmp, buf, 512)
+            raise LammpsError(buf.value.decode())
+
+    def version(self):
+        return self.lib.lammps_version(self.lmp)
+
+    def file(self, path):
+        self.lib.lammps_file(self.lmp, path.encode())
+        self._check()
+
+    def command(self, cmd):
+        self.lib.lammps_command(self.lmp, cmd.encode())
+        self._check()
+
+    def commands_list(self, cmdlist):
+        for c in cmdlist:
+            self.command(c)
+
+    def commands_string(self, multicmd):
+        self.lib.lammps_commands_string(self.lmp, multicmd.encode())
+        self._check()
+
+    def get_natoms(self):
+        return int(self.lib.lammps_get_natoms(self.lmp))
+
+    def get_thermo(self, name):
+        v = self.lib.lammps_get_thermo(self.lmp, name.encode())
+        self._check()
+        return v
+
+    def extract_setting(self, name):
+        return self.lib.lammps_extract_setting(self.lmp, name.encode())
+
+    def extract_box(self):
+        lo = (C.c_double * 3)()
+        hi = (C.c_double * 3)()
+        xy, yz, xz = C.c_double(), C.c_double(), C.c_double()
+        pf = (C.c_int * 3)()
+        bf = C.c_int()
+        self.lib.lammps_extract_box(self.lmp, lo, hi, C.byref(xy), C.byref(yz), C.byref(xz), pf, C.byref(bf))
+        return list(lo), list(hi), xy.value, yz.value, xz.value, list(pf), bf.value
+
+    def extract_fix(self, fid, style, type, nrow=0, ncol=0):
+        p = self.lib.lammps_extract_fix(self.lmp, fid.encode(), style, type, nrow, ncol)
+        self._check()
+        if not p:
+            return None
+        val = C.cast(p, C.POINTER(C.c_double))[0]
+        self.lib.lammps_free(p)
+        return val
+
+    def gather_atoms(self, name, type, count):
+        """As python/lammps.py: returns a ctypes array of natoms*count values ordered by atom ID."""
+        n = self.get_natoms()
+        data = ((C.c_double if type == 1 else C.c_int) * (n * count))()
+        self.lib.lammps_gather_atoms(self.lmp, name.encode(), type, count, data)
+        self._check()
+        return data
+
+    def scatter_atoms(self, name, type, count, data):
+        self.lib.lammps_scatter_atoms(self.lmp, name.encode(), type, count, data)
+        self._check()
+
+    # -- numpy conveniences (python/lammps.py has the same idea in lammps.numpy) --
+    def gather(self, name):
+        ints = {"type": 1, "id": 1, "mask": 1, "molecule": 1, "image": 3, "num_bond": 1, "nspecial": 3}
+        n = self.get_natoms()
+        if name in ("x", "v", "f"):
+            return np.ctypeslib.as_array(self.gather_atoms(name, 1, 3)).reshape(n, 3).copy()
+        if name in ("bond_type", "bond_atom"):
+            w = self.extract_setting("bond_per_atom")
+        elif name == "special":
+            w = self.extract_setting("maxspecial")
+        else:
+            w = ints[name]
+        a = np.ctypeslib.as_array(self.gather_atoms(name, 0, w)).reshape(n, w).copy()
+        return a[:, 0] if w == 1 else a
+
+    def scatter(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64 if name in ("x", "v", "f") else np.int32)
+        self.scatter_atoms(name, 1 if arr.dtype == np.float64 else 0, arr.shape[1] if arr.ndim > 1 else 1,
+                           arr.ctypes.data_as(C.c_void_p))
+
+    def bond_set(self):
+        """Set of (type, lo_tag, hi_tag) over all stored bonds."""
+        nb, bt, ba = self.gather("num_bond"), self.gather("bond_type"), self.gather("bond_atom")
+        out = set()
+        for i in np.nonzero(nb)[0]:
+            for m in range(nb[i]):
+                a, b = int(i) + 1, int(ba[i, m])
+                out.add((int(bt[i, m]), min(a, b), max(a, b)))
+        return out
+
+    def has_style(self, category, name):
+        return self.lib.lammps_has_style(self.lmp, category.encode(), name.encode()) != 0
+
+    def stat(self, name):
+        return self.lib.lammps_le_stat(self.lmp, name.encode())

@@ -1,0 +1,268 @@
+// capi.cpp — extern "C" boundary (include/lammps_le.h): the reference's library.h subset for this path.
+// Behaviour follows src/library.cpp; every entry point catches LammpsError and records it
+// (the reference does the same when built with LAMMPS_EXCEPTIONS, src/library.cpp BEGIN_CAPTURE/END_CAPTURE).
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/lammps_le.h"
+#include "device.h"
+
+using namespace lmp_le;
+
+#define BEGIN_CAPTURE Engine *e = (Engine *)handle; try {
+#define END_CAPTURE } catch (const std::exception &ex) { e->last_error = ex.what(); e->has_error = true; \
+    if (e->screen) { fprintf(e->screen, "ERROR: %s\n", ex.what()); fflush(e->screen); } \
+    if (e->logfile) { fprintf(e->logfile, "ERROR: %s\n", ex.what()); fflush(e->logfile); } }
+
+extern "C" {
+
+void *lammps_open_no_mpi(int argc, char **argv, void **ptr) {
+  Engine *e = nullptr;
+  try { e = new Engine(argc, argv); } catch (const std::exception &ex) { fprintf(stderr, "LAMMPS Exception: %s\n", ex.what()); }
+  if (ptr) *ptr = (void *)e;
+  return (void *)e;
+}
+void lammps_close(void *handle) { delete (Engine *)handle; }
+
+void lammps_file(void *handle, const char *file) { BEGIN_CAPTURE e->file(file); END_CAPTURE }
+char *lammps_command(void *handle, const char *cmd) {
+  char *result = nullptr;
+  BEGIN_CAPTURE result = (char *)e->one(cmd); END_CAPTURE
+  return result;
+}
+void lammps_commands_list(void *handle, int ncmd, const char **cmds) {
+  for (int i = 0; i < ncmd; i++) {
+    lammps_command(handle, cmds[i]);
+    if (((Engine *)handle)->has_error) return;
+  }
+}
+void lammps_commands_string(void *handle, const char *str) {
+  std::string s(str), line;
+  size_t pos = 0;
+  while (pos <= s.size()) {
+    size_t nl = s.find('\n', pos);
+    line = s.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
+    lammps_command(handle, line.c_str());
+    if (((Engine *)handle)->has_error || nl == std::string::npos) return;
+    pos = nl + 1;
+  }
+}
+
+double lammps_get_natoms(void *handle) { return (double)((Engine *)handle)->natoms; }
+
+double lammps_get_thermo(void *handle, const char *keyword) {
+  double val = 0.0;
+  BEGIN_CAPTURE
+    const ThermoRow &r = e->last_thermo;
+    std::string k = keyword;
+    if (k == "step") val = (double)e->ntimestep;
+    else if (k == "temp") val = r.temp;
+    else if (k == "epair" || k == "evdwl") val = r.epair;
+    else if (k == "emol" || k == "ebond") val = r.emol;
+    else if (k == "etotal") val = r.etotal;
+    else if (k == "press") val = r.press;
+    else if (k == "ke") val = r.ke;
+    else if (k == "pe") val = r.pe;
+    else if (k == "bonds") val = (double)e->nbonds;
+    else if (k == "atoms") val = (double)e->natoms;
+    else if (k == "vol") val = e->box.prd[0] * e->box.prd[1] * e->box.prd[2];
+    else if (k == "dt") val = e->dt;
+    else throw LammpsError("Unknown keyword in thermo_style custom command: " + k);
+  END_CAPTURE
+  return val;
+}
+
+void lammps_extract_box(void *handle, double *boxlo, double *boxhi, double *xy, double *yz, double *xz, int *pflags,
+                        int *boxflag) {
+  Engine *e = (Engine *)handle;
+  for (int d = 0; d < 3; d++) {
+    if (boxlo) boxlo[d] = e->box.lo[d];
+    if (boxhi) boxhi[d] = e->box.hi[d];
+    if (pflags) pflags[d] = 1;
+  }
+  if (xy) *xy = 0.0;
+  if (yz) *yz = 0.0;
+  if (xz) *xz = 0.0;
+  if (boxflag) *boxflag = 0;
+}
+
+int lammps_extract_setting(void *handle, const char *keyword) {
+  Engine *e = (Engine *)handle;
+  std::string k = keyword;
+  if (k == "bigint") return 8;
+  if (k == "tagint" || k == "imageint") return 4;
+  if (k == "nlocal" || k == "nall") return e->natoms;
+  if (k == "ntypes") return e->ntypes;
+  if (k == "nbondtypes") return e->nbondtypes;
+  if (k == "bond_per_atom") return e->bpa;
+  if (k == "maxspecial") return e->maxspecial;
+  if (k == "newton_bond") return 0;
+  if (k == "molecule_flag") return e->atom_style != "atomic";
+  if (k == "dimension") return 3;
+  if (k == "box_exist") return e->box_exist;
+  return -1;
+}
+
+void *lammps_extract_global(void *handle, const char *name) {
+  Engine *e = (Engine *)handle;
+  std::string k = name;
+  if (k == "dt") return &e->dt;
+  if (k == "ntimestep") return &e->ntimestep;
+  if (k == "boxlo") return e->box.lo;
+  if (k == "boxhi") return e->box.hi;
+  if (k == "natoms") { e->scratch_scalar = e->natoms; return &e->scratch_scalar; }
+  if (k == "nbonds") return &e->nbonds;
+  if (k == "ntypes") return &e->ntypes;
+  if (k == "boltz") return &e->boltz;
+  if (k == "units") return (void *)e->units.c_str();
+  return nullptr;
+}
+
+void *lammps_extract_atom(void *handle, const char *name) {
+  void *result = nullptr;
+  BEGIN_CAPTURE
+    e->download();
+    std::string k = name;
+    auto rows = [&](std::vector<double> &a) {
+      e->scratch_rows.resize(e->natoms);
+      for (int i = 0; i < e->natoms; i++) e->scratch_rows[i] = &a[3 * (size_t)i];
+      return (void *)e->scratch_rows.data();
+    };
+    if (k == "x") result = rows(e->x);
+    else if (k == "v") result = rows(e->v);
+    else if (k == "f") result = rows(e->f);
+    else if (k == "type") result = e->type.data();
+    else if (k == "mass") result = e->mass.data();
+    else if (k == "id") {
+      auto &a = e->scratch_i["id"]; a.resize(e->natoms);
+      for (int i = 0; i < e->natoms; i++) a[i] = i + 1;
+      result = a.data();
+    } else if (k == "mask") {
+      auto &a = e->scratch_i["mask"]; a.assign(e->natoms, 1);
+      result = a.data();
+    } else if (k == "image") {
+      auto &a = e->scratch_i["image"]; a.resize(e->natoms);
+      for (int i = 0; i < e->natoms; i++) a[i] = lammps_encode_image_flags(e->image[3 * i], e->image[3 * i + 1], e->image[3 * i + 2]);
+      result = a.data();
+    } else if (k == "molecule") result = e->molecule.data();
+  END_CAPTURE
+  return result;
+}
+
+void *lammps_extract_fix(void *handle, char *id, int style, int type, int nrow, int /*ncol*/) {
+  void *result = nullptr;
+  BEGIN_CAPTURE
+    Fix *f = e->find_fix(id);
+    if (!f) throw LammpsError(std::string("Could not find fix ID ") + id);
+    if (style != 0 || type != 1) throw LammpsError("MI355X engine: only global fix vectors can be extracted");
+    double *d = (double *)malloc(sizeof(double));
+    *d = f->compute_vector(nrow);
+    result = d;
+  END_CAPTURE
+  return result;
+}
+
+static int topo_width(Engine *e, const std::string &k) {
+  if (k == "num_bond") return 1;
+  if (k == "bond_type" || k == "bond_atom") return e->bpa;
+  if (k == "nspecial") return 3;
+  if (k == "special") return e->maxspecial;
+  return 0;
+}
+
+void lammps_gather_atoms(void *handle, char *name, int type, int count, void *data) {
+  BEGIN_CAPTURE
+    e->download();
+    std::string k = name;
+    int n = e->natoms;
+    if (type == 1) {
+      std::vector<double> *src = (k == "x") ? &e->x : (k == "v") ? &e->v : (k == "f") ? &e->f : nullptr;
+      if (!src || count != 3) throw LammpsError("lammps_gather_atoms: unknown property name " + k);
+      memcpy(data, src->data(), 3 * (size_t)n * sizeof(double));
+    } else {
+      int *out = (int *)data;
+      if (k == "type" && count == 1) memcpy(out, e->type.data(), n * sizeof(int));
+      else if (k == "id" && count == 1) for (int i = 0; i < n; i++) out[i] = i + 1;
+      else if (k == "mask" && count == 1) for (int i = 0; i < n; i++) out[i] = 1;
+      else if (k == "molecule" && count == 1) memcpy(out, e->molecule.data(), n * sizeof(int));
+      else if (k == "image" && count == 3) memcpy(out, e->image.data(), 3 * (size_t)n * sizeof(int));
+      else if (k == "image" && count == 1)
+        for (int i = 0; i < n; i++) out[i] = lammps_encode_image_flags(e->image[3 * i], e->image[3 * i + 1], e->image[3 * i + 2]);
+      else if (topo_width(e, k) == count && count > 0) {
+        const std::vector<int> &src = (k == "num_bond") ? e->num_bond : (k == "bond_type") ? e->bond_type :
+                                      (k == "bond_atom") ? e->bond_atom : (k == "nspecial") ? e->nspecial : e->special;
+        memcpy(out, src.data(), (size_t)n * count * sizeof(int));
+      } else throw LammpsError("lammps_gather_atoms: unknown property name " + k);
+    }
+  END_CAPTURE
+}
+
+void lammps_scatter_atoms(void *handle, char *name, int type, int count, void *data) {
+  BEGIN_CAPTURE
+    e->download();
+    std::string k = name;
+    int n = e->natoms;
+    if (type == 1 && count == 3 && (k == "x" || k == "v" || k == "f")) {
+      std::vector<double> &dst = (k == "x") ? e->x : (k == "v") ? e->v : e->f;
+      memcpy(dst.data(), data, 3 * (size_t)n * sizeof(double));
+    } else if (type == 0 && count == 1 && k == "type") memcpy(e->type.data(), data, n * sizeof(int));
+    else if (type == 0 && count == 3 && k == "image") memcpy(e->image.data(), data, 3 * (size_t)n * sizeof(int));
+    else throw LammpsError("lammps_scatter_atoms: unknown property name " + k);
+    e->dev_current = false;   // next run re-uploads
+  END_CAPTURE
+}
+
+int lammps_version(void *) { return 20201029; }
+/* src/library.cpp lammps_encode_image_flags: 10 bits per dimension, offset 512 (LAMMPS_SMALLBIG) */
+int lammps_encode_image_flags(int ix, int iy, int iz) {
+  return ((ix + 512) & 1023) | (((iy + 512) & 1023) << 10) | (((iz + 512) & 1023) << 20);
+}
+void lammps_decode_image_flags(int image, int *flags) {
+  flags[0] = (image & 1023) - 512;
+  flags[1] = ((image >> 10) & 1023) - 512;
+  flags[2] = (image >> 20) - 512;
+}
+void lammps_free(void *ptr) { free(ptr); }
+int lammps_is_running(void *) { return 0; }
+int lammps_has_error(void *handle) { return ((Engine *)handle)->has_error ? 1 : 0; }
+int lammps_get_last_error_message(void *handle, char *buffer, int buf_size) {
+  Engine *e = (Engine *)handle;
+  if (!e->has_error) { if (buf_size > 0) buffer[0] = '\0'; return 0; }
+  snprintf(buffer, buf_size, "%s", e->last_error.c_str());
+  e->has_error = false;
+  e->last_error.clear();
+  return 1;   // 1 = normal (recoverable) error, as ERROR_NORMAL in src/library.cpp
+}
+int lammps_config_has_exceptions(void) { return 1; }
+int lammps_has_style(void *, const char *category, const char *name) {
+  std::string c = category, s = name;
+  if (c == "fix") return s == "nve" || s == "langevin" || s == "extrusion" || s == "ex_load" || s == "ex_unload";
+  if (c == "pair") return s == "lj/cut" || s == "zero" || s == "none";
+  if (c == "bond") return s == "fene" || s == "harmonic" || s == "hybrid" || s == "zero" || s == "none";
+  if (c == "atom") return s == "bond" || s == "molecular" || s == "atomic" || s == "full" || s == "angle";
+  return 0;
+}
+
+double lammps_le_stat(void *handle, const char *name) {
+  Engine *e = (Engine *)handle;
+  std::string k = name;
+  if (k == "loop_time") return e->loop_time;
+  if (k == "neigh_builds") return (double)e->neigh_builds;
+  if (k == "neigh_time") return e->timers[2];
+  if (k == "pair_kernel_ms") return e->kstat_ms;
+  if (k == "pair_kernel_launches") return (double)e->kstat_n;
+  if (k == "neigh_pairs") return e->stat_neigh_pairs();
+  if (k == "maxneigh") return e->dev ? (double)e->dev->maxneigh : 0.0;
+  if (k == "fene_warnings") return e->dev && e->dev->flags_h ? (double)e->dev->flags_h[FLAG_FENE_WARN] : 0.0;
+  return -1.0;
+}
+
+}  // extern "C"
+
+// test hook (not part of the reference surface): RanMarsInt stream after a jump, for the CPU unit tests
+extern "C" void lammps_le_test_ranmars(int seed, long long skip, int n, double *out) {
+  lmp_le::RanMarsInt r;
+  r.seed(seed);
+  r.jump((uint64_t)skip);
+  for (int i = 0; i < n; i++) out[i] = r.uniform();
+}

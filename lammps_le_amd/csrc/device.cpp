@@ -1,0 +1,105 @@
+// device.cpp — HBM allocation for one engine instance (288 GB per MI355X: everything stays resident).
+#include "device.h"
+
+#include <cmath>
+
+namespace lmp_le {
+
+template <class T>
+static void dalloc(T *&p, size_t count) {
+  HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+  HIP_CHECK(hipMemset(p, 0, count * sizeof(T)));
+}
+template <class T>
+static void dfree(T *&p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+void dev_alloc_neigh(DeviceState &d, int maxneigh) {
+  dfree(d.neigh);
+  d.maxneigh = maxneigh;
+  dalloc(d.neigh, (size_t)maxneigh * d.npad);
+}
+
+void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxspecial, const Box &box,
+               double cutneigh) {
+  if (!d.stream) HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+  d.n = n;
+  d.npad = ((n + 63) / 64) * 64 + 64;
+  d.maxtag = maxtag;
+  d.ntypes = ntypes;
+  d.bpa = bpa;
+  d.maxspecial = maxspecial;
+  d.box = box;
+  size_t np = d.npad, nt = (size_t)maxtag + 2;
+  dalloc(d.pos, np); dalloc(d.pos_tmp, np); dalloc(d.xhold, np);
+  for (int k = 0; k < 3; k++) { dalloc(d.v[k], np); dalloc(d.v_tmp[k], np); dalloc(d.f[k], np); }
+  dalloc(d.tag, np); dalloc(d.tag_tmp, np);
+  dalloc(d.img, 3 * np); dalloc(d.img_tmp, 3 * np);
+  dalloc(d.map, nt); dalloc(d.type_t, nt); dalloc(d.crank, nt);
+  dalloc(d.num_bond, nt); dalloc(d.bond_type, nt * bpa); dalloc(d.bond_atom, nt * bpa);
+  dalloc(d.nspecial, nt * 3); dalloc(d.special, nt * (size_t)maxspecial);
+  // cells of edge >= cutneigh
+  d.ncells = 1;
+  for (int k = 0; k < 3; k++) {
+    d.ncell[k] = cutneigh > 0.0 ? (int)(box.prd[k] / cutneigh) : 1;
+    if (d.ncell[k] < 1) d.ncell[k] = 1;
+    // keep cells from getting needlessly tiny for bond-only runs
+    d.cellinv[k] = d.ncell[k] / box.prd[k];
+    d.ncells *= d.ncell[k];
+  }
+  dalloc(d.cell_of, np); dalloc(d.cell_count, (size_t)d.ncells + 1); dalloc(d.cell_start, (size_t)d.ncells + 1);
+  dalloc(d.cell_fill, (size_t)d.ncells + 1); dalloc(d.scan_tmp, (size_t)d.ncells / 1024 + 2); dalloc(d.perm, np);
+  double vol = box.prd[0] * box.prd[1] * box.prd[2];
+  double expect = (double)n / vol * 4.18879020478639 * cutneigh * cutneigh * cutneigh;
+  int mn = (int)(expect * 1.5) + 24;
+  dalloc(d.numneigh, np);
+  dalloc(d.bpart, (size_t)bpa * np);
+  dev_alloc_neigh(d, mn);
+  dalloc(d.pairtab, (size_t)6 * (ntypes + 1) * (ntypes + 1));
+  d.nred_blocks = (n + 255) / 256 + 8;
+  dalloc(d.partial, (size_t)d.nred_blocks * 16);
+  HIP_CHECK(hipHostMalloc((void **)&d.partial_h, (size_t)d.nred_blocks * 16 * sizeof(double)));
+  dalloc(d.flags, NFLAGS);
+  HIP_CHECK(hipHostMalloc((void **)&d.flags_h, NFLAGS * sizeof(int)));
+  for (int k = 0; k < NFLAGS; k++) d.flags_h[k] = 0;
+  // LE fix scratch
+  dalloc(d.xt, nt);
+  for (int k = 0; k < 8; k++) dalloc(d.le_i[k], nt);
+  for (int k = 0; k < 2; k++) dalloc(d.le_d[k], nt);
+  dalloc(d.le_bits, nt / 64 + 4);
+  dalloc(d.le_rng_state, 3 * 100);
+  dalloc(d.le_draws, nt);
+  dalloc(d.le_list, 4 * nt);
+  dalloc(d.le_scan, nt + 1024);
+}
+
+void dev_free(DeviceState &d) {
+  dfree(d.pos); dfree(d.pos_tmp); dfree(d.xhold);
+  for (int k = 0; k < 3; k++) { dfree(d.v[k]); dfree(d.v_tmp[k]); dfree(d.f[k]); }
+  dfree(d.tag); dfree(d.tag_tmp); dfree(d.img); dfree(d.img_tmp);
+  dfree(d.map); dfree(d.type_t); dfree(d.crank);
+  dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special);
+  dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
+  dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.pairtab); dfree(d.partial);
+  if (d.partial_h) (void)hipHostFree(d.partial_h);
+  d.partial_h = nullptr;
+  dfree(d.flags);
+  if (d.flags_h) (void)hipHostFree(d.flags_h);
+  d.flags_h = nullptr;
+  dfree(d.rng_state); dfree(d.rng_jump); dfree(d.rng_out);
+  dfree(d.xt);
+  for (int k = 0; k < 8; k++) dfree(d.le_i[k]);
+  for (int k = 0; k < 2; k++) dfree(d.le_d[k]);
+  dfree(d.le_bits); dfree(d.le_rng_state); dfree(d.le_draws); dfree(d.le_list); dfree(d.le_scan);
+  if (d.stream) (void)hipStreamDestroy(d.stream);
+  d.stream = nullptr;
+}
+
+void sync_flags(DeviceState &d) {
+  HIP_CHECK(hipMemcpyAsync(d.flags_h, d.flags, NFLAGS * sizeof(int), hipMemcpyDeviceToHost, d.stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+}
+
+}  // namespace lmp_le

@@ -1,0 +1,145 @@
+// device.h — HBM layout of the engine and the kernel launchers (gfx950).
+//
+// Physical (p-indexed) arrays are kept in CELL order: every reneighbor re-sorts the atoms by
+// neighbor cell (ties by tag), so a cell's atoms are one contiguous range and the neighbor
+// gathers of the pair kernel stay inside a few L2-resident rows.  Topology (bonds, specials,
+// extruder state) stays TAG-indexed and is never permuted; map[tag] -> p links the two.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "engine.h"
+
+namespace lmp_le {
+
+#define HIP_CHECK(x)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (x);                                                                          \
+    if (e_ != hipSuccess)                                                                         \
+      throw LammpsError(std::string("HIP error: ") + hipGetErrorString(e_) + " at " + __FILE__ + \
+                        ":" + std::to_string(__LINE__));                                          \
+  } while (0)
+
+enum FlagSlot {
+  FLAG_MOVED = 0,       // some atom moved more than skin/2 since the last build
+  FLAG_ERROR = 1,       // device-side error code (see ERR_*)
+  FLAG_NEIGH_OVERFLOW = 2,
+  FLAG_FENE_WARN = 3,   // count of "FENE bond too long" warnings
+  FLAG_TOPO_CHANGED = 4,
+  FLAG_COUNT_A = 5,     // LE fix counters (created / broken)
+  FLAG_COUNT_B = 6,
+  FLAG_NDRAW = 7,       // number of RNG draws requested by an LE fix
+  FLAG_NLIST = 8,       // number of extruder listings
+  FLAG_MAXNEIGH = 9,    // largest neighbor count seen at the last build
+  FLAG_AUX = 10,
+  NFLAGS = 16
+};
+enum DevErr {
+  ERR_NONE = 0, ERR_BAD_FENE = 1, ERR_BOND_MISSING = 2, ERR_EXT_MULTI = 3, ERR_BPA = 4,
+  ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8
+};
+
+struct DeviceState {
+  hipStream_t stream = nullptr;
+  int n = 0;        // owned atoms
+  int npad = 0;     // stride of the column-major (ELL) tables, multiple of 64
+  int maxtag = 0;
+  int ntypes = 0, bpa = 0, maxspecial = 0;
+  Box box{};
+
+  // ---- physical order ----
+  double4 *pos = nullptr, *pos_tmp = nullptr;   // x y z type
+  double4 *xhold = nullptr;                      // positions at the last build (same order)
+  double *v[3] = {nullptr, nullptr, nullptr}, *v_tmp[3] = {nullptr, nullptr, nullptr};
+  double *f[3] = {nullptr, nullptr, nullptr};
+  int *tag = nullptr, *tag_tmp = nullptr;
+  int *img = nullptr, *img_tmp = nullptr;        // [3][npad]
+  // ---- tag order ----
+  int *map = nullptr;                            // [maxtag+2] tag -> p
+  int *type_t = nullptr;                         // [maxtag+2]
+  int *crank = nullptr;                          // [maxtag+2] canonical (reference local) index
+  int *num_bond = nullptr, *bond_type = nullptr, *bond_atom = nullptr;   // [(maxtag+2)], [*bpa]
+  int *nspecial = nullptr, *special = nullptr;                            // [*3], [*maxspecial]
+  // ---- cells / neighbor list ----
+  int ncell[3] = {0, 0, 0}, ncells = 0;
+  double cellinv[3] = {0, 0, 0};
+  int *cell_of = nullptr, *cell_count = nullptr, *cell_start = nullptr, *cell_fill = nullptr;
+  int *scan_tmp = nullptr, *perm = nullptr;
+  int maxneigh = 0;
+  int *neigh = nullptr;      // [maxneigh][npad] full list, special bits in the top 2 bits
+  int *numneigh = nullptr;   // [npad]
+  int *bpart = nullptr;      // [bpa][npad] (type << 26) | partner p ; -1 = none
+  double *pairtab = nullptr; // 6 * nt*nt : cutsq lj1 lj2 lj3 lj4 offset
+  // ---- thermo partial sums ----
+  int nred_blocks = 0;
+  double *partial = nullptr;     // [nblocks][16]
+  double *partial_h = nullptr;   // pinned
+  // ---- flags ----
+  int *flags = nullptr;          // device
+  int *flags_h = nullptr;        // pinned host copy
+  // ---- Langevin RNG (block-parallel RanMars) ----
+  int rng_B = 0, rng_nblocks = 0;
+  uint32_t *rng_state = nullptr;   // [nblocks][97]
+  uint32_t *rng_jump = nullptr;    // [97] coefficients of x^(3N)
+  uint32_t *rng_out = nullptr;     // [3N] 24-bit draws of the current call, canonical order
+  // ---- LE fixes (tag order) ----
+  double4 *xt = nullptr;           // [maxtag+2] stored coordinates by tag
+  int *le_i[8] = {nullptr};        // integer scratch arrays [maxtag+2]
+  double *le_d[2] = {nullptr};     // double scratch [maxtag+2]
+  unsigned long long *le_bits = nullptr;
+  uint32_t *le_rng_state = nullptr;   // [3][100]: w[97], n_lo, n_hi per LE fix slot
+  uint32_t *le_draws = nullptr;       // [maxtag+2]
+  int *le_list = nullptr;             // extruder listings [4][maxtag+2]
+  int *le_scan = nullptr;
+  // ---- kernel timing (HIP events on the launch stream) ----
+  std::vector<hipEvent_t> ev0, ev1;
+  size_t ev_used = 0;
+};
+
+// ------------------------------- launchers (kernels_*.hip) -------------------------------------
+void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxspecial, const Box &box,
+               double cutneigh);
+void dev_free(DeviceState &d);
+void dev_alloc_neigh(DeviceState &d, int maxneigh);
+
+// integrate (kernels_md.hip)
+void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check);
+void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4], bool eflag, bool has_pair);
+void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
+void launch_final_integrate(DeviceState &d, const TypeTables &tt);
+void launch_ke(DeviceState &d, const TypeTables &tt);
+// reductions: returns sums of `partial` columns on the host (synchronises the stream)
+void reduce_partials(DeviceState &d, double *out16);
+
+// neighbor (kernels_neigh.hip)
+void launch_reneighbor(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
+
+// rng (kernels_rng.hip)
+void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms);
+void launch_rng_langevin(DeviceState &d, uint64_t first_raw);
+void launch_ranmars_gen(DeviceState &d, int slot, const int *count_ptr, uint32_t *out, int maxout);
+
+// LE fixes (kernels_le.hip)
+struct ExLoadParams {
+  int iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype;
+  double cutsq, fraction;
+};
+struct ExUnloadParams {
+  int btype;
+  double cutsq, fraction;
+};
+struct ExtrusionParams {
+  int neutral, ctcf_left, ctcf_right, ctcf_lr, btype;
+  double through_prob;
+};
+void le_rng_upload(DeviceState &d, int slot, const RanMarsInt &r);
+void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
+// each returns after enqueueing; counters are read back by the caller through flags_h
+void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
+void launch_ex_unload(DeviceState &d, const ExUnloadParams &p, int rng_slot);
+void launch_extrusion(DeviceState &d, const ExtrusionParams &p, int rng_slot);
+void sync_flags(DeviceState &d);   // copy flags to flags_h and wait
+
+}  // namespace lmp_le

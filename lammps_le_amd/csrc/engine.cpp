@@ -1,0 +1,566 @@
+// engine.cpp — run control of the MI355X engine: init / setup / Verlet loop / reneighbor decision /
+// thermo.  Mirrors src/run.cpp:38-188, src/verlet.cpp:87-156 (setup) and :223-354 (run),
+// src/neighbor.cpp:1933-1948 (decide), src/thermo.cpp + compute_temp/pe/pressure for the printed line.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "device.h"
+
+namespace lmp_le {
+
+static double wall() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+Engine::Engine(int argc, char **argv) {
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    if ((a == "-screen" || a == "-sc") && i + 1 < argc) {
+      std::string v = argv[++i];
+      if (v == "none") screen = nullptr;
+    } else if ((a == "-log" || a == "-l") && i + 1 < argc) {
+      std::string v = argv[++i];
+      if (v != "none") logfile = fopen(v.c_str(), "w");
+    } else if ((a == "-echo" || a == "-e") && i + 1 < argc) {
+      echo_screen = std::string(argv[++i]) != "none";
+    } else if ((a == "-var" || a == "-v") && i + 2 < argc) {
+      variables[argv[i + 1]] = argv[i + 2];
+      i += 2;
+    }
+  }
+  thermo_keywords = {"step", "temp", "epair", "emol", "etotal", "press"};
+  const char *kt = getenv("LAMMPS_LE_KERNEL_TIMING");
+  kernel_timing = kt && atoi(kt) != 0;
+}
+
+Engine::~Engine() {
+  if (dev) {
+    try { dev_free(*dev); } catch (...) {}
+    delete dev;
+  }
+  if (logfile) fclose(logfile);
+}
+
+void Engine::say(const std::string &s) {
+  if (screen) { fputs(s.c_str(), screen); fflush(screen); }
+  if (logfile) { fputs(s.c_str(), logfile); fflush(logfile); }
+}
+void Engine::warning(const std::string &s) { say("WARNING: " + s + "\n"); }
+
+Fix *Engine::find_fix(const std::string &id) {
+  for (auto &f : fixes) if (f->id == id) return f.get();
+  return nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// init: pair coefficients (src/pair_lj_cut.cpp:512-569), neighbor cutoffs (src/neighbor.cpp:240-),
+// special lists (src/special.cpp:55-), fix init
+// ---------------------------------------------------------------------------------------------
+void Engine::init() {
+  if (!box_exist) throw LammpsError("Run command before simulation box is defined");
+  for (int t = 1; t <= ntypes; t++)
+    if (!mass_set[t]) throw LammpsError("Not all per-type masses are set");
+  if (ntypes > MAXTYPES || nbondtypes > MAXTYPES)
+    throw LammpsError("MI355X engine handles at most " + std::to_string(MAXTYPES) + " atom/bond types");
+  int nt = ntypes + 1;
+  lj1.assign(nt * nt, 0.0); lj2 = lj3 = lj4 = offset = cutsq = lj1;
+  cutforcemax = 0.0;
+  if (pair_lj) {
+    for (int i = 1; i <= ntypes; i++)
+      if (!pc_set[i * nt + i]) throw LammpsError("All pair coeffs are not set");
+    for (int i = 1; i <= ntypes; i++)
+      for (int j = i; j <= ntypes; j++) {
+        int ij = i * nt + j, ji = j * nt + i, ii = i * nt + i, jj = j * nt + j;
+        double eps, sig, cut;
+        if (pc_set[ij]) { eps = pc_eps[ij]; sig = pc_sig[ij]; cut = pc_cut[ij]; }
+        else {   // src/pair.cpp mix_energy / mix_distance
+          eps = std::sqrt(pc_eps[ii] * pc_eps[jj]);
+          sig = pair_mix ? 0.5 * (pc_sig[ii] + pc_sig[jj]) : std::sqrt(pc_sig[ii] * pc_sig[jj]);
+          cut = pair_mix ? 0.5 * (pc_cut[ii] + pc_cut[jj]) : std::sqrt(pc_cut[ii] * pc_cut[jj]);
+        }
+        lj1[ij] = 48.0 * eps * std::pow(sig, 12.0);
+        lj2[ij] = 24.0 * eps * std::pow(sig, 6.0);
+        lj3[ij] = 4.0 * eps * std::pow(sig, 12.0);
+        lj4[ij] = 4.0 * eps * std::pow(sig, 6.0);
+        if (pair_shift && cut > 0.0) {
+          double ratio = sig / cut;
+          offset[ij] = 4.0 * eps * (std::pow(ratio, 12.0) - std::pow(ratio, 6.0));
+        } else offset[ij] = 0.0;
+        cutsq[ij] = cut * cut;
+        lj1[ji] = lj1[ij]; lj2[ji] = lj2[ij]; lj3[ji] = lj3[ij]; lj4[ji] = lj4[ij];
+        offset[ji] = offset[ij]; cutsq[ji] = cutsq[ij];
+        cutforcemax = std::max(cutforcemax, cut);
+      }
+  } else if (pair_zero) cutforcemax = pair_cut_global;
+  cutneighmax = (pair_lj || pair_zero) ? cutforcemax + skin : 0.0;
+  if (atom_style != "atomic" && !bond_style_name.empty() && bond_style_name != "zero" && bond_style_name != "none")
+    for (int b = 1; b <= nbondtypes; b++)
+      if (bondtab.style[b] == 0 && nbonds > 0) throw LammpsError("All bond coeffs are not set");
+  if (!special_built) build_special();
+  for (auto &f : fixes) f->init();
+}
+
+// ---------------------------------------------------------------------------------------------
+void Engine::device_init() {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    throw LammpsError("No HIP device: the MI355X engine has no CPU fallback (hipGetDeviceCount: " +
+                      std::string(hipGetErrorString(e)) + ")");
+  const char *lr = getenv("LOCAL_RANK");
+  int devid = lr ? atoi(lr) % ndev : 0;
+  HIP_CHECK(hipSetDevice(devid));
+  if (!dev) dev = new DeviceState();
+}
+
+void Engine::upload() {
+  device_init();
+  if (natoms <= 0) throw LammpsError("No atoms to run");
+  for (int d = 0; d < 3; d++) {
+    if (cutneighmax > 0.0 && box.prd[d] < 3.0 * cutneighmax)
+      throw LammpsError("Box is smaller than 3 neighbor cutoffs in a periodic dimension: "
+                        "not supported by the MI355X engine (minimum-image cell lists)");
+  }
+  DeviceState &d = *dev;
+  bool realloc = (d.n != natoms || d.bpa != bpa || d.maxspecial != maxspecial || d.ntypes != ntypes || !d.pos);
+  double cellcut = cutneighmax > 0.0 ? cutneighmax : std::max({box.prd[0], box.prd[1], box.prd[2]}) / 3.0;
+  if (!realloc)
+    for (int k = 0; k < 3; k++)
+      if ((int)(box.prd[k] / cellcut) != d.ncell[k]) realloc = true;
+  if (realloc) {
+    if (d.pos) dev_free(d);
+    dev_alloc(d, natoms, natoms, ntypes, bpa, maxspecial, box, cellcut);
+    for (auto &f : fixes)
+      if (auto *l = dynamic_cast<FixLangevin *>(f.get())) l->dev_ready = false;
+  }
+  d.box = box;
+  int n = natoms, np = d.npad;
+  size_t nt = (size_t)n + 2;
+  std::vector<double4> pos(np);
+  std::vector<double> vv(3 * (size_t)np, 0.0), ff(3 * (size_t)np, 0.0);
+  std::vector<int> tg(np, 0), im(3 * (size_t)np, 0), mp(nt, -1), ty(nt, 0), cr(nt, 0);
+  for (int i = 0; i < n; i++) {
+    pos[i] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], (double)type[i]);
+    for (int k = 0; k < 3; k++) {
+      vv[(size_t)k * np + i] = v[3 * i + k];
+      ff[(size_t)k * np + i] = f[3 * i + k];
+      im[(size_t)k * np + i] = image[3 * i + k];
+    }
+    tg[i] = i + 1; mp[i + 1] = i; ty[i + 1] = type[i]; cr[i + 1] = crank[i];
+  }
+  auto up = [&](void *dst, const void *src, size_t bytes) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d.stream));
+  };
+  up(d.pos, pos.data(), np * sizeof(double4));
+  up(d.xhold, pos.data(), np * sizeof(double4));
+  for (int k = 0; k < 3; k++) {
+    up(d.v[k], vv.data() + (size_t)k * np, np * sizeof(double));
+    up(d.f[k], ff.data() + (size_t)k * np, np * sizeof(double));
+  }
+  up(d.tag, tg.data(), np * sizeof(int));
+  up(d.img, im.data(), 3 * (size_t)np * sizeof(int));
+  up(d.map, mp.data(), nt * sizeof(int));
+  up(d.type_t, ty.data(), nt * sizeof(int));
+  up(d.crank, cr.data(), nt * sizeof(int));
+  // topology: host index t-1 -> device index t
+  std::vector<int> nb(nt, 0), bt(nt * bpa, 0), ba(nt * bpa, 0), ns(nt * 3, 0), sp(nt * (size_t)maxspecial, 0);
+  std::copy(num_bond.begin(), num_bond.end(), nb.begin() + 1);
+  std::copy(bond_type.begin(), bond_type.end(), bt.begin() + bpa);
+  std::copy(bond_atom.begin(), bond_atom.end(), ba.begin() + bpa);
+  std::copy(nspecial.begin(), nspecial.end(), ns.begin() + 3);
+  std::copy(special.begin(), special.end(), sp.begin() + maxspecial);
+  up(d.num_bond, nb.data(), nt * sizeof(int));
+  up(d.bond_type, bt.data(), nt * bpa * sizeof(int));
+  up(d.bond_atom, ba.data(), nt * bpa * sizeof(int));
+  up(d.nspecial, ns.data(), nt * 3 * sizeof(int));
+  up(d.special, sp.data(), nt * (size_t)maxspecial * sizeof(int));
+  int ntp = ntypes + 1;
+  std::vector<double> tab(6 * (size_t)ntp * ntp, 0.0);
+  if (pair_lj)
+    for (int k = 0; k < ntp * ntp; k++) {
+      tab[k] = cutsq[k]; tab[ntp * ntp + k] = lj1[k]; tab[2 * ntp * ntp + k] = lj2[k];
+      tab[3 * ntp * ntp + k] = lj3[k]; tab[4 * ntp * ntp + k] = lj4[k]; tab[5 * ntp * ntp + k] = offset[k];
+    }
+  up(d.pairtab, tab.data(), tab.size() * sizeof(double));
+  HIP_CHECK(hipMemsetAsync(d.flags, 0, NFLAGS * sizeof(int), d.stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+  dev_current = true;
+  host_current = true;
+}
+
+void Engine::download() {
+  if (!dev || !dev_current || host_current) return;
+  DeviceState &d = *dev;
+  int n = natoms, np = d.npad;
+  size_t nt = (size_t)n + 2;
+  std::vector<double4> pos(np);
+  std::vector<double> vv(3 * (size_t)np), ff(3 * (size_t)np);
+  std::vector<int> tg(np), im(3 * (size_t)np), ty(nt);
+  auto down = [&](void *dst, const void *src, size_t bytes) {
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, d.stream));
+  };
+  down(pos.data(), d.pos, np * sizeof(double4));
+  for (int k = 0; k < 3; k++) {
+    down(vv.data() + (size_t)k * np, d.v[k], np * sizeof(double));
+    down(ff.data() + (size_t)k * np, d.f[k], np * sizeof(double));
+  }
+  down(tg.data(), d.tag, np * sizeof(int));
+  down(im.data(), d.img, 3 * (size_t)np * sizeof(int));
+  down(ty.data(), d.type_t, nt * sizeof(int));
+  std::vector<int> nb(nt), bt(nt * bpa), ba(nt * bpa), ns(nt * 3), sp(nt * (size_t)maxspecial);
+  down(nb.data(), d.num_bond, nt * sizeof(int));
+  down(bt.data(), d.bond_type, nt * bpa * sizeof(int));
+  down(ba.data(), d.bond_atom, nt * bpa * sizeof(int));
+  down(ns.data(), d.nspecial, nt * 3 * sizeof(int));
+  down(sp.data(), d.special, nt * (size_t)maxspecial * sizeof(int));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+  for (int p = 0; p < n; p++) {
+    int i = tg[p] - 1;
+    x[3 * i] = pos[p].x; x[3 * i + 1] = pos[p].y; x[3 * i + 2] = pos[p].z;
+    for (int k = 0; k < 3; k++) {
+      v[3 * i + k] = vv[(size_t)k * np + p];
+      f[3 * i + k] = ff[(size_t)k * np + p];
+      image[3 * i + k] = im[(size_t)k * np + p];
+    }
+  }
+  for (int i = 0; i < n; i++) type[i] = ty[i + 1];
+  std::copy(nb.begin() + 1, nb.begin() + 1 + n, num_bond.begin());
+  std::copy(bt.begin() + bpa, bt.begin() + bpa + (size_t)n * bpa, bond_type.begin());
+  std::copy(ba.begin() + bpa, ba.begin() + bpa + (size_t)n * bpa, bond_atom.begin());
+  std::copy(ns.begin() + 3, ns.begin() + 3 + (size_t)n * 3, nspecial.begin());
+  std::copy(sp.begin() + maxspecial, sp.begin() + maxspecial + (size_t)n * maxspecial, special.begin());
+  host_current = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+static void check_device_error(Engine *e, DeviceState &d) {
+  int code = d.flags_h[FLAG_ERROR];
+  if (!code) return;
+  const char *msg = "device error";
+  switch (code) {
+    case ERR_BAD_FENE: msg = "Bad FENE bond"; break;
+    case ERR_BOND_MISSING: msg = "Bond atoms missing"; break;
+    case ERR_EXT_MULTI: msg = "Fix extrusion, more than one bond type 2"; break;
+    case ERR_BPA: msg = "New bond exceeded bonds per atom in fix ex_load"; break;
+    case ERR_SPECIAL: msg = "New bond exceeded special list size in fix ex_load"; break;
+    case ERR_COUNT_MISMATCH: msg = "Numbers of created and broken bonds are not equal"; break;
+    case ERR_NONFINITE: msg = "Non-numeric atom coords - simulation unstable"; break;
+    case ERR_SPECIAL_SCRATCH: msg = "Special list size exceeded in fix bond/create"; break;
+  }
+  (void)e;
+  throw LammpsError(msg);
+}
+
+void Engine::reneighbor() {
+  DeviceState &d = *dev;
+  double t0 = wall();
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MOVED, 0, sizeof(int), d.stream));
+  for (int attempt = 0; attempt < 6; attempt++) {
+    HIP_CHECK(hipMemsetAsync(d.flags + FLAG_NEIGH_OVERFLOW, 0, sizeof(int), d.stream));
+    launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
+    sync_flags(d);
+    check_device_error(this, d);
+    if (!d.flags_h[FLAG_NEIGH_OVERFLOW]) break;
+    // grow the ELL table and rebuild (atoms are already wrapped and sorted: the rebuild is idempotent)
+    dev_alloc_neigh(d, d.flags_h[FLAG_MAXNEIGH] + 16);
+  }
+  ago = 0;
+  neigh_builds++;
+  timers[2] += wall() - t0;
+}
+
+// Neighbor::decide (src/neighbor.cpp:1933-1948); `moved` was produced by the initial_integrate kernel
+bool Engine::decide() {
+  for (size_t k = 0; k < fixes.size(); k++)
+    if (fixes[k]->force_reneighbor && le_reneigh_step[k] == ntimestep) return true;
+  ago++;
+  if (ago >= neigh_delay && ago % neigh_every == 0) {
+    if (!neigh_check) return true;
+    sync_flags(*dev);
+    check_device_error(this, *dev);
+    bool moved = dev->flags_h[FLAG_MOVED] != 0;
+    if (moved && ago == std::max(neigh_every, neigh_delay)) neigh_dangerous++;
+    return moved;
+  }
+  return false;
+}
+
+// keep `crank` equal to the reference's local atom order: Atom::sort (src/atom.cpp:2003-2094) with
+// bins of 1/2 cutneighmax over the box (setup_sort_bins :2100-2208), stable within a bin
+void Engine::emulate_atom_sort() {
+  nextsort = (ntimestep / sortfreq) * sortfreq + sortfreq;
+  double binsize = 0.5 * cutneighmax;
+  if (binsize == 0.0) return;
+  host_current = false;
+  download();
+  double bininv = 1.0 / binsize;
+  int nb[3]; double binv[3];
+  for (int d = 0; d < 3; d++) {
+    nb[d] = (int)((box.hi[d] - box.lo[d]) * bininv);
+    if (nb[d] == 0) nb[d] = 1;
+    binv[d] = nb[d] / (box.hi[d] - box.lo[d]);
+  }
+  if ((long)nb[0] * nb[1] * nb[2] == 1) return;
+  std::vector<std::pair<long long, int>> key(natoms);   // (bin, old canonical index) -> tag-1
+  std::vector<int> bytag(natoms);
+  for (int i = 0; i < natoms; i++) {
+    int c[3];
+    for (int d = 0; d < 3; d++) {
+      c[d] = (int)((x[3 * i + d] - box.lo[d]) * binv[d]);
+      c[d] = std::min(std::max(c[d], 0), nb[d] - 1);
+    }
+    long long ibin = ((long long)c[2] * nb[1] + c[1]) * nb[0] + c[0];
+    key[i] = {ibin * (long long)natoms + crank[i], i};
+  }
+  std::sort(key.begin(), key.end());
+  for (int r = 0; r < natoms; r++) crank[key[r].second] = r;
+  std::vector<int> cr((size_t)natoms + 2, 0);
+  for (int i = 0; i < natoms; i++) cr[i + 1] = crank[i];
+  HIP_CHECK(hipMemcpyAsync(dev->crank, cr.data(), cr.size() * sizeof(int), hipMemcpyHostToDevice, dev->stream));
+  HIP_CHECK(hipStreamSynchronize(dev->stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+static TypeTables make_tables(Engine *e, FixLangevin *lg) {
+  TypeTables tt{};
+  double dtf = 0.5 * e->dt * e->ftm2v;
+  for (int t = 1; t <= e->ntypes; t++) {
+    tt.mass[t] = e->mass[t];
+    tt.dtfm[t] = dtf / e->mass[t];
+    if (lg) {
+      // src/fix_langevin.cpp:296-310 (init) and :784-797 (compute_target), :662-663
+      double g1 = -e->mass[t] / lg->t_period / e->ftm2v;
+      double g2 = std::sqrt(e->mass[t]) * std::sqrt(24.0 * e->boltz / lg->t_period / e->dt / e->mvv2e) / e->ftm2v;
+      g1 *= 1.0 / 1.0;
+      g2 *= 1.0 / std::sqrt(1.0);
+      double delta = (double)(e->ntimestep - e->beginstep);
+      if (delta != 0.0) delta /= (double)(e->endstep - e->beginstep);
+      double t_target = lg->t_start + delta * (lg->t_stop - lg->t_start);
+      double tsqrt = std::sqrt(t_target);
+      tt.g1[t] = g1;
+      tt.g2[t] = g2 * tsqrt;
+    }
+  }
+  return tt;
+}
+
+static FixLangevin *the_langevin(Engine *e) {
+  FixLangevin *lg = nullptr;
+  for (auto &f : e->fixes)
+    if (auto *l = dynamic_cast<FixLangevin *>(f.get())) {
+      if (lg) throw LammpsError("MI355X engine supports one fix langevin");
+      lg = l;
+    }
+  return lg;
+}
+static int count_nve(Engine *e) {
+  int c = 0;
+  for (auto &f : e->fixes) if (dynamic_cast<FixNVE *>(f.get())) c++;
+  return c;
+}
+
+void Engine::compute_forces(bool eflag) {
+  DeviceState &d = *dev;
+  bool timed = kernel_timing && !eflag && d.ev_used < 4096;
+  if (timed) {
+    if (d.ev0.size() <= d.ev_used) {
+      hipEvent_t a, b;
+      HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+      d.ev0.push_back(a); d.ev1.push_back(b);
+    }
+    HIP_CHECK(hipEventRecord(d.ev0[d.ev_used], d.stream));
+  }
+  launch_force(d, bondtab, special_lj, eflag, pair_lj);
+  if (timed) { HIP_CHECK(hipEventRecord(d.ev1[d.ev_used], d.stream)); d.ev_used++; }
+}
+
+double Engine::stat_neigh_pairs() {
+  if (!dev || !dev->numneigh) return 0.0;
+  std::vector<int> nn(dev->n);
+  HIP_CHECK(hipMemcpy(nn.data(), dev->numneigh, (size_t)dev->n * sizeof(int), hipMemcpyDeviceToHost));
+  double s = 0.0;
+  for (int v : nn) s += v;
+  return s;
+}
+
+static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
+  DeviceState &d = *e->dev;
+  if (!lg->dev_ready) {
+    // position a host generator at the first draw of this call and cut the stream into blocks
+    RanMarsInt r;
+    r.seed(lg->seed);
+    r.jump(lg->draws);
+    rng_langevin_setup(d, r, e->natoms);
+    lg->dev_ready = true;
+  }
+  launch_rng_langevin(d, lg->draws + 1);     // raw index of draw k is k+1 (constructor warm-up)
+  lg->draws += 3ull * e->natoms;
+  TypeTables tt = make_tables(e, lg);
+  bool ident = (e->sortfreq == 0);
+  launch_langevin(d, tt, ident, fuse_final);
+}
+
+ThermoRow Engine::eval_thermo() {
+  DeviceState &d = *dev;
+  TypeTables tt = make_tables(this, nullptr);
+  launch_ke(d, tt);
+  double s[16];
+  reduce_partials(d, s);
+  ThermoRow r{};
+  r.step = ntimestep;
+  double dof = 3.0 * natoms - 3.0;                       // src/compute_temp.cpp:60-68
+  double tfactor = dof > 0 ? mvv2e / (dof * boltz) : 0.0;
+  r.temp = s[14] * tfactor;
+  double norm = thermo_norm ? (double)natoms : 1.0;
+  double ke = r.temp * 0.5 * dof * boltz;
+  r.evdwl = s[0]; r.ebond = s[1];
+  for (int k = 0; k < 6; k++) r.virial[k] = s[2 + k] + s[8 + k];
+  double vol = box.prd[0] * box.prd[1] * box.prd[2];
+  r.press = (dof * boltz * r.temp + r.virial[0] + r.virial[1] + r.virial[2]) / 3.0 / vol * nktv2p;
+  r.epair = r.evdwl / norm; r.emol = r.ebond / norm;
+  r.pe = (r.evdwl + r.ebond) / norm;
+  r.ke = ke / norm;
+  r.etotal = (ke + r.evdwl + r.ebond) / norm;
+  r.nbonds = nbonds;
+  sync_flags(d);
+  check_device_error(this, d);
+  return r;
+}
+
+static double thermo_value(Engine *e, const ThermoRow &r, const std::string &k) {
+  if (k == "step") return (double)r.step;
+  if (k == "temp") return r.temp;
+  if (k == "epair") return r.epair;
+  if (k == "emol" || k == "ebond") return r.emol;
+  if (k == "etotal") return r.etotal;
+  if (k == "press") return r.press;
+  if (k == "ke") return r.ke;
+  if (k == "pe") return r.pe;
+  if (k == "evdwl") return r.epair;
+  if (k == "bonds") return (double)r.nbonds;
+  if (k == "atoms") return (double)e->natoms;
+  if (k == "vol") return e->box.prd[0] * e->box.prd[1] * e->box.prd[2];
+  if (k.rfind("f_", 0) == 0) {
+    size_t b = k.find('[');
+    std::string id = k.substr(2, b == std::string::npos ? std::string::npos : b - 2);
+    Fix *f = e->find_fix(id);
+    if (!f) throw LammpsError("Could not find thermo fix ID " + id);
+    int idx = (b == std::string::npos) ? 1 : atoi(k.c_str() + b + 1);
+    return f->compute_vector(idx - 1);
+  }
+  throw LammpsError("Unknown keyword in thermo_style custom command: " + k);
+}
+
+void Engine::print_thermo_header() {
+  std::string h;
+  for (auto &k : thermo_keywords) {
+    std::string n = k;
+    if (k == "step") n = "Step"; else if (k == "temp") n = "Temp"; else if (k == "epair") n = "E_pair";
+    else if (k == "emol") n = "E_mol"; else if (k == "etotal") n = "TotEng"; else if (k == "press") n = "Press";
+    else if (k == "ke") n = "KinEng"; else if (k == "pe") n = "PotEng"; else if (k == "bonds") n = "Bonds";
+    h += n + " ";
+  }
+  say(h + "\n");
+}
+void Engine::print_thermo(const ThermoRow &r) {
+  std::string line;
+  char buf[64];
+  for (auto &k : thermo_keywords) {
+    double val = thermo_value(this, r, k);
+    if (k == "step" || k == "bonds" || k == "atoms") snprintf(buf, sizeof buf, "%8ld ", (long)val);
+    else snprintf(buf, sizeof buf, "%12.8g ", val);
+    line += buf;
+  }
+  say(line + "\n");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Verlet::setup (src/verlet.cpp:87-156)
+// ---------------------------------------------------------------------------------------------
+void Engine::setup() {
+  reneighbor();                       // pbc + (spatial sort) + lists; ncalls reset below
+  neigh_builds = 0;
+  if (sortfreq > 0) emulate_atom_sort();
+  compute_forces(true);
+  FixLangevin *lg = the_langevin(this);
+  for (auto &f : fixes) f->setup();
+  if (lg) langevin_post_force(this, lg, false);   // FixLangevin::setup -> post_force (:372-373)
+  last_thermo = eval_thermo();
+  thermo_log.push_back(last_thermo);
+  print_thermo_header();
+  print_thermo(last_thermo);
+}
+
+// Verlet::run (src/verlet.cpp:223-354)
+void Engine::iterate(long nsteps) {
+  DeviceState &d = *dev;
+  FixLangevin *lg = the_langevin(this);
+  int nnve = count_nve(this);
+  double triggersq = 0.25 * skin * skin;
+  for (long it = 0; it < nsteps; it++) {
+    ntimestep++;
+    bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
+    TypeTables tt = make_tables(this, nullptr);
+    bool will_check = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
+    for (int k = 0; k < nnve; k++) launch_initial_integrate(d, tt, dt, triggersq, will_check && k == nnve - 1);
+    for (auto &f : fixes) if (f->has_post_integrate) f->post_integrate();
+    if (decide()) {
+      reneighbor();
+      if (sortfreq > 0 && ntimestep >= nextsort) emulate_atom_sort();
+    }
+    compute_forces(eflag);
+    if (lg) langevin_post_force(this, lg, nnve == 1);
+    if (!(lg && nnve == 1))
+      for (int k = 0; k < nnve; k++) launch_final_integrate(d, tt);
+    if (eflag) {
+      last_thermo = eval_thermo();
+      thermo_log.push_back(last_thermo);
+      print_thermo(last_thermo);
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+}
+
+void Engine::run(long nsteps) {
+  if (nsteps < 0) throw LammpsError("Invalid run command N value");
+  init();
+  if (!dev_current || !dev || !dev->pos) upload();
+  le_reneigh_step.assign(fixes.size(), -1);
+  beginstep = ntimestep;
+  endstep = ntimestep + nsteps;
+  host_current = false;
+  for (int k = 0; k < 8; k++) timers[k] = 0.0;
+  setup();
+  dev->ev_used = 0;
+  double t0 = wall();
+  iterate(nsteps);
+  loop_time = wall() - t0;
+  kstat_ms = 0.0; kstat_n = 0;
+  for (size_t k = 0; k < dev->ev_used; k++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, dev->ev0[k], dev->ev1[k]) == hipSuccess) { kstat_ms += ms; kstat_n++; }
+  }
+  if (kstat_n) kstat_ms /= kstat_n;
+  sync_flags(*dev);
+  check_device_error(this, *dev);
+  char buf[256];
+  snprintf(buf, sizeof buf, "Loop time of %g on 1 procs for %ld steps with %d atoms\n\n", loop_time, nsteps, natoms);
+  say(buf);
+  if (nsteps > 0 && loop_time > 0) {
+    double sps = nsteps / loop_time;
+    if (units == "lj") snprintf(buf, sizeof buf, "Performance: %.3f tau/day, %.3f timesteps/s\n", 86400.0 * sps * dt, sps);
+    else snprintf(buf, sizeof buf, "Performance: %.3f ns/day, %.3f timesteps/s\n", 86400.0 * sps * dt * 1e-6, sps);
+    say(buf);
+  }
+  snprintf(buf, sizeof buf, "Neigh   | %g s\nNeighbor list builds = %ld\nDangerous builds = %ld\n", timers[2], neigh_builds,
+           neigh_dangerous);
+  say(buf);
+  if (dev->flags_h[FLAG_FENE_WARN]) {
+    snprintf(buf, sizeof buf, "FENE bond too long warnings: %d", dev->flags_h[FLAG_FENE_WARN]);
+    warning(buf);
+  }
+}
+
+}  // namespace lmp_le

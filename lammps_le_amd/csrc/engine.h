@@ -1,0 +1,275 @@
+// engine.h — MI355X-native bead-spring MD engine behind the reference's script / C-library boundary.
+//
+// Host side (C++17) mirrors the reference objects that the hot path talks to
+// (/root/reference/src: input.cpp, read_data.cpp, modify.cpp, verlet.cpp, neighbor.cpp,
+// pair_lj_cut.cpp, MOLECULE/bond_fene.cpp, fix_nve.cpp, fix_langevin.cpp, USER-LE/fix_*.cpp);
+// all per-atom work runs as hand-written HIP kernels for gfx950 (kernels_*.hip).
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace lmp_le {
+
+struct LammpsError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+constexpr int MAXTYPES = 16;       // atom types and bond types handled by the by-value kernel tables
+constexpr int MAXBPA = 8;          // bonds per atom the bond-partner table can hold
+constexpr int MS_MAX = 32;         // max special neighbors per atom handled by the device rebuild
+constexpr int NEIGH_SB_SHIFT = 30; // special-bond bits, as src/lmptype.h:61-62
+constexpr int NEIGH_MASK = 0x3FFFFFFF;
+constexpr int BOND_TYPE_SHIFT = 26; // bond partner table: (type << 26) | partner index
+constexpr int BOND_IDX_MASK = (1 << BOND_TYPE_SHIFT) - 1;
+
+// ---------------------------------------------------------------------------------------------
+// RanMars in exact integer arithmetic (src/random_mars.cpp:29-95; every value is k * 2^-24)
+// ---------------------------------------------------------------------------------------------
+struct RanMarsInt {
+  // history window w[k] = y_{n-97+k}, k = 0..96, of the lagged-Fibonacci part
+  //   y_n = y_{n-97} - y_{n-33}  (mod 2^24),  y_{-k} = u[k] of the reference's seed table
+  uint32_t w[97];
+  uint64_t n;  // raw index of the NEXT value to generate (the constructor's warm-up draw was n = 0)
+  void seed(int seed);
+  uint32_t next_raw();  // 24-bit integer of the next uniform(): uniform = value / 2^24
+  double uniform() { return next_raw() * (1.0 / 16777216.0); }
+  static uint32_t c_of(uint64_t n);  // arithmetic-sequence term used for raw index n
+  void jump(uint64_t k);             // advance by k draws in O(97^2 log k)
+};
+// coefficients a[0..96] of x^k mod (x^97 + x^64 - 1) over Z/2^24: y_{n+k} = sum_j a[j] y_{n+j}
+void ranmars_jump_poly(uint64_t k, uint32_t a[97]);
+
+// ---------------------------------------------------------------------------------------------
+// device-side views (plain pointers; filled by Engine, consumed by the kernel launchers)
+// ---------------------------------------------------------------------------------------------
+struct Box {
+  double lo[3], hi[3], prd[3], half[3];
+};
+
+struct TypeTables {  // by-value kernel argument
+  double dtfm[MAXTYPES + 1];   // dtf / mass[type]           (src/fix_nve.cpp:95)
+  double g1[MAXTYPES + 1];     // gfactor1[type]             (src/fix_langevin.cpp:296-310)
+  double g2[MAXTYPES + 1];     // gfactor2[type] * tsqrt     (src/fix_langevin.cpp:663)
+  double mass[MAXTYPES + 1];
+};
+
+struct PairTable {  // lj/cut per type pair, row-major (ntypes+1)^2; lives in device memory
+  int nt;           // ntypes + 1
+  double special_lj[4];
+};
+
+struct BondTable {  // by-value kernel argument
+  int style[MAXTYPES + 1];  // 0 none/zero, 1 fene, 2 harmonic
+  double p0[MAXTYPES + 1], p1[MAXTYPES + 1], p2[MAXTYPES + 1], p3[MAXTYPES + 1];
+};
+
+struct DeviceState;  // defined in device.h (HIP side)
+
+// ---------------------------------------------------------------------------------------------
+// fixes (style registry mirrors src/modify.cpp:93-99 / style names of the reference)
+// ---------------------------------------------------------------------------------------------
+class Engine;
+
+struct Fix {
+  std::string id, group, style;
+  Engine *eng = nullptr;
+  bool force_reneighbor = false;
+  virtual ~Fix() {}
+  virtual void init() {}
+  virtual void setup() {}
+  // which hooks this fix has (src/fix.h:247-273 mask bits)
+  bool has_initial_integrate = false, has_post_integrate = false, has_post_force = false,
+       has_final_integrate = false;
+  virtual void initial_integrate() {}
+  virtual void post_integrate() {}
+  virtual void post_force() {}
+  virtual void final_integrate() {}
+  virtual double compute_vector(int) { throw LammpsError("Fix does not compute a vector"); }
+};
+
+struct FixNVE : Fix {
+  FixNVE(Engine *e, const std::vector<std::string> &arg);
+};
+
+struct FixLangevin : Fix {
+  double t_start, t_stop, t_period;
+  int seed;
+  RanMarsInt rng;          // host mirror of the stream position (kept in sync by draw counting)
+  uint64_t draws = 0;      // Langevin draws consumed so far (3 per atom per post_force call)
+  bool dev_ready = false;  // device block states initialised
+  FixLangevin(Engine *e, const std::vector<std::string> &arg);
+};
+
+struct FixExtrusion : Fix {
+  int nevery, neutral, ctcf_left, ctcf_right, ctcf_lr, btype;
+  double through_prob;
+  RanMarsInt rng;
+  bool rng_on_device = false;
+  int last_break = 0;
+  FixExtrusion(Engine *e, const std::vector<std::string> &arg);
+  void post_integrate() override;
+  double compute_vector(int n) override;
+};
+
+struct FixExLoad : Fix {
+  int nevery, iatomtype, jatomtype, btype, imaxbond = 0, inewtype, jmaxbond = 0, jnewtype;
+  double cutsq, fraction = 1.0;
+  int seed = 12345;
+  RanMarsInt rng;
+  bool rng_on_device = false;
+  int last_create = 0;
+  long total_create = 0;
+  FixExLoad(Engine *e, const std::vector<std::string> &arg);
+  void init() override;
+  void post_integrate() override;
+  double compute_vector(int n) override;
+};
+
+struct FixExUnload : Fix {
+  int nevery, btype;
+  double cutsq, fraction = 1.0;
+  int seed = 12345;
+  RanMarsInt rng;
+  bool rng_on_device = false;
+  int last_break = 0;
+  long total_break = 0;
+  FixExUnload(Engine *e, const std::vector<std::string> &arg);
+  void post_integrate() override;
+  double compute_vector(int n) override;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Engine = the LAMMPS instance behind one C-API handle
+// ---------------------------------------------------------------------------------------------
+struct ThermoRow {
+  long step;
+  double temp, epair, emol, etotal, press, ke, pe;
+  double evdwl, ebond, virial[6];
+  long nbonds;
+};
+
+class Engine {
+ public:
+  Engine(int argc, char **argv);
+  ~Engine();
+
+  // ---- script layer (src/input.cpp:181 file, :327 one, :689 execute_command) ----
+  void file(const std::string &path);
+  const char *one(const std::string &line);  // returns the command name (borrowed), like Input::one
+  void execute(const std::string &cmd, std::vector<std::string> &arg);
+
+  // ---- global state ----
+  std::string units = "lj", atom_style = "atomic";
+  double boltz = 1, mvv2e = 1, ftm2v = 1, nktv2p = 1, dt = 0.005;
+  double skin = 0.3;
+  int neigh_every = 1, neigh_delay = 10, neigh_check = 1;
+  bool newton_pair = true, newton_bond = true;
+  int sortfreq = 1000;
+  long nextsort = 0;
+  double special_lj[4] = {1.0, 0.0, 0.0, 0.0};
+  double comm_cutoff = 0.0;
+  long ntimestep = 0, beginstep = 0, endstep = 0;
+  int thermo_every = 0;
+  bool thermo_norm = true;
+  std::vector<std::string> thermo_keywords;
+  bool box_exist = false;
+  Box box{};
+
+  // ---- atoms: host master copies in TAG order (tag t at index t-1) ----
+  int natoms = 0, ntypes = 0, nbondtypes = 0;
+  int extra_bond = 0, extra_special = 0, bpa = 0, maxspecial = 0;
+  long nbonds = 0;
+  std::vector<double> mass;                        // [ntypes+1]
+  std::vector<int> mass_set;
+  std::vector<double> x, v, f;                     // [natoms*3]
+  std::vector<int> type, image, molecule;          // image: 3 ints per atom
+  std::vector<int> num_bond, bond_type, bond_atom; // [natoms], [natoms*bpa]
+  std::vector<int> nspecial, special;              // [natoms*3], [natoms*maxspecial]
+  std::vector<int> crank;                          // canonical (reference local) index of tag t-1
+  bool special_built = false;
+  bool host_current = true;    // host x/v/f/type/topology reflect the device state
+  bool dev_current = false;    // device state reflects the host copies
+
+  // ---- styles ----
+  bool pair_lj = false, pair_zero = false;
+  double pair_cut_global = 0.0;
+  bool pair_shift = false;
+  int pair_mix = 0;  // 0 geometric, 1 arithmetic
+  std::vector<double> pc_eps, pc_sig, pc_cut;
+  std::vector<int> pc_set;
+  std::vector<double> lj1, lj2, lj3, lj4, offset, cutsq;
+  double cutforcemax = 0.0, cutneighmax = 0.0;
+  std::string bond_style_name;                    // "", "fene", "harmonic", "hybrid", "zero"
+  std::vector<std::string> bond_hybrid_styles;
+  BondTable bondtab{};
+
+  std::vector<std::unique_ptr<Fix>> fixes;
+  Fix *find_fix(const std::string &id);
+
+  // ---- run control (src/run.cpp:38-188, src/verlet.cpp) ----
+  void run(long nsteps);
+  void init();          // lmp->init(): pair coefficients, neighbor cutoffs, fix init, special lists
+  void setup();         // Verlet::setup
+  void iterate(long n); // Verlet::run
+  void compute_forces(bool eflag);
+  ThermoRow eval_thermo();
+  void print_thermo_header();
+  void print_thermo(const ThermoRow &);
+  ThermoRow last_thermo{};
+  std::vector<ThermoRow> thermo_log;
+  double loop_time = 0.0;
+  long neigh_builds = 0, neigh_dangerous = 0;
+  int ago = 0;
+  double timers[8] = {0};
+  bool kernel_timing = false;  // LAMMPS_LE_KERNEL_TIMING=1: HIP events around every force-kernel launch
+  double kstat_ms = 0.0;       // mean force-kernel duration of the last run (ms)
+  long kstat_n = 0;
+  double stat_neigh_pairs();   // stored full-list entries of the current neighbor list
+
+  // ---- topology on the host (read_data path) ----
+  void read_data(const std::string &path);
+  void write_data(const std::string &path);
+  void build_special();               // src/special.cpp:55-
+  void create_box_atoms_check();
+
+  // ---- device ----
+  DeviceState *dev = nullptr;
+  void device_init();                 // throws LammpsError if no HIP device
+  void upload();                      // host -> device (after read_data / scatter)
+  void download();                    // device -> host (x, v, f, type, image, topology)
+  void reneighbor();                  // pbc + spatial sort + cell lists + neighbor list + bond table
+  bool decide();                      // Neighbor::decide (src/neighbor.cpp:1933-1948)
+  void emulate_atom_sort();           // keep `crank` equal to the reference's local order (Atom::sort)
+  std::vector<long> le_reneigh_step;  // next_reneighbor per fix
+
+  // ---- output ----
+  FILE *screen = stdout, *logfile = nullptr;
+  bool echo_screen = false;
+  void say(const std::string &s);
+  void warning(const std::string &s);
+  std::string last_cmd;
+  std::map<std::string, std::string> variables;
+  std::string substitute(const std::string &line);
+
+  // error state for the C API (src/library.cpp LAMMPS_EXCEPTIONS behaviour)
+  std::string last_error;
+  bool has_error = false;
+
+  // extract_* scratch (borrowed pointers handed to the caller)
+  std::map<std::string, std::vector<double>> scratch_d;
+  std::map<std::string, std::vector<int>> scratch_i;
+  std::vector<double *> scratch_rows;
+  double scratch_scalar = 0.0;
+};
+
+// helpers
+double numeric(const std::string &s);
+int inumeric(const std::string &s);
+std::vector<std::string> split_words(const std::string &line);
+
+}  // namespace lmp_le

@@ -1,0 +1,233 @@
+// fixes.cpp — fix styles of the hot path, registered under the reference's style names
+// (src/fix_nve.h, src/fix_langevin.h, src/USER-LE/fix_extrusion.h:14-18, fix_ex_load.h, fix_ex_unload.h).
+// Argument grammars and error strings follow the reference constructors.
+#include <cstring>
+
+#include "device.h"
+
+namespace lmp_le {
+
+static void need_all(const std::vector<std::string> &arg) {
+  if (arg[1] != "all") throw LammpsError("MI355X engine: fix group must be 'all' (got " + arg[1] + ")");
+}
+
+// fix ID group nve  (src/fix_nve.cpp:33-45)
+FixNVE::FixNVE(Engine *e, const std::vector<std::string> &arg) {
+  eng = e; id = arg[0]; group = arg[1]; style = arg[2];
+  if (arg.size() < 3) throw LammpsError("Illegal fix nve command");
+  need_all(arg);
+  has_initial_integrate = has_final_integrate = true;
+}
+
+// fix ID group langevin Tstart Tstop damp seed  (src/fix_langevin.cpp:54-196)
+FixLangevin::FixLangevin(Engine *e, const std::vector<std::string> &arg) {
+  eng = e; id = arg[0]; group = arg[1]; style = arg[2];
+  if (arg.size() < 7) throw LammpsError("Illegal fix langevin command");
+  need_all(arg);
+  t_start = numeric(arg[3]);
+  t_stop = numeric(arg[4]);
+  t_period = numeric(arg[5]);
+  seed = inumeric(arg[6]);
+  if (t_period <= 0.0) throw LammpsError("Fix langevin period must be > 0.0");
+  if (seed <= 0) throw LammpsError("Illegal fix langevin command");
+  if (arg.size() > 7) throw LammpsError("MI355X engine: fix langevin optional keywords are not supported: " + arg[7]);
+  rng.seed(seed);   // seed + comm->me, me = 0
+  has_post_force = true;
+}
+
+// fix ID group extrusion N1 neutral ctcf_left ctcf_right through_prob btype [ctcf_left_right]
+// (src/USER-LE/fix_extrusion.cpp:38-142; narg < 8 is rejected but arg[8] is read, so 9 are needed)
+FixExtrusion::FixExtrusion(Engine *e, const std::vector<std::string> &arg) {
+  eng = e; id = arg[0]; group = arg[1]; style = arg[2];
+  if (arg.size() < 9) throw LammpsError("Illegal fix extrusion command");
+  need_all(arg);
+  nevery = inumeric(arg[3]);
+  if (nevery <= 0) throw LammpsError("Illegal fix extrusion command, n_steps <= 0");
+  neutral = inumeric(arg[4]); ctcf_left = inumeric(arg[5]); ctcf_right = inumeric(arg[6]);
+  if (neutral < 1 || neutral > e->ntypes || ctcf_left < 1 || ctcf_left > e->ntypes || ctcf_right < 1 ||
+      ctcf_right > e->ntypes)
+    throw LammpsError("Invalid atom type (CTCF) in fix extrusion command");
+  through_prob = numeric(arg[7]);
+  if (through_prob < 0 || through_prob > 1)
+    throw LammpsError("Invalid probability to pass through CTCF in fix extrusion command");
+  btype = inumeric(arg[8]);
+  if (btype < 1 || btype > e->nbondtypes) throw LammpsError("Invalid atom type in fix extrusion command");
+  ctcf_lr = (arg.size() == 10) ? inumeric(arg[9]) : -1;
+  e->say("Attention! Type of bidirectional CTCF is " + std::to_string(ctcf_lr) + "\n");
+  e->say("Amount of args in loop extrusion is " + std::to_string(arg.size()) + "\n");
+  if (ctcf_lr > e->ntypes) throw LammpsError("Invalid atom type in fix extrusion command");
+  if (e->atom_style == "atomic") throw LammpsError("Cannot use fix extrusion with non-molecular systems");
+  if (ctcf_lr == ctcf_left || ctcf_lr == ctcf_right)
+    throw LammpsError("MI355X engine: bidirectional CTCF type must differ from the left/right CTCF types");
+  rng.seed(12345);   // hard-coded 12345 + me (:98-99)
+  e->say("Attention! maxspecial = " + std::to_string(e->maxspecial) + "\n");
+  force_reneighbor = true;
+  has_post_integrate = true;
+}
+double FixExtrusion::compute_vector(int n) { return n == 0 ? (double)last_break : 0.0; }   // :1496-1501
+
+// fix ID group ex_load Nevery itype jtype Rmin bondtype [iparam ..] [jparam ..] [prob f seed] (:39-176)
+FixExLoad::FixExLoad(Engine *e, const std::vector<std::string> &arg) {
+  eng = e; id = arg[0]; group = arg[1]; style = arg[2];
+  if (arg.size() < 8) throw LammpsError("Illegal fix ex_load command");
+  need_all(arg);
+  nevery = inumeric(arg[3]);
+  if (nevery <= 0) throw LammpsError("Illegal fix ex_load command");
+  iatomtype = inumeric(arg[4]); jatomtype = inumeric(arg[5]);
+  double cutoff = numeric(arg[6]);
+  btype = inumeric(arg[7]);
+  if (iatomtype < 1 || iatomtype > e->ntypes || jatomtype < 1 || jatomtype > e->ntypes)
+    throw LammpsError("Invalid atom type in fix ex_load command");
+  if (cutoff < 0.0) throw LammpsError("Illegal fix ex_load command");
+  if (btype < 1 || btype > e->nbondtypes) throw LammpsError("Invalid bond type in fix ex_load command");
+  cutsq = cutoff * cutoff;
+  inewtype = iatomtype; jnewtype = jatomtype;
+  size_t iarg = 8;
+  while (iarg < arg.size()) {
+    if (arg[iarg] == "iparam") {
+      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      imaxbond = inumeric(arg[iarg + 1]); inewtype = inumeric(arg[iarg + 2]);
+      if (imaxbond < 0) throw LammpsError("Illegal fix ex_load command");
+      if (inewtype < 1 || inewtype > e->ntypes) throw LammpsError("Invalid atom type in fix ex_load command");
+      iarg += 3;
+    } else if (arg[iarg] == "jparam") {
+      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      jmaxbond = inumeric(arg[iarg + 1]); jnewtype = inumeric(arg[iarg + 2]);
+      if (jmaxbond < 0) throw LammpsError("Illegal fix ex_load command");
+      if (jnewtype < 1 || jnewtype > e->ntypes) throw LammpsError("Invalid atom type in fix ex_load command");
+      iarg += 3;
+    } else if (arg[iarg] == "prob") {
+      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      fraction = numeric(arg[iarg + 1]); seed = inumeric(arg[iarg + 2]);
+      if (fraction < 0.0 || fraction > 1.0) throw LammpsError("Illegal fix ex_load command");
+      if (seed <= 0) throw LammpsError("Illegal fix ex_load command");
+      iarg += 3;
+    } else if (arg[iarg] == "atype" || arg[iarg] == "dtype" || arg[iarg] == "itype") {
+      if (iarg + 2 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      if (inumeric(arg[iarg + 1]) != 0)
+        throw LammpsError("MI355X engine: fix ex_load angle/dihedral/improper creation is not supported");
+      iarg += 2;
+    } else throw LammpsError("Illegal fix ex_load command");
+  }
+  if (e->atom_style == "atomic") throw LammpsError("Cannot use fix ex_load with non-molecular systems");
+  if (iatomtype == jatomtype && (imaxbond != jmaxbond || inewtype != jnewtype))
+    throw LammpsError("Inconsistent iparam/jparam values in fix ex_load command");
+  rng.seed(seed);
+  force_reneighbor = true;
+  has_post_integrate = true;
+}
+void FixExLoad::init() {
+  // src/USER-LE/fix_ex_load.cpp:217-218
+  if (!eng->pair_lj) throw LammpsError("Fix ex_load cutoff is longer than pairwise cutoff");
+  int nt = eng->ntypes + 1;
+  if (cutsq > eng->cutsq[iatomtype * nt + jatomtype])
+    throw LammpsError("Fix ex_load cutoff is longer than pairwise cutoff");
+}
+double FixExLoad::compute_vector(int n) { return n == 0 ? (double)last_create : (double)total_create; }
+
+// fix ID group ex_unload Nevery bondtype Rmax [prob fraction seed]  (src/USER-LE/fix_ex_unload.cpp:34-115)
+FixExUnload::FixExUnload(Engine *e, const std::vector<std::string> &arg) {
+  eng = e; id = arg[0]; group = arg[1]; style = arg[2];
+  if (arg.size() < 6) throw LammpsError("Illegal fix ex_unload command");
+  need_all(arg);
+  nevery = inumeric(arg[3]);
+  if (nevery <= 0) throw LammpsError("Illegal fix ex_unload command");
+  btype = inumeric(arg[4]);
+  double cutoff = numeric(arg[5]);
+  if (btype < 1 || btype > e->nbondtypes) throw LammpsError("Invalid bond type in fix ex_unload command");
+  if (cutoff < 0.0) throw LammpsError("Illegal fix ex_unload command");
+  cutsq = cutoff * cutoff;
+  size_t iarg = 6;
+  while (iarg < arg.size()) {
+    if (arg[iarg] == "prob") {
+      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_unload command");
+      fraction = numeric(arg[iarg + 1]); seed = inumeric(arg[iarg + 2]);
+      if (fraction < 0.0 || fraction > 1.0) throw LammpsError("Illegal fix ex_unload command");
+      if (seed <= 0) throw LammpsError("Illegal fix ex_unload command");
+      iarg += 3;
+    } else throw LammpsError("Illegal fix ex_unload command");
+  }
+  rng.seed(seed);
+  force_reneighbor = true;
+  has_post_integrate = true;
+}
+double FixExUnload::compute_vector(int n) { return n == 0 ? (double)last_break : (double)total_break; }
+
+// ---------------------------------------------------------------------------------------------
+// post_integrate: firing rule + device launch + counter read-back (firing steps only)
+// ---------------------------------------------------------------------------------------------
+static int fix_index(Engine *e, Fix *f) {
+  for (size_t k = 0; k < e->fixes.size(); k++) if (e->fixes[k].get() == f) return (int)k;
+  return -1;
+}
+static int le_slot(Engine *e, Fix *f) {
+  int s = 0;
+  for (auto &g : e->fixes) {
+    if (g.get() == f) return s;
+    if (g->force_reneighbor) s++;
+  }
+  return s;
+}
+static void check_le_error(DeviceState &d, const char *style) {
+  int code = d.flags_h[FLAG_ERROR];
+  if (!code) return;
+  std::string st = style;
+  switch (code) {
+    case ERR_EXT_MULTI: throw LammpsError("Fix extrusion, more than one bond type 2");
+    case ERR_BPA: throw LammpsError("New bond exceeded bonds per atom in fix " + st);
+    case ERR_SPECIAL: throw LammpsError("New bond exceeded special list size in fix " + st);
+    case ERR_COUNT_MISMATCH: throw LammpsError("Numbers of created and broken bonds are not equal");
+    case ERR_SPECIAL_SCRATCH: throw LammpsError("Special list size exceeded in fix bond/create");
+    default: throw LammpsError("device error in fix " + st);
+  }
+}
+
+void FixExtrusion::post_integrate() {
+  if (eng->ntimestep % nevery - 1) return;               // src/USER-LE/fix_extrusion.cpp:265
+  DeviceState &d = *eng->dev;
+  int slot = le_slot(eng, this);
+  if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
+  if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
+  ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob};
+  launch_extrusion(d, p, slot);
+  sync_flags(d);
+  check_le_error(d, "extrusion");
+  last_break = d.flags_h[FLAG_COUNT_A];
+  int created = d.flags_h[FLAG_COUNT_B];
+  if (last_break != created) throw LammpsError("Numbers of created and broken bonds are not equal");
+  if (last_break) eng->le_reneigh_step[fix_index(eng, this)] = eng->ntimestep;
+}
+
+void FixExLoad::post_integrate() {
+  if (eng->ntimestep % nevery - 3) return;               // src/USER-LE/fix_ex_load.cpp:338
+  DeviceState &d = *eng->dev;
+  int slot = le_slot(eng, this);
+  if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
+  if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
+  ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction};
+  launch_ex_load(d, p, slot);
+  sync_flags(d);
+  check_le_error(d, "ex_load");
+  last_create = d.flags_h[FLAG_COUNT_A];
+  total_create += last_create;
+  eng->nbonds += last_create;
+  if (last_create) eng->le_reneigh_step[fix_index(eng, this)] = eng->ntimestep;
+}
+
+void FixExUnload::post_integrate() {
+  if (eng->ntimestep % nevery - 2) return;               // src/USER-LE/fix_ex_unload.cpp:178
+  DeviceState &d = *eng->dev;
+  int slot = le_slot(eng, this);
+  if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
+  if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
+  ExUnloadParams p{btype, cutsq, fraction};
+  launch_ex_unload(d, p, slot);
+  sync_flags(d);
+  check_le_error(d, "ex_unload");
+  last_break = d.flags_h[FLAG_COUNT_A];
+  total_break += last_break;
+  eng->nbonds -= last_break;
+  if (last_break) eng->le_reneigh_step[fix_index(eng, this)] = eng->ntimestep;
+}
+
+}  // namespace lmp_le

@@ -1,0 +1,622 @@
+// input.cpp — the script layer: the subset of the reference's input-script grammar that drives the
+// hot path.  Command names, argument order, defaults and error strings follow
+// src/input.cpp (file :181, one :327-355, execute_command :689-), src/read_data.cpp, src/atom.cpp
+// (data_atoms / data_bonds :1235-1282), src/special.cpp, src/force.cpp (special_bonds :748-).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "engine.h"
+
+namespace lmp_le {
+
+double numeric(const std::string &s) {
+  if (s.empty()) throw LammpsError("Expected floating point parameter instead of NULL or empty string");
+  char *end = nullptr;
+  double v = strtod(s.c_str(), &end);
+  if (*end != '\0') throw LammpsError("Expected floating point parameter instead of '" + s + "' in input script or data file");
+  return v;
+}
+int inumeric(const std::string &s) {
+  if (s.empty()) throw LammpsError("Expected integer parameter instead of NULL or empty string");
+  char *end = nullptr;
+  long v = strtol(s.c_str(), &end, 10);
+  if (*end != '\0') throw LammpsError("Expected integer parameter instead of '" + s + "' in input script or data file");
+  return (int)v;
+}
+std::vector<std::string> split_words(const std::string &line) {
+  std::vector<std::string> w;
+  size_t i = 0, n = line.size();
+  while (i < n) {
+    while (i < n && isspace((unsigned char)line[i])) i++;
+    if (i >= n) break;
+    if (line[i] == '"' || line[i] == '\'') {
+      char q = line[i++];
+      size_t j = line.find(q, i);
+      if (j == std::string::npos) throw LammpsError("Unbalanced quotes in input line");
+      w.push_back(line.substr(i, j - i));
+      i = j + 1;
+    } else {
+      size_t j = i;
+      while (j < n && !isspace((unsigned char)line[j])) j++;
+      w.push_back(line.substr(i, j - i));
+      i = j;
+    }
+  }
+  return w;
+}
+
+// ${name} and $x substitution (src/input.cpp:473- substitute), index/string/equal-constant variables only
+std::string Engine::substitute(const std::string &line) {
+  std::string out;
+  for (size_t i = 0; i < line.size(); i++) {
+    if (line[i] != '$') { out += line[i]; continue; }
+    std::string name;
+    if (i + 1 < line.size() && line[i + 1] == '{') {
+      size_t j = line.find('}', i);
+      if (j == std::string::npos) throw LammpsError("Invalid variable name");
+      name = line.substr(i + 2, j - i - 2);
+      i = j;
+    } else if (i + 1 < line.size()) {
+      name = line.substr(i + 1, 1);
+      i++;
+    }
+    auto it = variables.find(name);
+    if (it == variables.end()) throw LammpsError("Substitution for illegal variable " + name);
+    out += it->second;
+  }
+  return out;
+}
+
+void Engine::file(const std::string &path) {
+  std::ifstream in(path);
+  if (!in) throw LammpsError("Cannot open input script " + path);
+  std::string line, acc;
+  while (std::getline(in, line)) {
+    // '&' continuation (src/input.cpp:210-231)
+    size_t e = line.find_last_not_of(" \t\r\n");
+    if (e != std::string::npos && line[e] == '&') { acc += line.substr(0, e) + " "; continue; }
+    acc += line;
+    one(acc);
+    acc.clear();
+  }
+  if (!acc.empty()) one(acc);
+}
+
+const char *Engine::one(const std::string &raw) {
+  std::string line = raw;
+  // strip comments outside quotes
+  bool q1 = false, q2 = false;
+  for (size_t i = 0; i < line.size(); i++) {
+    if (line[i] == '"' && !q1) q2 = !q2;
+    else if (line[i] == '\'' && !q2) q1 = !q1;
+    else if (line[i] == '#' && !q1 && !q2) { line = line.substr(0, i); break; }
+  }
+  if (echo_screen) say(raw + "\n");
+  line = substitute(line);
+  std::vector<std::string> w = split_words(line);
+  if (w.empty()) { last_cmd.clear(); return nullptr; }
+  last_cmd = w[0];
+  std::vector<std::string> arg(w.begin() + 1, w.end());
+  execute(last_cmd, arg);
+  return last_cmd.c_str();
+}
+
+static void set_units(Engine *e, const std::string &u) {
+  // src/update.cpp:132-200
+  if (u == "lj") {
+    e->boltz = 1.0; e->mvv2e = 1.0; e->ftm2v = 1.0; e->nktv2p = 1.0; e->dt = 0.005; e->skin = 0.3;
+    e->thermo_norm = true;
+  } else if (u == "real") {
+    e->boltz = 0.0019872067; e->mvv2e = 48.88821291 * 48.88821291; e->ftm2v = 1.0 / 48.88821291 / 48.88821291;
+    e->nktv2p = 68568.415; e->dt = 1.0; e->skin = 2.0;
+    e->thermo_norm = false;
+  } else throw LammpsError("Illegal units command (MI355X engine supports lj and real)");
+  e->units = u;
+}
+
+// expand "*", "n*", "*m", "n*m" type ranges (src/utils.cpp bounds)
+static void bounds(const std::string &s, int nmax, int &lo, int &hi) {
+  size_t star = s.find('*');
+  if (star == std::string::npos) { lo = hi = inumeric(s); }
+  else {
+    lo = (star == 0) ? 1 : inumeric(s.substr(0, star));
+    hi = (star + 1 == s.size()) ? nmax : inumeric(s.substr(star + 1));
+  }
+  if (lo < 1 || hi > nmax || lo > hi) throw LammpsError("Numeric index is out of bounds");
+}
+
+void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
+  auto need = [&](size_t n) { if (arg.size() < n) throw LammpsError("Illegal " + cmd + " command"); };
+  if (cmd == "units") {
+    need(1);
+    if (box_exist) throw LammpsError("Units command after simulation box is defined");
+    set_units(this, arg[0]);
+  } else if (cmd == "atom_style") {
+    need(1);
+    if (box_exist) throw LammpsError("Atom_style command after simulation box is defined");
+    if (arg[0] != "bond" && arg[0] != "molecular" && arg[0] != "atomic" && arg[0] != "angle" && arg[0] != "full")
+      throw LammpsError("Unknown atom style " + arg[0]);
+    atom_style = arg[0];
+  } else if (cmd == "dimension") {
+    need(1);
+    if (inumeric(arg[0]) != 3) throw LammpsError("MI355X engine is 3d only");
+  } else if (cmd == "boundary") {
+    need(3);
+    for (int k = 0; k < 3; k++) if (arg[k] != "p") throw LammpsError("MI355X engine supports boundary p p p only");
+  } else if (cmd == "newton") {
+    need(1);
+    auto flag = [&](const std::string &s) {
+      if (s == "on") return true;
+      if (s == "off") return false;
+      throw LammpsError("Illegal newton command");
+    };
+    if (arg.size() == 1) newton_pair = newton_bond = flag(arg[0]);
+    else { newton_pair = flag(arg[0]); newton_bond = flag(arg[1]); }
+  } else if (cmd == "atom_modify") {
+    for (size_t i = 0; i < arg.size();) {
+      if (arg[i] == "sort") {
+        if (i + 3 > arg.size()) throw LammpsError("Illegal atom_modify command");
+        sortfreq = inumeric(arg[i + 1]);
+        if (sortfreq < 0) throw LammpsError("Illegal atom_modify command");
+        i += 3;
+      } else if (arg[i] == "map" || arg[i] == "first" || arg[i] == "id") {
+        if (i + 2 > arg.size()) throw LammpsError("Illegal atom_modify command");
+        i += 2;
+      } else throw LammpsError("Illegal atom_modify command");
+    }
+  } else if (cmd == "special_bonds") {
+    // src/force.cpp:748- set_special
+    need(1);
+    for (size_t i = 0; i < arg.size();) {
+      if (arg[i] == "fene") { special_lj[1] = 0.0; special_lj[2] = 1.0; special_lj[3] = 1.0; i++; }
+      else if (arg[i] == "lj" || arg[i] == "lj/coul") {
+        if (i + 4 > arg.size()) throw LammpsError("Illegal special_bonds command");
+        for (int k = 1; k <= 3; k++) {
+          special_lj[k] = numeric(arg[i + k]);
+          if (special_lj[k] < 0.0 || special_lj[k] > 1.0) throw LammpsError("Illegal special_bonds command");
+        }
+        i += 4;
+      } else if (arg[i] == "coul") { if (i + 4 > arg.size()) throw LammpsError("Illegal special_bonds command"); i += 4; }
+      else if (arg[i] == "charmm") { special_lj[1] = special_lj[2] = special_lj[3] = 0.0; i++; }
+      else if (arg[i] == "amber") { special_lj[1] = special_lj[2] = 0.0; special_lj[3] = 0.5; i++; }
+      else if (arg[i] == "angle" || arg[i] == "dihedral") { i += 2; }
+      else throw LammpsError("Illegal special_bonds command");
+    }
+    if (box_exist && natoms) { special_built = false; }
+  } else if (cmd == "read_data") {
+    need(1);
+    read_data(arg[0]);
+  } else if (cmd == "mass") {
+    need(2);
+    if (!box_exist) throw LammpsError("Mass command before simulation box is defined");
+    int lo, hi;
+    bounds(arg[0], ntypes, lo, hi);
+    double m = numeric(arg[1]);
+    if (m <= 0.0) throw LammpsError("Invalid mass value");
+    for (int t = lo; t <= hi; t++) { mass[t] = m; mass_set[t] = 1; }
+  } else if (cmd == "neighbor") {
+    need(2);
+    skin = numeric(arg[0]);
+    if (skin < 0.0) throw LammpsError("Illegal neighbor command");
+    if (arg[1] != "bin" && arg[1] != "nsq" && arg[1] != "multi") throw LammpsError("Illegal neighbor command");
+  } else if (cmd == "neigh_modify") {
+    for (size_t i = 0; i < arg.size();) {
+      if (i + 2 > arg.size()) throw LammpsError("Illegal neigh_modify command");
+      if (arg[i] == "every") { neigh_every = inumeric(arg[i + 1]); if (neigh_every <= 0) throw LammpsError("Illegal neigh_modify command"); }
+      else if (arg[i] == "delay") { neigh_delay = inumeric(arg[i + 1]); if (neigh_delay < 0) throw LammpsError("Illegal neigh_modify command"); }
+      else if (arg[i] == "check") {
+        if (arg[i + 1] == "yes") neigh_check = 1; else if (arg[i + 1] == "no") neigh_check = 0;
+        else throw LammpsError("Illegal neigh_modify command");
+      } else if (arg[i] == "one" || arg[i] == "page" || arg[i] == "binsize" || arg[i] == "once" || arg[i] == "cluster") {}
+      else throw LammpsError("Illegal neigh_modify command");
+      i += 2;
+    }
+  } else if (cmd == "comm_modify") {
+    for (size_t i = 0; i < arg.size();) {
+      if (i + 2 > arg.size()) throw LammpsError("Illegal comm_modify command");
+      if (arg[i] == "cutoff") comm_cutoff = numeric(arg[i + 1]);   // ghost cutoff: bonds use minimum image here
+      else if (arg[i] == "mode" || arg[i] == "vel" || arg[i] == "group") {}
+      else throw LammpsError("Illegal comm_modify command");
+      i += 2;
+    }
+  } else if (cmd == "bond_style") {
+    need(1);
+    if (atom_style == "atomic") throw LammpsError("Bond_style command when no bonds allowed");
+    bond_style_name = arg[0];
+    bond_hybrid_styles.clear();
+    for (int b = 0; b <= MAXTYPES; b++) bondtab.style[b] = 0;
+    if (arg[0] == "hybrid") {
+      for (size_t i = 1; i < arg.size(); i++) {
+        if (arg[i] != "fene" && arg[i] != "harmonic" && arg[i] != "zero") throw LammpsError("Unknown bond style " + arg[i]);
+        bond_hybrid_styles.push_back(arg[i]);
+      }
+      if (bond_hybrid_styles.empty()) throw LammpsError("Illegal bond_style command");
+    } else if (arg[0] != "fene" && arg[0] != "harmonic" && arg[0] != "zero" && arg[0] != "none")
+      throw LammpsError("Unknown bond style " + arg[0]);
+  } else if (cmd == "bond_coeff") {
+    need(1);
+    if (!box_exist) throw LammpsError("Bond_coeff command before simulation box is defined");
+    if (bond_style_name.empty() || bond_style_name == "none") throw LammpsError("Bond_coeff command before bond_style is defined");
+    int lo, hi;
+    bounds(arg[0], nbondtypes, lo, hi);
+    std::string st = bond_style_name;
+    size_t a0 = 1;
+    if (st == "hybrid") {
+      need(2);
+      st = arg[1];
+      if (std::find(bond_hybrid_styles.begin(), bond_hybrid_styles.end(), st) == bond_hybrid_styles.end())
+        throw LammpsError("Bond coeff for hybrid has invalid style");
+      a0 = 2;
+    }
+    for (int b = lo; b <= hi; b++) {
+      if (st == "fene") {
+        // K R0 epsilon sigma (src/MOLECULE/bond_fene.cpp:149-173)
+        if (arg.size() != a0 + 4) throw LammpsError("Incorrect args for bond coefficients");
+        bondtab.style[b] = 1;
+        bondtab.p0[b] = numeric(arg[a0]); bondtab.p1[b] = numeric(arg[a0 + 1]);
+        bondtab.p2[b] = numeric(arg[a0 + 2]); bondtab.p3[b] = numeric(arg[a0 + 3]);
+      } else if (st == "harmonic") {
+        // K r0 (src/MOLECULE/bond_harmonic.cpp:121-141)
+        if (arg.size() != a0 + 2) throw LammpsError("Incorrect args for bond coefficients");
+        bondtab.style[b] = 2;
+        bondtab.p0[b] = numeric(arg[a0]); bondtab.p1[b] = numeric(arg[a0 + 1]);
+      } else bondtab.style[b] = 0;
+    }
+  } else if (cmd == "pair_style") {
+    need(1);
+    pair_lj = pair_zero = false;
+    if (arg[0] == "lj/cut") {
+      need(2);
+      pair_lj = true;
+      pair_cut_global = numeric(arg[1]);
+    } else if (arg[0] == "zero") {
+      need(2);
+      pair_zero = true;
+      pair_cut_global = numeric(arg[1]);
+    } else if (arg[0] != "none") throw LammpsError("Unknown pair style " + arg[0]);
+    if (box_exist) {
+      int nt = ntypes + 1;
+      pc_eps.assign(nt * nt, 0.0); pc_sig = pc_cut = pc_eps; pc_set.assign(nt * nt, 0);
+    }
+  } else if (cmd == "pair_modify") {
+    for (size_t i = 0; i < arg.size();) {
+      if (i + 2 > arg.size()) throw LammpsError("Illegal pair_modify command");
+      if (arg[i] == "shift") {
+        if (arg[i + 1] == "yes") pair_shift = true; else if (arg[i + 1] == "no") pair_shift = false;
+        else throw LammpsError("Illegal pair_modify command");
+      } else if (arg[i] == "mix") {
+        if (arg[i + 1] == "geometric") pair_mix = 0; else if (arg[i + 1] == "arithmetic") pair_mix = 1;
+        else throw LammpsError("Illegal pair_modify command (MI355X engine: mix geometric|arithmetic)");
+      } else if (arg[i] == "tail") { if (arg[i + 1] != "no") throw LammpsError("MI355X engine: pair_modify tail yes not supported"); }
+      else throw LammpsError("Illegal pair_modify command");
+      i += 2;
+    }
+  } else if (cmd == "pair_coeff") {
+    // i j epsilon sigma [cut]  (src/pair_lj_cut.cpp:446-474)
+    if (!box_exist) throw LammpsError("Pair_coeff command before simulation box is defined");
+    if (!pair_lj && !pair_zero) throw LammpsError("Pair_coeff command before pair_style is defined");
+    if (pair_zero) return;
+    if (arg.size() < 4 || arg.size() > 5) throw LammpsError("Incorrect args for pair coefficients");
+    int ilo, ihi, jlo, jhi;
+    bounds(arg[0], ntypes, ilo, ihi);
+    bounds(arg[1], ntypes, jlo, jhi);
+    double eps = numeric(arg[2]), sig = numeric(arg[3]);
+    double cut = (arg.size() == 5) ? numeric(arg[4]) : pair_cut_global;
+    int nt = ntypes + 1, count = 0;
+    if ((int)pc_set.size() != nt * nt) { pc_eps.assign(nt * nt, 0.0); pc_sig = pc_cut = pc_eps; pc_set.assign(nt * nt, 0); }
+    for (int i = ilo; i <= ihi; i++)
+      for (int j = std::max(jlo, i); j <= jhi; j++) {
+        pc_eps[i * nt + j] = eps; pc_sig[i * nt + j] = sig; pc_cut[i * nt + j] = cut; pc_set[i * nt + j] = 1;
+        count++;
+      }
+    if (count == 0) throw LammpsError("Incorrect args for pair coefficients");
+  } else if (cmd == "fix") {
+    // src/modify.cpp:789-947 add_fix: ID group style args
+    if (arg.size() < 3) throw LammpsError("Illegal fix command");
+    if (!box_exist) throw LammpsError("Fix command before simulation box is defined");
+    if (find_fix(arg[0])) throw LammpsError("MI355X engine: replacing an existing fix ID is not supported: " + arg[0]);
+    std::unique_ptr<Fix> f;
+    const std::string &st = arg[2];
+    if (st == "nve") f.reset(new FixNVE(this, arg));
+    else if (st == "langevin") f.reset(new FixLangevin(this, arg));
+    else if (st == "extrusion") f.reset(new FixExtrusion(this, arg));
+    else if (st == "ex_load") f.reset(new FixExLoad(this, arg));
+    else if (st == "ex_unload") f.reset(new FixExUnload(this, arg));
+    else throw LammpsError("Unknown fix style " + st);
+    fixes.push_back(std::move(f));
+  } else if (cmd == "unfix") {
+    need(1);
+    auto it = std::find_if(fixes.begin(), fixes.end(), [&](const std::unique_ptr<Fix> &f) { return f->id == arg[0]; });
+    if (it == fixes.end()) throw LammpsError("Could not find fix ID to delete");
+    fixes.erase(it);
+  } else if (cmd == "thermo") {
+    need(1);
+    thermo_every = inumeric(arg[0]);
+    if (thermo_every < 0) throw LammpsError("Illegal thermo command");
+  } else if (cmd == "thermo_style") {
+    need(1);
+    if (arg[0] == "one") thermo_keywords = {"step", "temp", "epair", "emol", "etotal", "press"};
+    else if (arg[0] == "custom") {
+      if (arg.size() < 2) throw LammpsError("Illegal thermo style custom command");
+      thermo_keywords.assign(arg.begin() + 1, arg.end());
+    } else throw LammpsError("Illegal thermo_style command");
+  } else if (cmd == "thermo_modify") {
+    for (size_t i = 0; i < arg.size();) {
+      if (i + 2 > arg.size()) throw LammpsError("Illegal thermo_modify command");
+      if (arg[i] == "norm") thermo_norm = (arg[i + 1] == "yes");
+      else if (arg[i] == "format") { i += 3; continue; }
+      i += 2;
+    }
+  } else if (cmd == "timestep") {
+    need(1);
+    dt = numeric(arg[0]);
+  } else if (cmd == "reset_timestep") {
+    need(1);
+    ntimestep = atol(arg[0].c_str());
+  } else if (cmd == "run") {
+    need(1);
+    run(atol(arg[0].c_str()));
+  } else if (cmd == "write_data") {
+    need(1);
+    write_data(arg[0]);
+  } else if (cmd == "variable") {
+    need(3);
+    if (arg[1] == "index" || arg[1] == "string" || arg[1] == "equal") {
+      if (arg[1] == "index" && variables.count(arg[0])) return;   // command-line -var wins
+      variables[arg[0]] = arg[2];
+    } else throw LammpsError("MI355X engine: variable style " + arg[1] + " not supported");
+  } else if (cmd == "print") {
+    need(1);
+    say(arg[0] + "\n");
+  } else if (cmd == "echo" || cmd == "log" || cmd == "timer" || cmd == "processors" || cmd == "package" ||
+             cmd == "suffix" || cmd == "group" || cmd == "velocity_zero") {
+    if (cmd == "group" && !(arg.size() >= 1 && arg[0] == "all"))
+      throw LammpsError("MI355X engine: only group all is supported");
+  } else if (cmd == "clear") {
+    throw LammpsError("MI355X engine: clear is not supported; open a new instance");
+  } else {
+    throw LammpsError("Unknown command: " + cmd);   // src/input.cpp:352-353
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// read_data (src/read_data.cpp): header keywords incl. "extra bond per atom" (:1112) and
+// "extra special per atom" (:1124); sections Masses, Atoms (bond/molecular: id mol type x y z [ix iy iz];
+// full: id mol type q x y z [..]), Velocities, Bonds; bond coefficient sections are skipped.
+// ---------------------------------------------------------------------------------------------
+void Engine::read_data(const std::string &path) {
+  if (box_exist) throw LammpsError("MI355X engine: read_data can be used once per instance");
+  std::ifstream in(path);
+  if (!in) throw LammpsError("Cannot open file " + path);
+  std::string line;
+  std::getline(in, line);   // title
+  long nb_hdr = 0;
+  int na = 0;
+  bool have[3] = {false, false, false};
+  static const char *sections[] = {"Masses", "Atoms", "Velocities", "Bonds", "Angles", "Dihedrals", "Impropers",
+                                   "Pair Coeffs", "PairIJ Coeffs", "Bond Coeffs", "Angle Coeffs", "Dihedral Coeffs",
+                                   "Improper Coeffs", "BondBond Coeffs", "BondAngle Coeffs"};
+  auto strip = [](std::string s) {
+    size_t h = s.find('#');
+    if (h != std::string::npos) s = s.substr(0, h);
+    size_t b = s.find_first_not_of(" \t\r\n");
+    if (b == std::string::npos) return std::string();
+    size_t e = s.find_last_not_of(" \t\r\n");
+    return s.substr(b, e - b + 1);
+  };
+  auto is_section = [&](const std::string &s) -> const char * {
+    for (const char *sec : sections) if (s == sec) return sec;
+    return nullptr;
+  };
+  std::string section;
+  // header
+  while (std::getline(in, line)) {
+    std::string s = strip(line);
+    if (s.empty()) continue;
+    if (is_section(s)) { section = s; break; }
+    std::vector<std::string> w = split_words(s);
+    auto ends = [&](const char *suffix) {
+      std::string suf = suffix;
+      return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+    };
+    if (ends("atoms")) na = inumeric(w[0]);
+    else if (ends("bonds")) nb_hdr = atol(w[0].c_str());
+    else if (ends("angles") || ends("dihedrals") || ends("impropers")) {}
+    else if (ends("atom types")) ntypes = inumeric(w[0]);
+    else if (ends("bond types")) nbondtypes = inumeric(w[0]);
+    else if (ends("angle types") || ends("dihedral types") || ends("improper types")) {}
+    else if (ends("extra bond per atom")) extra_bond = inumeric(w[0]);
+    else if (ends("extra special per atom")) extra_special = inumeric(w[0]);
+    else if (ends("extra angle per atom") || ends("extra dihedral per atom") || ends("extra improper per atom")) {}
+    else if (ends("xlo xhi")) { box.lo[0] = numeric(w[0]); box.hi[0] = numeric(w[1]); have[0] = true; }
+    else if (ends("ylo yhi")) { box.lo[1] = numeric(w[0]); box.hi[1] = numeric(w[1]); have[1] = true; }
+    else if (ends("zlo zhi")) { box.lo[2] = numeric(w[0]); box.hi[2] = numeric(w[1]); have[2] = true; }
+    else if (ends("xy xz yz")) throw LammpsError("MI355X engine: triclinic boxes are not supported");
+    else throw LammpsError("Unknown identifier in data file: " + s);
+  }
+  if (!have[0] || !have[1] || !have[2]) throw LammpsError("Box bounds are missing in data file");
+  for (int d = 0; d < 3; d++) {
+    if (box.lo[d] >= box.hi[d]) throw LammpsError("Box bounds are invalid or missing");
+    box.prd[d] = box.hi[d] - box.lo[d];
+    box.half[d] = 0.5 * box.prd[d];
+  }
+  natoms = na;
+  box_exist = true;
+  mass.assign(ntypes + 1, 0.0);
+  mass_set.assign(ntypes + 1, 0);
+  x.assign(3 * (size_t)natoms, 0.0); v = f = x;
+  type.assign(natoms, 0); molecule.assign(natoms, 0); image.assign(3 * (size_t)natoms, 0);
+  crank.resize(natoms);
+  for (int i = 0; i < natoms; i++) crank[i] = -1;
+  std::vector<int> b_t, b_1, b_2;
+  bool atoms_read = false;
+  int file_rank = 0;
+  bool full = (atom_style == "full"), has_mol = (atom_style != "atomic");
+  // sections
+  while (!section.empty()) {
+    std::string cur = section;
+    section.clear();
+    while (std::getline(in, line)) {
+      std::string s = strip(line);
+      if (s.empty()) continue;
+      if (is_section(s)) { section = s; break; }
+      std::vector<std::string> w = split_words(s);
+      if (cur == "Masses") {
+        if (w.size() < 2) throw LammpsError("Invalid mass line in data file");
+        int t = inumeric(w[0]);
+        if (t < 1 || t > ntypes) throw LammpsError("Invalid type for mass set");
+        mass[t] = numeric(w[1]);
+        if (mass[t] <= 0.0) throw LammpsError("Invalid mass value");
+        mass_set[t] = 1;
+      } else if (cur == "Atoms") {
+        size_t base = 1 + (has_mol ? 1 : 0) + 1 + (full ? 1 : 0);   // id [mol] type [q]
+        if (w.size() != base + 3 && w.size() != base + 6) throw LammpsError("Incorrect atom format in data file");
+        int id = inumeric(w[0]);
+        if (id < 1 || id > natoms) throw LammpsError("MI355X engine: atom IDs must be 1..natoms");
+        int i = id - 1;
+        if (crank[i] >= 0) throw LammpsError("Duplicate atom IDs exist");
+        if (has_mol) molecule[i] = inumeric(w[1]);
+        type[i] = inumeric(w[has_mol ? 2 : 1]);
+        if (type[i] < 1 || type[i] > ntypes) throw LammpsError("Invalid atom type in Atoms section of data file");
+        for (int d = 0; d < 3; d++) x[3 * i + d] = numeric(w[base + d]);
+        if (w.size() == base + 6) for (int d = 0; d < 3; d++) image[3 * i + d] = inumeric(w[base + 3 + d]);
+        crank[i] = file_rank++;   // local order of the reference = file order (1 rank)
+        atoms_read = true;
+      } else if (cur == "Velocities") {
+        if (w.size() < 4) throw LammpsError("Incorrect velocity format in data file");
+        int id = inumeric(w[0]);
+        if (id < 1 || id > natoms) throw LammpsError("Invalid atom ID in Velocities section of data file");
+        for (int d = 0; d < 3; d++) v[3 * (id - 1) + d] = numeric(w[1 + d]);
+      } else if (cur == "Bonds") {
+        if (w.size() != 4) throw LammpsError("Incorrect format of Bonds section in data file");
+        int bt = inumeric(w[1]), a1 = inumeric(w[2]), a2 = inumeric(w[3]);
+        if (a1 <= 0 || a1 > natoms || a2 <= 0 || a2 > natoms || a1 == a2)
+          throw LammpsError("Invalid atom ID in Bonds section of data file");
+        if (bt <= 0 || bt > nbondtypes) throw LammpsError("Invalid bond type in Bonds section of data file");
+        b_t.push_back(bt); b_1.push_back(a1); b_2.push_back(a2);
+      }  // other sections are read and ignored
+    }
+  }
+  if (!atoms_read || file_rank != natoms) throw LammpsError("Did not assign all atoms correctly");
+  if ((long)b_t.size() != nb_hdr) throw LammpsError("Bonds assigned incorrectly");
+  // apply PBC to read-in coordinates is done at setup (Domain::pbc); remap like read_data's domain->remap
+  for (int i = 0; i < natoms; i++)
+    for (int d = 0; d < 3; d++) {
+      double &c = x[3 * i + d];
+      while (c < box.lo[d]) { c += box.prd[d]; image[3 * i + d]--; }
+      while (c >= box.hi[d]) { c -= box.prd[d]; image[3 * i + d]++; }
+    }
+  // bonds stored on both atoms: the LE fixes require newton_bond off semantics (SURVEY §0 req. 1);
+  // this engine always stores each bond with both of its atoms (src/atom.cpp:1269 newton_bond == 0)
+  nbonds = (long)b_t.size();
+  std::vector<int> cnt(natoms, 0);
+  for (size_t b = 0; b < b_t.size(); b++) { cnt[b_1[b] - 1]++; cnt[b_2[b] - 1]++; }
+  int mx = 0;
+  for (int c : cnt) mx = std::max(mx, c);
+  bpa = std::max(1, mx + extra_bond);
+  if (bpa > MAXBPA) throw LammpsError("MI355X engine: too many bonds per atom");
+  num_bond.assign(natoms, 0);
+  bond_type.assign((size_t)natoms * bpa, 0);
+  bond_atom.assign((size_t)natoms * bpa, 0);
+  for (size_t b = 0; b < b_t.size(); b++) {
+    int m = b_1[b] - 1;
+    bond_type[(size_t)m * bpa + num_bond[m]] = b_t[b]; bond_atom[(size_t)m * bpa + num_bond[m]] = b_2[b]; num_bond[m]++;
+    m = b_2[b] - 1;
+    bond_type[(size_t)m * bpa + num_bond[m]] = b_t[b]; bond_atom[(size_t)m * bpa + num_bond[m]] = b_1[b]; num_bond[m]++;
+  }
+  int nt = ntypes + 1;
+  pc_eps.assign(nt * nt, 0.0); pc_sig = pc_cut = pc_eps; pc_set.assign(nt * nt, 0);
+  special_built = false;
+  build_special();
+  host_current = true;
+  dev_current = false;
+  char buf[256];
+  snprintf(buf, sizeof buf, "  orthogonal box = (%g %g %g) to (%g %g %g)\n  %d atoms\n  %ld bonds\n  %d = max bonds/atom\n",
+           box.lo[0], box.lo[1], box.lo[2], box.hi[0], box.hi[1], box.hi[2], natoms, nbonds, mx);
+  say(buf);
+}
+
+// Special::build (src/special.cpp:55-): set semantics of onetwo/onethree/onefour + dedup + combine;
+// 1-3 / 1-4 are only built when their weights differ from 1.0 (:103-131)
+void Engine::build_special() {
+  bool do13 = !(special_lj[2] == 1.0 && special_lj[3] == 1.0), do14 = do13 && !(special_lj[3] == 1.0);
+  std::vector<std::vector<int>> l12(natoms), l13(natoms), l14(natoms);
+  auto has = [](const std::vector<int> &a, int val) { return std::find(a.begin(), a.end(), val) != a.end(); };
+  for (int i = 0; i < natoms; i++)
+    for (int m = 0; m < num_bond[i]; m++) {
+      int u = bond_atom[(size_t)i * bpa + m];
+      if (u != i + 1 && !has(l12[i], u)) l12[i].push_back(u);
+    }
+  if (do13)
+    for (int i = 0; i < natoms; i++)
+      for (int j : l12[i])
+        for (int k : l12[j - 1])
+          if (k != i + 1 && !has(l12[i], k) && !has(l13[i], k)) l13[i].push_back(k);
+  if (do14)
+    for (int i = 0; i < natoms; i++)
+      for (int j : l13[i])
+        for (int k : l12[j - 1])
+          if (k != i + 1 && !has(l12[i], k) && !has(l13[i], k) && !has(l14[i], k)) l14[i].push_back(k);
+  size_t maxall = 0;
+  for (int i = 0; i < natoms; i++) maxall = std::max(maxall, l12[i].size() + l13[i].size() + l14[i].size());
+  maxspecial = std::max<int>(1, (int)maxall + extra_special);
+  if (maxspecial > MS_MAX) throw LammpsError("MI355X engine: more than " + std::to_string(MS_MAX) + " special neighbors per atom");
+  nspecial.assign(3 * (size_t)natoms, 0);
+  special.assign((size_t)natoms * maxspecial, 0);
+  for (int i = 0; i < natoms; i++) {
+    int *sp = &special[(size_t)i * maxspecial];
+    int n = 0;
+    for (int u : l12[i]) sp[n++] = u;
+    nspecial[3 * i] = n;
+    for (int u : l13[i]) sp[n++] = u;
+    nspecial[3 * i + 1] = n;
+    for (int u : l14[i]) sp[n++] = u;
+    nspecial[3 * i + 2] = n;
+  }
+  special_built = true;
+  dev_current = false;
+  char buf[160];
+  snprintf(buf, sizeof buf, "Finding 1-2 1-3 1-4 neighbors ...\n  special bond factors lj:    %-8g %-8g %-8g\n  %d = max # of special neighbors\n",
+           special_lj[1], special_lj[2], special_lj[3], (int)maxall);
+  say(buf);
+}
+
+// write_data (src/write_data.cpp): header, Masses, Atoms (with image flags), Velocities, Bonds (each once)
+void Engine::write_data(const std::string &path) {
+  download();
+  FILE *fp = fopen(path.c_str(), "w");
+  if (!fp) throw LammpsError("Cannot open data file " + path);
+  fprintf(fp, "LAMMPS data file via write_data, MI355X engine, timestep = %ld\n\n", ntimestep);
+  fprintf(fp, "%d atoms\n%d atom types\n%ld bonds\n%d bond types\n", natoms, ntypes, nbonds, nbondtypes);
+  if (extra_bond) fprintf(fp, "%d extra bond per atom\n", extra_bond);
+  if (extra_special) fprintf(fp, "%d extra special per atom\n", extra_special);
+  fprintf(fp, "\n%.17g %.17g xlo xhi\n%.17g %.17g ylo yhi\n%.17g %.17g zlo zhi\n\nMasses\n\n", box.lo[0], box.hi[0], box.lo[1],
+          box.hi[1], box.lo[2], box.hi[2]);
+  for (int t = 1; t <= ntypes; t++) fprintf(fp, "%d %.17g\n", t, mass[t]);
+  fprintf(fp, "\nAtoms # %s\n\n", atom_style.c_str());
+  for (int i = 0; i < natoms; i++) {
+    if (atom_style == "atomic")
+      fprintf(fp, "%d %d %.17g %.17g %.17g %d %d %d\n", i + 1, type[i], x[3 * i], x[3 * i + 1], x[3 * i + 2], image[3 * i],
+              image[3 * i + 1], image[3 * i + 2]);
+    else
+      fprintf(fp, "%d %d %d %.17g %.17g %.17g %d %d %d\n", i + 1, molecule[i], type[i], x[3 * i], x[3 * i + 1], x[3 * i + 2],
+              image[3 * i], image[3 * i + 1], image[3 * i + 2]);
+  }
+  fprintf(fp, "\nVelocities\n\n");
+  for (int i = 0; i < natoms; i++) fprintf(fp, "%d %.17g %.17g %.17g\n", i + 1, v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+  if (nbonds) {
+    fprintf(fp, "\nBonds\n\n");
+    long k = 0;
+    for (int i = 0; i < natoms; i++)
+      for (int m = 0; m < num_bond[i]; m++) {
+        int u = bond_atom[(size_t)i * bpa + m];
+        if (i + 1 < u) fprintf(fp, "%ld %d %d %d\n", ++k, bond_type[(size_t)i * bpa + m], i + 1, u);
+      }
+  }
+  fclose(fp);
+}
+
+}  // namespace lmp_le

@@ -1,0 +1,270 @@
+// kernels_neigh.hip — reneighboring on the device: periodic wrap, spatial (cell) sort of the
+// physical arrays, bond-partner table, full neighbor list with special-bond encoding.
+//
+// Reference behaviour restated (the data structures are NOT the reference's):
+//   Domain::pbc                      src/domain.cpp:528-645   (wrap + image flags)
+//   NBinStandard / NPairHalfBin*     src/nbin_standard.cpp:192-232, src/npair_half_bin_newtoff.cpp:36-128
+//   NPair::find_special + flags      src/npair.h:112-136, src/neighbor.cpp:360-376, src/lmptype.h:61-62
+//   NTopoBondAll::build              src/ntopo_bond_all.cpp:39-86 (partner = closest image -> min image here)
+//   Neighbor::build xhold            src/neighbor.cpp:2048-2052
+//
+// MI355X design: cells of edge >= cutneigh, atoms re-sorted into cell order at every build
+// (deterministic: ties by tag), so a cell is a contiguous range and the 27-cell sweep of the list
+// build and the x-gathers of the pair kernel read L2-resident rows.  The list is a FULL list stored
+// column-major (neigh[k][p]) so that lane p's k-th neighbor load is coalesced and no force atomics
+// are needed.
+#include "device.h"
+
+namespace lmp_le {
+
+constexpr int BLOCK = 256;
+constexpr int SCAN_BLOCK = 1024;
+
+__global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__ pos, int *__restrict__ img, int npad,
+                                                    Box box, int ncx, int ncy, int ncz, double cix, double ciy,
+                                                    double ciz, int *__restrict__ cell_of,
+                                                    int *__restrict__ cell_count, int *__restrict__ flags) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n) return;
+  double4 r = pos[p];
+  if (!(isfinite(r.x) && isfinite(r.y) && isfinite(r.z))) {
+    flags[FLAG_ERROR] = ERR_NONFINITE;
+    cell_of[p] = 0;
+    atomicAdd(&cell_count[0], 1);
+    return;
+  }
+  double *c = &r.x;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    double x = c[d];
+    int im = img[d * npad + p];
+    if (x < box.lo[d]) { x += box.prd[d]; im--; }
+    if (x >= box.hi[d]) { x -= box.prd[d]; x = fmax(x, box.lo[d]); im++; }
+    c[d] = x;
+    img[d * npad + p] = im;
+  }
+  pos[p] = r;
+  int cx = (int)((r.x - box.lo[0]) * cix), cy = (int)((r.y - box.lo[1]) * ciy), cz = (int)((r.z - box.lo[2]) * ciz);
+  cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
+  int cell = (cz * ncy + cy) * ncx + cx;
+  cell_of[p] = cell;
+  atomicAdd(&cell_count[cell], 1);
+}
+
+// ---- exclusive scan of cell_count[0..m) into cell_start[0..m], three small kernels ----
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(int m, const int *__restrict__ in, int *__restrict__ out,
+                                                           int *__restrict__ blocksum) {
+  __shared__ int s[SCAN_BLOCK];
+  int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  int v = (i < m) ? in[i] : 0;
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+    int t = (threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (i < m) out[i] = s[threadIdx.x] - v;   // exclusive
+  if (threadIdx.x == SCAN_BLOCK - 1) blocksum[blockIdx.x] = s[threadIdx.x];
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(int nb, int *__restrict__ blocksum) {
+  // single block: exclusive scan of up to many block sums, SCAN_BLOCK at a time with a running carry
+  __shared__ int s[SCAN_BLOCK];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += SCAN_BLOCK) {
+    int i = base + threadIdx.x;
+    int v = (i < nb) ? blocksum[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+      int t = (threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int c = carry;
+    if (i < nb) blocksum[i] = c + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == SCAN_BLOCK - 1) carry = c + s[threadIdx.x];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int m, int *__restrict__ out, const int *__restrict__ blocksum,
+                                                         int total_slot_n) {
+  int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  if (i < m) out[i] += blocksum[blockIdx.x];
+  if (i == 0) out[m] = total_slot_n;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scatter(int n, const int *__restrict__ cell_of,
+                                                   const int *__restrict__ cell_start, int *__restrict__ cell_fill,
+                                                   int *__restrict__ perm) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n) return;
+  int c = cell_of[p];
+  int slot = cell_start[c] + atomicAdd(&cell_fill[c], 1);
+  perm[slot] = p;
+}
+// one thread per cell: order the cell's entries by tag so the final order is deterministic
+__global__ __launch_bounds__(BLOCK) void k_sort_cells(int ncells, const int *__restrict__ cell_start,
+                                                      int *__restrict__ perm, const int *__restrict__ tag) {
+  int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= ncells) return;
+  int b = cell_start[c], e = cell_start[c + 1];
+  for (int i = b + 1; i < e; i++) {
+    int pi = perm[i], ti = tag[pi], j = i - 1;
+    while (j >= b && tag[perm[j]] > ti) { perm[j + 1] = perm[j]; j--; }
+    perm[j + 1] = pi;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *__restrict__ perm,
+                                                   const double4 *__restrict__ pos, double4 *__restrict__ pos_new,
+                                                   double4 *__restrict__ xhold, const double *__restrict__ vx,
+                                                   const double *__restrict__ vy, const double *__restrict__ vz,
+                                                   double *__restrict__ vxn, double *__restrict__ vyn,
+                                                   double *__restrict__ vzn, const int *__restrict__ tag,
+                                                   int *__restrict__ tagn, const int *__restrict__ img,
+                                                   int *__restrict__ imgn, int *__restrict__ map) {
+  int s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= n) return;
+  int p = perm[s];
+  double4 r = pos[p];
+  pos_new[s] = r;
+  xhold[s] = r;
+  vxn[s] = vx[p]; vyn[s] = vy[p]; vzn[s] = vz[p];
+  int t = tag[p];
+  tagn[s] = t;
+  imgn[s] = img[p]; imgn[npad + s] = img[npad + p]; imgn[2 * npad + s] = img[2 * npad + p];
+  map[t] = s;
+}
+__global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, const int *__restrict__ tag,
+                                                      const int *__restrict__ map, const int *__restrict__ num_bond,
+                                                      const int *__restrict__ bond_type,
+                                                      const int *__restrict__ bond_atom, int maxtag,
+                                                      int *__restrict__ bpart, int *__restrict__ flags) {
+  int s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= n) return;
+  int t = tag[s];
+  int nb = num_bond[t];
+  for (int m = 0; m < bpa; m++) {
+    int e = -1;
+    if (m < nb) {
+      int bt = bond_type[(size_t)t * bpa + m];
+      int u = bond_atom[(size_t)t * bpa + m];
+      int q = (u >= 1 && u <= maxtag) ? map[u] : -1;
+      if (q < 0) flags[FLAG_ERROR] = ERR_BOND_MISSING;
+      else if (bt > 0) e = (bt << BOND_TYPE_SHIFT) | q;
+    }
+    bpart[(size_t)m * npad + s] = e;
+  }
+}
+
+// full neighbor list of atom s: sweep the 27 cells around its cell; entries in (stencil, index) order
+template <bool NOSPECIAL>
+__global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+                                                       const int *__restrict__ tag,
+                                                       const int *__restrict__ cell_start, int ncx, int ncy, int ncz,
+                                                       double cix, double ciy, double ciz, Box box, double cutneighsq,
+                                                       const int *__restrict__ nspecial,
+                                                       const int *__restrict__ special, int ms, int sf1, int sf2,
+                                                       int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
+                                                       int *__restrict__ flags) {
+  int s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= n) return;
+  double4 ri = pos[s];
+  int cx = (int)((ri.x - box.lo[0]) * cix), cy = (int)((ri.y - box.lo[1]) * ciy), cz = (int)((ri.z - box.lo[2]) * ciz);
+  cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
+  int n1 = 0, n2 = 0, n3 = 0;
+  const int *slist = nullptr;
+  if (!NOSPECIAL) {
+    int t = tag[s];
+    n1 = nspecial[3 * (size_t)t]; n2 = nspecial[3 * (size_t)t + 1]; n3 = nspecial[3 * (size_t)t + 2];
+    slist = special + (size_t)t * ms;
+  }
+  const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
+  int cnt = 0;
+  for (int dz = -1; dz <= 1; dz++) {
+    int az = cz + dz; if (az < 0) az += ncz; else if (az >= ncz) az -= ncz;
+    for (int dy = -1; dy <= 1; dy++) {
+      int ay = cy + dy; if (ay < 0) ay += ncy; else if (ay >= ncy) ay -= ncy;
+      for (int dx = -1; dx <= 1; dx++) {
+        int ax = cx + dx; if (ax < 0) ax += ncx; else if (ax >= ncx) ax -= ncx;
+        int c = (az * ncy + ay) * ncx + ax;
+        int b = cell_start[c], e = cell_start[c + 1];
+        for (int q = b; q < e; q++) {
+          if (q == s) continue;
+          double4 rj = pos[q];
+          double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
+          if (delx > hx) delx -= box.prd[0]; else if (delx < -hx) delx += box.prd[0];
+          if (dely > hy) dely -= box.prd[1]; else if (dely < -hy) dely += box.prd[1];
+          if (delz > hz) delz -= box.prd[2]; else if (delz < -hz) delz += box.prd[2];
+          double rsq = delx * delx + dely * dely + delz * delz;
+          if (rsq > cutneighsq) continue;
+          int entry = q;
+          if (!NOSPECIAL && n3 > 0) {
+            int tq = tag[q];
+            int which = 0;
+            for (int k = 0; k < n3; k++)
+              if (slist[k] == tq) { which = (k < n1) ? 1 : (k < n2) ? 2 : 3; break; }
+            if (which) {
+              int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
+              if (sf == 0) continue;                       // weight 0.0: excluded from the list
+              if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
+            }
+          }
+          if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
+          cnt++;
+        }
+      }
+    }
+  }
+  numneigh[s] = min(cnt, maxneigh);
+  if (cnt > maxneigh) flags[FLAG_NEIGH_OVERFLOW] = 1;
+  atomicMax(&flags[FLAG_MAXNEIGH], cnt);
+}
+
+void launch_reneighbor(DeviceState &d, double cutneighsq, const double sl[4], bool has_pair) {
+  int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
+  hipStream_t st = d.stream;
+  HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(d.ncells + 1) * sizeof(int), st));
+  HIP_CHECK(hipMemsetAsync(d.cell_fill, 0, (size_t)(d.ncells + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.img, d.npad, d.box, d.ncell[0],
+                     d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.cell_of, d.cell_count,
+                     d.flags);
+  int sb = (d.ncells + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, d.ncells, d.cell_count, d.cell_start,
+                     d.scan_tmp);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sb, d.scan_tmp);
+  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, st, d.ncells, d.cell_start, d.scan_tmp, n);
+  hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, n, d.cell_of, d.cell_start, d.cell_fill, d.perm);
+  hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
+                     d.cell_start, d.perm, d.tag);
+  hipLaunchKernelGGL(k_permute, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.perm, d.pos, d.pos_tmp, d.xhold, d.v[0],
+                     d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map);
+  std::swap(d.pos, d.pos_tmp);
+  for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
+  std::swap(d.tag, d.tag_tmp);
+  std::swap(d.img, d.img_tmp);
+  hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.bpa, d.tag, d.map, d.num_bond,
+                     d.bond_type, d.bond_atom, d.maxtag, d.bpart, d.flags);
+  if (has_pair) {
+    auto sflag = [](double w) { return w == 0.0 ? 0 : (w == 1.0 ? 1 : 2); };
+    int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
+    HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), st));
+    if (sf1 == 1 && sf2 == 1 && sf3 == 1)
+      hipLaunchKernelGGL((k_build_neigh<true>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag,
+                         d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2],
+                         d.box, cutneighsq, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3, d.neigh, d.numneigh,
+                         d.flags);
+    else
+      hipLaunchKernelGGL((k_build_neigh<false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag,
+                         d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2],
+                         d.box, cutneighsq, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3, d.neigh, d.numneigh,
+                         d.flags);
+  }
+}
+
+}  // namespace lmp_le

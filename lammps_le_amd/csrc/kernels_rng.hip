@@ -1,0 +1,137 @@
+// kernels_rng.hip — RanMars streams on the device, bit-exact with src/random_mars.cpp:81-95.
+//
+// FixLangevin draws 3 uniforms per bead per call from ONE serial generator
+// (src/fix_langevin.cpp:670-674); the value used for component c of the bead at canonical
+// position r in the k-th call is draw 3N*k + 3r + c of the stream.  The stream is cut into
+// blocks of B draws; block b keeps the 97-value history window in front of its first draw.  One
+// wavefront per block (a) generates its B draws 33 at a time (the lag-33 term forbids more),
+// (b) writes them as 24-bit integers, (c) advances its window by the fixed per-call jump 3N with
+// the precomputed polynomial x^(3N) mod (x^97 + x^64 - 1) (97 dot products of length 97).
+#include "device.h"
+
+namespace lmp_le {
+
+static constexpr uint32_t M24 = 0xFFFFFFu;
+
+__device__ __forceinline__ uint32_t c_of_dev(unsigned long long n) {
+  const unsigned long long CM = 16777213ull, CD = 7654321ull, C0 = 362436ull;
+  unsigned long long dec = (((n + 1) % CM) * CD) % CM;
+  return (uint32_t)((C0 + CM - dec) % CM);
+}
+
+constexpr int RNG_MAXB = 3072;
+
+__global__ __launch_bounds__(64) void k_rng_langevin(int B, long long total, unsigned long long first_raw,
+                                                     uint32_t *__restrict__ state, const uint32_t *__restrict__ jump,
+                                                     uint32_t *__restrict__ out) {
+  __shared__ uint32_t buf[97 + RNG_MAXB];
+  __shared__ uint32_t a[97];
+  int b = blockIdx.x, lane = threadIdx.x;
+  long long off = (long long)b * B;
+  int nout = (int)min((long long)B, total - off);
+  int G = max(nout, 96);
+  for (int k = lane; k < 97; k += 64) { buf[k] = state[(size_t)b * 97 + k]; a[k] = jump[k]; }
+  __syncthreads();
+  for (int base = 0; base < G; base += 33) {
+    int i = base + lane;
+    if (lane < 33 && i < G) buf[97 + i] = (buf[i] - buf[i + 64]) & M24;
+    __syncthreads();
+  }
+  for (int i = lane; i < nout; i += 64)
+    out[off + i] = (buf[97 + i] - c_of_dev(first_raw + (unsigned long long)(off + i))) & M24;
+  // window for the next call: y'[i] = sum_j a[j] * y[i + j]
+  uint32_t acc0 = 0, acc1 = 0;
+  int i1 = lane + 64;
+  for (int j = 0; j < 97; j++) {
+    uint32_t aj = a[j];
+    acc0 += aj * buf[lane + j];
+    if (i1 < 97) acc1 += aj * buf[i1 + j];
+  }
+  state[(size_t)b * 97 + lane] = acc0 & M24;
+  if (i1 < 97) state[(size_t)b * 97 + i1] = acc1 & M24;
+}
+
+void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
+  long long total = 3ll * natoms;
+  d.rng_B = 1536;
+  d.rng_nblocks = (int)((total + d.rng_B - 1) / d.rng_B);
+  if (d.rng_state) { (void)hipFree(d.rng_state); d.rng_state = nullptr; }
+  if (d.rng_jump) { (void)hipFree(d.rng_jump); d.rng_jump = nullptr; }
+  if (d.rng_out) { (void)hipFree(d.rng_out); d.rng_out = nullptr; }
+  HIP_CHECK(hipMalloc(&d.rng_state, (size_t)d.rng_nblocks * 97 * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&d.rng_jump, 97 * sizeof(uint32_t)));
+  HIP_CHECK(hipMalloc(&d.rng_out, (size_t)total * sizeof(uint32_t)));
+  std::vector<uint32_t> st((size_t)d.rng_nblocks * 97);
+  RanMarsInt r = host_rng;   // positioned at the first draw of the next call
+  for (int b = 0; b < d.rng_nblocks; b++) {
+    for (int k = 0; k < 97; k++) st[(size_t)b * 97 + k] = r.w[k];
+    if (b + 1 < d.rng_nblocks) for (int k = 0; k < d.rng_B; k++) r.next_raw();
+  }
+  uint32_t a[97];
+  ranmars_jump_poly((uint64_t)total, a);
+  HIP_CHECK(hipMemcpyAsync(d.rng_state, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.stream));
+  HIP_CHECK(hipMemcpyAsync(d.rng_jump, a, sizeof a, hipMemcpyHostToDevice, d.stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+}
+
+void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
+  long long total = 3ll * d.n;
+  hipLaunchKernelGGL(k_rng_langevin, dim3(d.rng_nblocks), dim3(64), 0, d.stream, d.rng_B, total,
+                     (unsigned long long)first_raw, d.rng_state, d.rng_jump, d.rng_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// serial-stream generator for the LE fixes: `count` (device-resident) draws from one RanMars state,
+// one wavefront, 33 values per dependent step through a 256-entry LDS ring.
+// state layout: w[0..96] = y_{n-97..n-1}, [97] = n low, [98] = n high
+__global__ __launch_bounds__(64) void k_ranmars_gen(uint32_t *__restrict__ state, const int *__restrict__ count_ptr,
+                                                    uint32_t *__restrict__ out, int maxout) {
+  __shared__ uint32_t ring[256];
+  int lane = threadIdx.x;
+  int count = min(*count_ptr, maxout);
+  unsigned long long n0 = (unsigned long long)state[97] | ((unsigned long long)state[98] << 32);
+  for (int k = lane; k < 97; k += 64) ring[k] = state[k];    // position i holds y_{n0-97+i}
+  __syncthreads();
+  for (int base = 0; base < count; base += 33) {
+    int i = base + lane;                                      // draw index within this call
+    if (lane < 33 && i < count) {
+      uint32_t y = (ring[i & 255] - ring[(i + 64) & 255]) & M24;
+      ring[(i + 97) & 255] = y;
+      out[i] = (y - c_of_dev(n0 + (unsigned long long)i)) & M24;
+    }
+    __syncthreads();
+  }
+  uint32_t w0 = 0, w1 = 0;
+  w0 = ring[(count + lane) & 255];
+  if (lane + 64 < 97) w1 = ring[(count + lane + 64) & 255];
+  __syncthreads();
+  state[lane] = w0;
+  if (lane + 64 < 97) state[lane + 64] = w1;
+  if (lane == 0) {
+    unsigned long long n1 = n0 + (unsigned long long)count;
+    state[97] = (uint32_t)(n1 & 0xFFFFFFFFull);
+    state[98] = (uint32_t)(n1 >> 32);
+  }
+}
+
+void launch_ranmars_gen(DeviceState &d, int slot, const int *count_ptr, uint32_t *out, int maxout) {
+  hipLaunchKernelGGL(k_ranmars_gen, dim3(1), dim3(64), 0, d.stream, d.le_rng_state + slot * 100, count_ptr, out,
+                     maxout);
+}
+void le_rng_upload(DeviceState &d, int slot, const RanMarsInt &r) {
+  uint32_t st[100] = {0};
+  for (int k = 0; k < 97; k++) st[k] = r.w[k];
+  st[97] = (uint32_t)(r.n & 0xFFFFFFFFull);
+  st[98] = (uint32_t)(r.n >> 32);
+  HIP_CHECK(hipMemcpyAsync(d.le_rng_state + slot * 100, st, sizeof st, hipMemcpyHostToDevice, d.stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+}
+void le_rng_download(DeviceState &d, int slot, RanMarsInt &r) {
+  uint32_t st[100];
+  HIP_CHECK(hipMemcpyAsync(st, d.le_rng_state + slot * 100, sizeof st, hipMemcpyDeviceToHost, d.stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+  for (int k = 0; k < 97; k++) r.w[k] = st[k];
+  r.n = (uint64_t)st[97] | ((uint64_t)st[98] << 32);
+}
+
+}  // namespace lmp_le

@@ -1,0 +1,271 @@
+"""Test infrastructure: synthetic bead-spring systems, data-file writer, and a small interpreter
+that drives the CPU oracle from the SAME in.* script text the product engine runs.
+"""
+import os
+
+import numpy as np
+
+from oracle import Oracle
+
+
+# ------------------------------------------------------------------------------------------
+def lattice_chain(nbeads, nchains=1, density=0.85, seed=1, jitter=0.03, temp=1.0, types=None):
+    """nchains chains of nbeads/nchains beads laid along a serpentine path through a simple-cubic
+    lattice (no overlaps, every bond = lattice spacing); small seeded jitter and Maxwell velocities."""
+    rng = np.random.RandomState(seed)
+    n = nbeads
+    a = (1.0 / density) ** (1.0 / 3.0)
+    L = int(np.ceil(n ** (1.0 / 3.0)))
+    k = np.arange(n)
+    iz = k // (L * L)
+    yy = (k % (L * L)) // L
+    col = k % L
+    iy = np.where(iz % 2 == 0, yy, L - 1 - yy)
+    ix = np.where((k // L) % 2 == 0, col, L - 1 - col)
+    pts = np.stack([ix, iy, iz], axis=1).astype(np.float64) * a
+    box = np.array([[0.0, L * a]] * 3)
+    x = pts + 0.5 * a + rng.uniform(-jitter, jitter, size=(n, 3))
+    v = rng.normal(0.0, np.sqrt(temp), size=(n, 3))
+    v -= v.mean(axis=0)
+    per = n // nchains
+    bonds = []
+    for c in range(nchains):
+        lo = c * per
+        hi = n if c == nchains - 1 else (c + 1) * per
+        for i in range(lo, hi - 1):
+            bonds.append((1, i + 1, i + 2))
+    typ = np.ones(n, dtype=np.int32) if types is None else np.asarray(types, dtype=np.int32)
+    mol = np.minimum(np.arange(n) // per, nchains - 1).astype(np.int32) + 1
+    return dict(box=box, x=x, v=v, type=typ, mol=mol, image=np.zeros((n, 3), dtype=np.int32),
+                bonds=np.array(bonds, dtype=np.int32).reshape(-1, 3), ntypes=int(typ.max()), nbondtypes=2,
+                mass=[1.0] * int(typ.max()), extra_bond=1, extra_special=20, atom_style="bond")
+
+
+def write_data(path, s):
+    n = len(s["x"])
+    with open(path, "w") as fh:
+        fh.write("synthetic bead-spring system\n\n")
+        fh.write("%d atoms\n%d atom types\n%d bonds\n%d bond types\n" % (n, s["ntypes"], len(s["bonds"]), s["nbondtypes"]))
+        if s.get("extra_bond"):
+            fh.write("%d extra bond per atom\n" % s["extra_bond"])
+        if s.get("extra_special"):
+            fh.write("%d extra special per atom\n" % s["extra_special"])
+        fh.write("\n")
+        for d, nm in enumerate("xyz"):
+            fh.write("%.17g %.17g %slo %shi\n" % (s["box"][d][0], s["box"][d][1], nm, nm))
+        fh.write("\nMasses\n\n")
+        for t, m in enumerate(s["mass"]):
+            fh.write("%d %.17g\n" % (t + 1, m))
+        fh.write("\nAtoms\n\n")
+        x, typ, mol, img = s["x"], s["type"], s["mol"], s["image"]
+        order = s.get("file_order", np.arange(n))
+        for i in order:
+            fh.write("%d %d %d %.17g %.17g %.17g %d %d %d\n" % (i + 1, mol[i], typ[i], x[i, 0], x[i, 1], x[i, 2],
+                                                            img[i, 0], img[i, 1], img[i, 2]))
+        fh.write("\nVelocities\n\n")
+        v = s["v"]
+        for i in range(n):
+            fh.write("%d %.17g %.17g %.17g\n" % (i + 1, v[i, 0], v[i, 1], v[i, 2]))
+        if len(s["bonds"]):
+            fh.write("\nBonds\n\n")
+            for k, (bt, a, b) in enumerate(s["bonds"]):
+                fh.write("%d %d %d %d\n" % (k + 1, bt, a, b))
+
+
+def wrap_into_box(s):
+    """What read_data does to the coordinates it reads (domain->remap): wrap + image flags."""
+    x = s["x"].copy()
+    img = s["image"].copy()
+    for d in range(3):
+        lo, hi = s["box"][d]
+        prd = hi - lo
+        while True:
+            m = x[:, d] < lo
+            if not m.any():
+                break
+            x[m, d] += prd
+            img[m, d] -= 1
+        while True:
+            m = x[:, d] >= hi
+            if not m.any():
+                break
+            x[m, d] -= prd
+            img[m, d] += 1
+    return x, img
+
+
+# ------------------------------------------------------------------------------------------
+class OracleScript:
+    """Feed LAMMPS script lines to the oracle (the subset of commands of SURVEY §8b(1))."""
+
+    def __init__(self, system):
+        self.sys = system
+        self.o = None
+        self.units = "lj"
+        self.special = (0.0, 0.0, 0.0)
+        self.pending = []
+        self.bond_style = None
+        self.hybrid = []
+        self.shift = False
+        self.mix = "geometric"
+
+    def _make(self):
+        s = self.sys
+        n = len(s["x"])
+        o = Oracle(n, s["ntypes"], s["nbondtypes"], s.get("extra_bond", 0), s.get("extra_special", 0))
+        o.units(self.units)
+        box = np.asarray(s["box"])
+        o.box(box[:, 0], box[:, 1])
+        for t, m in enumerate(s["mass"]):
+            o.mass(t + 1, m)
+        x, img = wrap_into_box(s)
+        order = s.get("file_order", np.arange(n))
+        tag = (np.asarray(order) + 1).astype(np.int32)
+        o.atoms(tag, s["type"][order], x[order], s["v"][order], img[order])
+        o.bonds(s["bonds"])
+        o.special_bonds(*self.special)
+        self.o = o
+
+    def line(self, text):
+        text = text.split("#")[0].strip()
+        if not text:
+            return
+        w = text.split()
+        c, a = w[0], w[1:]
+        o = self.o
+        if c == "units":
+            self.units = a[0]
+        elif c in ("atom_style", "newton", "comm_modify", "boundary", "thermo_style", "thermo_modify", "echo", "log"):
+            pass
+        elif c == "atom_modify":
+            if a[0] == "sort":
+                self.sort = int(a[1])
+                if o:
+                    o.atom_sort(self.sort)
+        elif c == "special_bonds":
+            self.special = (0.0, 1.0, 1.0) if a[0] == "fene" else tuple(float(v) for v in a[1:4])
+            if o:
+                o.special_bonds(*self.special)
+        elif c == "read_data":
+            self._make()
+            if hasattr(self, "sort"):
+                self.o.atom_sort(self.sort)
+        elif c == "neighbor":
+            o.neighbor(skin=float(a[0]))
+        elif c == "neigh_modify":
+            kw = dict(zip(a[::2], a[1::2]))
+            o.neighbor(every=int(kw.get("every", 0)), delay=int(kw.get("delay", -1)),
+                       check={"yes": 1, "no": 0, None: -1}[kw.get("check")])
+        elif c == "bond_style":
+            self.bond_style = a[0]
+            self.hybrid = a[1:]
+        elif c == "bond_coeff":
+            st = self.bond_style
+            vals = a[1:]
+            if st == "hybrid":
+                st, vals = a[1], a[2:]
+            types = range(1, self.sys["nbondtypes"] + 1) if a[0] == "*" else [int(a[0])]
+            for bt in types:
+                o.bond_coeff(bt, st, *[float(v) for v in vals])
+        elif c == "pair_style":
+            self.pair_cut = float(a[1])
+            self._pair = True
+            o.pair_lj_cut(self.pair_cut, self.shift, self.mix)
+        elif c == "pair_modify":
+            kw = dict(zip(a[::2], a[1::2]))
+            if "shift" in kw:
+                self.shift = kw["shift"] == "yes"
+            if "mix" in kw:
+                self.mix = kw["mix"]
+            o.pair_lj_cut(self.pair_cut, self.shift, self.mix)
+        elif c == "pair_coeff":
+            def rng(tok):
+                nt = self.sys["ntypes"]
+                if "*" not in tok:
+                    return [int(tok)]
+                lo, hi = tok.split("*")
+                return range(int(lo) if lo else 1, (int(hi) if hi else nt) + 1)
+            for i in rng(a[0]):
+                for j in rng(a[1]):
+                    if j >= i:
+                        o.pair_coeff(i, j, float(a[2]), float(a[3]), float(a[4]) if len(a) > 4 else -1.0)
+        elif c == "fix":
+            fid, style, p = a[0], a[2], a[3:]
+            if style == "nve":
+                o.fix_nve(fid)
+            elif style == "langevin":
+                o.fix_langevin(float(p[0]), float(p[1]), float(p[2]), int(p[3]), fid)
+            elif style == "extrusion":
+                o.fix_extrusion(int(p[0]), int(p[1]), int(p[2]), int(p[3]), float(p[4]), int(p[5]),
+                                int(p[6]) if len(p) > 6 else -1, fid)
+            elif style == "ex_load":
+                kw = dict(imax=0, inew=None, jmax=0, jnew=None, fraction=1.0, seed=12345)
+                k = 4
+                while k < len(p):
+                    if p[k] == "iparam":
+                        kw["imax"], kw["inew"] = int(p[k + 1]), int(p[k + 2])
+                    elif p[k] == "jparam":
+                        kw["jmax"], kw["jnew"] = int(p[k + 1]), int(p[k + 2])
+                    elif p[k] == "prob":
+                        kw["fraction"], kw["seed"] = float(p[k + 1]), int(p[k + 2])
+                    k += 3
+                o.fix_ex_load(int(p[0]), int(p[1]), int(p[2]), float(p[3]), int(p[4]), fid=fid, **kw)
+            elif style == "ex_unload":
+                kw = dict(fraction=1.0, seed=12345)
+                if len(p) > 3 and p[3] == "prob":
+                    kw["fraction"], kw["seed"] = float(p[4]), int(p[5])
+                o.fix_ex_unload(int(p[0]), int(p[1]), float(p[2]), fid=fid, **kw)
+            else:
+                raise ValueError("oracle script: unknown fix " + style)
+        elif c == "timestep":
+            o.timestep(float(a[0]))
+        elif c == "thermo":
+            o.thermo_every(int(a[0]))
+        elif c == "run":
+            o.run(int(a[0]))
+        else:
+            raise ValueError("oracle script: unknown command " + c)
+
+    def run(self, script):
+        for ln in script.split("\n"):
+            self.line(ln)
+        return self.o
+
+
+def run_oracle(script, system):
+    return OracleScript(system).run(script)
+
+
+def run_product(script, system, tmpdir, cmdargs=("-screen", "none")):
+    """Run the same script on the product engine (through the C-ABI); the data file named in the
+    script's read_data line is written into tmpdir."""
+    from lammps_le_amd import lammps
+    lmp = lammps(cmdargs=list(cmdargs))
+    for ln in script.split("\n"):
+        w = ln.split("#")[0].split()
+        if w and w[0] == "read_data":
+            path = os.path.join(str(tmpdir), os.path.basename(w[1]))
+            write_data(path, system)
+            ln = "read_data " + path
+        lmp.command(ln)
+    return lmp
+
+
+CHAIN_SCRIPT = """
+units lj
+atom_style bond
+newton off
+atom_modify sort 0 0
+special_bonds fene
+read_data data.chain
+neighbor 0.4 bin
+neigh_modify every 1 delay 1 check yes
+comm_modify cutoff 5.0
+bond_style fene
+bond_coeff 1 30.0 1.5 1.0 1.0
+bond_coeff 2 30.0 4.0 1.0 1.0
+pair_style lj/cut 1.12
+pair_modify shift yes
+pair_coeff * * 1.0 1.0 1.12
+timestep 0.005
+"""
