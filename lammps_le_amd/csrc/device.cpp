@@ -66,13 +66,13 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   for (int k = 0; k < NFLAGS; k++) d.flags_h[k] = 0;
   // LE fix scratch
   dalloc(d.xt, nt);
-  for (int k = 0; k < 8; k++) dalloc(d.le_i[k], nt);
+  for (int k = 0; k < 16; k++) dalloc(d.le_i[k], nt);
   for (int k = 0; k < 2; k++) dalloc(d.le_d[k], nt);
-  dalloc(d.le_bits, nt / 64 + 4);
+  dalloc(d.le_bits, nt / 64 + 16);
   dalloc(d.le_rng_state, 3 * 100);
   dalloc(d.le_draws, nt);
   dalloc(d.le_list, 4 * nt);
-  dalloc(d.le_scan, nt + 1024);
+  dalloc(d.le_scan, nt / 1024 + 16);
 }
 
 void dev_free(DeviceState &d) {
@@ -90,7 +90,7 @@ void dev_free(DeviceState &d) {
   d.flags_h = nullptr;
   dfree(d.rng_state); dfree(d.rng_jump); dfree(d.rng_out);
   dfree(d.xt);
-  for (int k = 0; k < 8; k++) dfree(d.le_i[k]);
+  for (int k = 0; k < 16; k++) dfree(d.le_i[k]);
   for (int k = 0; k < 2; k++) dfree(d.le_d[k]);
   dfree(d.le_bits); dfree(d.le_rng_state); dfree(d.le_draws); dfree(d.le_list); dfree(d.le_scan);
   if (d.stream) (void)hipStreamDestroy(d.stream);

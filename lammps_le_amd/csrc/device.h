@@ -86,7 +86,7 @@ struct DeviceState {
   uint32_t *rng_out = nullptr;     // [3N] 24-bit draws of the current call, canonical order
   // ---- LE fixes (tag order) ----
   double4 *xt = nullptr;           // [maxtag+2] stored coordinates by tag
-  int *le_i[8] = {nullptr};        // integer scratch arrays [maxtag+2]
+  int *le_i[16] = {nullptr};       // integer scratch arrays [maxtag+2]
   double *le_d[2] = {nullptr};     // double scratch [maxtag+2]
   unsigned long long *le_bits = nullptr;
   uint32_t *le_rng_state = nullptr;   // [3][100]: w[97], n_lo, n_hi per LE fix slot

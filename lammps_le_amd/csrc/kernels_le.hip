@@ -1,7 +1,645 @@
-// kernels_le.hip — USER-LE fixes on the device (placeholder launchers; implemented below in steps)
+// kernels_le.hip — the USER-LE fixes (extruder load / step / unload) as data-parallel HIP kernels.
+//
+// The reference implements each fix as serial loops whose result depends on visit order
+// (src/USER-LE/fix_ex_load.cpp:329-655, fix_extrusion.cpp:256-872, fix_ex_unload.cpp:172-372).
+// Here every phase is a kernel over beads (tag order, index = atom ID) or over extruder listings,
+// re-derived so that the outcome is IDENTICAL to the serial loops at the canonical configuration
+// (1 rank, newton off, atom_modify sort 0 0: local index = ID - 1; SURVEY §8a "order dependence"):
+//
+//  ex_load   accepted(a) = base(a) AND NOT accepted(a-1) for pair a = (a, a+2)  (the partner[mid] test,
+//            fix_ex_load.cpp:471-476,484) -> parity of the run of set bits below a in a ballot bitmask;
+//            closest-wins partner; k-th bead with a partner gets the k-th RanMars draw (prefix sum).
+//  extrusion listings (bond-list entries, double for bonds that straddle a periodic face,
+//            ntopo_bond_all.cpp:66-67) in order; RNG draws by prefix sum of the per-listing draw counts
+//            (barrier beads only, short-circuit order L then R, fix_extrusion.cpp:406-429); the
+//            closest-wins / first-wins writes of phase 1 resolved per target bead from <= 4 claim events;
+//            phases 2-4 per bead / per extruder (they only touch their own extruder's beads).
+//  ex_unload farthest-wins partner over own bonds with the image frozen at the last reneighbor.
+//  special lists: rebuild_special_one / dedup exactly as fix_extrusion.cpp:1045-1135, O(events).
 #include "device.h"
+
 namespace lmp_le {
-void launch_ex_load(DeviceState &, const ExLoadParams &, int) { throw LammpsError("fix ex_load: device path not built"); }
-void launch_ex_unload(DeviceState &, const ExUnloadParams &, int) { throw LammpsError("fix ex_unload: device path not built"); }
-void launch_extrusion(DeviceState &, const ExtrusionParams &, int) { throw LammpsError("fix extrusion: device path not built"); }
+
+constexpr int BLOCK = 256;
+constexpr int SCAN_BLOCK = 1024;
+#define BIGD 1.0e20
+
+// integer scratch slots (tag-indexed arrays of length T+2)
+enum { I_BC = 0, I_A, I_B, I_C, I_D, I_E, I_F, I_G, I_H, I_J, I_K, I_L, I_M, I_N, I_O, I_P };
+
+struct Topo {   // tag-indexed topology views
+  int T, bpa, ms;
+  int *num_bond, *bond_type, *bond_atom, *nspecial, *special, *type_t;
+};
+static Topo topo_of(DeviceState &d) {
+  return Topo{d.maxtag, d.bpa, d.maxspecial, d.num_bond, d.bond_type, d.bond_atom, d.nspecial, d.special, d.type_t};
 }
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of in[0..m) -> out[0..m], out[m] = total, also written to *total_slot
+__global__ __launch_bounds__(SCAN_BLOCK) void k_lscan_local(int m, const int *__restrict__ in, int *__restrict__ out,
+                                                            int *__restrict__ blocksum) {
+  __shared__ int s[SCAN_BLOCK];
+  int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  int v = (i < m) ? in[i] : 0;
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+    int t = (threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (i < m) out[i] = s[threadIdx.x] - v;
+  if (threadIdx.x == SCAN_BLOCK - 1) blocksum[blockIdx.x] = s[threadIdx.x];
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_lscan_sums(int nb, int *__restrict__ blocksum, int *__restrict__ total_slot) {
+  __shared__ int s[SCAN_BLOCK];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += SCAN_BLOCK) {
+    int i = base + threadIdx.x;
+    int v = (i < nb) ? blocksum[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+      int t = (threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int c = carry;
+    if (i < nb) blocksum[i] = c + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == SCAN_BLOCK - 1) carry = c + s[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_slot = carry;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_lscan_add(int m, int *__restrict__ out, const int *__restrict__ blocksum,
+                                                          const int *__restrict__ total_slot) {
+  int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  if (i < m) out[i] += blocksum[blockIdx.x];
+  if (i == 0) out[m] = *total_slot;
+}
+static void scan_ex(DeviceState &d, const int *in, int *out, int m, int total_flag) {
+  int sb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  int *tmp = d.le_scan;
+  hipLaunchKernelGGL(k_lscan_local, dim3(sb), dim3(SCAN_BLOCK), 0, d.stream, m, in, out, tmp);
+  hipLaunchKernelGGL(k_lscan_sums, dim3(1), dim3(SCAN_BLOCK), 0, d.stream, sb, tmp, d.flags + total_flag);
+  hipLaunchKernelGGL(k_lscan_add, dim3(sb), dim3(SCAN_BLOCK), 0, d.stream, m, out, tmp, d.flags + total_flag);
+}
+
+// ------------------------------------------------------------------------------------------
+// special-list / bond-table edits on one bead (device versions of the reference's in-place code)
+__device__ __forceinline__ void dev_delete_bond(const Topo &tp, int i, int partner) {   // fix_extrusion.cpp:656-668
+  int b = tp.bpa, nb = tp.num_bond[i];
+  for (int m = 0; m < nb; m++)
+    if (tp.bond_atom[(size_t)i * b + m] == partner) {
+      for (int k = m; k < nb - 1; k++) {
+        tp.bond_atom[(size_t)i * b + k] = tp.bond_atom[(size_t)i * b + k + 1];
+        tp.bond_type[(size_t)i * b + k] = tp.bond_type[(size_t)i * b + k + 1];
+      }
+      tp.num_bond[i] = nb - 1;
+      break;
+    }
+}
+__device__ __forceinline__ void dev_special_remove12(const Topo &tp, int i, int partner) {   // :673-683
+  int *slist = tp.special + (size_t)i * tp.ms;
+  int n1 = tp.nspecial[3 * (size_t)i], n3 = tp.nspecial[3 * (size_t)i + 2], m;
+  for (m = 0; m < n1; m++) if (slist[m] == partner) break;
+  for (; m < n3 - 1; m++) slist[m] = slist[m + 1];
+  tp.nspecial[3 * (size_t)i]--; tp.nspecial[3 * (size_t)i + 1]--; tp.nspecial[3 * (size_t)i + 2]--;
+}
+__device__ __forceinline__ bool dev_special_insert12(const Topo &tp, int i, int partner) {   // :748-771
+  int *slist = tp.special + (size_t)i * tp.ms;
+  int n1 = tp.nspecial[3 * (size_t)i], n2 = tp.nspecial[3 * (size_t)i + 1], n3 = tp.nspecial[3 * (size_t)i + 2], m, n;
+  for (m = n1; m < n3; m++) if (slist[m] == partner) break;
+  if (m < n3) {
+    for (n = m; n < n3 - 1; n++) slist[n] = slist[n + 1];
+    n3--;
+    if (m < n2) n2--;
+  }
+  if (n3 == tp.ms) return false;
+  for (m = n3; m > n1; m--) slist[m] = slist[m - 1];
+  slist[n1] = partner;
+  tp.nspecial[3 * (size_t)i] = n1 + 1; tp.nspecial[3 * (size_t)i + 1] = n2 + 1; tp.nspecial[3 * (size_t)i + 2] = n3 + 1;
+  return true;
+}
+__device__ int dev_dedup(int nstart, int nstop, int *copy) {   // fix_extrusion.cpp:1116-1135
+  int i, m = nstart;
+  while (m < nstop) {
+    for (i = 0; i < m; i++)
+      if (copy[i] == copy[m]) { copy[m] = copy[nstop - 1]; nstop--; break; }
+    if (i == m) m++;
+  }
+  return nstop;
+}
+// rebuild_special_one (fix_extrusion.cpp:1045-1108): 1-2 block kept; 1-3 / 1-4 from the 1-2 lists of others
+__device__ void dev_rebuild_special_one(const Topo &tp, int m, int *__restrict__ flags) {
+  int copy[MS_MAX * MS_MAX + MS_MAX];
+  const int ms = tp.ms;
+  int *slist = tp.special + (size_t)m * ms;
+  int n1 = tp.nspecial[3 * (size_t)m], cn1 = 0, cn2, cn3;
+  for (int i = 0; i < n1; i++) copy[cn1++] = slist[i];
+  cn2 = cn1;
+  for (int i = 0; i < cn1; i++) {
+    int n = copy[i];
+    const int *sl = tp.special + (size_t)n * ms;
+    int nn1 = tp.nspecial[3 * (size_t)n];
+    for (int j = 0; j < nn1; j++) if (sl[j] != m) copy[cn2++] = sl[j];
+  }
+  cn2 = dev_dedup(cn1, cn2, copy);
+  if (cn2 > ms) { flags[FLAG_ERROR] = ERR_SPECIAL_SCRATCH; return; }
+  cn3 = cn2;
+  for (int i = cn1; i < cn2; i++) {
+    int n = copy[i];
+    const int *sl = tp.special + (size_t)n * ms;
+    int nn1 = tp.nspecial[3 * (size_t)n];
+    for (int j = 0; j < nn1; j++) if (sl[j] != m) copy[cn3++] = sl[j];
+  }
+  cn3 = dev_dedup(cn2, cn3, copy);
+  if (cn3 > ms) { flags[FLAG_ERROR] = ERR_SPECIAL_SCRATCH; return; }
+  // the 1-2 block is unchanged: only the 1-3 / 1-4 blocks are rewritten, so concurrent rebuilds of
+  // neighbours (which read only 1-2 blocks) see consistent data
+  tp.nspecial[3 * (size_t)m + 1] = cn2;
+  tp.nspecial[3 * (size_t)m + 2] = cn3;
+  for (int i = cn1; i < cn3; i++) slist[i] = copy[i];
+}
+// influence rules of update_topology: broken (fix_extrusion.cpp:940-969), created (:971-1001)
+__global__ __launch_bounds__(64) void k_topo_broken(Topo tp, const int *__restrict__ fin, int *__restrict__ flags) {
+  int i = blockIdx.x * 64 + threadIdx.x + 1;
+  if (i > tp.T) return;
+  bool influenced = fin[i] != 0;
+  if (!influenced) {
+    const int *sl = tp.special + (size_t)i * tp.ms;
+    int n = tp.nspecial[3 * (size_t)i + 2];
+    for (int k = 0; k < n && !influenced; k++) {
+      int p = fin[sl[k]];
+      if (p)
+        for (int q = 0; q < n; q++) if (sl[q] == p) { influenced = true; break; }
+    }
+  }
+  if (influenced) dev_rebuild_special_one(tp, i, flags);
+}
+__global__ __launch_bounds__(64) void k_topo_created(Topo tp, const int *__restrict__ fin, int *__restrict__ flags) {
+  int i = blockIdx.x * 64 + threadIdx.x + 1;
+  if (i > tp.T) return;
+  bool influenced = fin[i] != 0;
+  if (!influenced) {
+    const int *sl = tp.special + (size_t)i * tp.ms;
+    int n = tp.nspecial[3 * (size_t)i + 1];
+    for (int k = 0; k < n; k++) if (fin[sl[k]]) { influenced = true; break; }
+  }
+  if (influenced) dev_rebuild_special_one(tp, i, flags);
+}
+
+// ------------------------------------------------------------------------------------------
+// stored coordinates by tag + bondcount of `btype`
+__global__ __launch_bounds__(BLOCK) void k_le_gather(Topo tp, const double4 *__restrict__ pos,
+                                                     const int *__restrict__ map, double4 *__restrict__ xt, int btype,
+                                                     int *__restrict__ bondcount, int check_multi,
+                                                     int *__restrict__ flags) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > tp.T + 1) return;
+  if (t == 0 || t == tp.T + 1) { bondcount[t] = 0; return; }
+  xt[t] = pos[map[t]];
+  int bc = 0, nb = tp.num_bond[t];
+  for (int m = 0; m < nb; m++) if (tp.bond_type[(size_t)t * tp.bpa + m] == btype) bc++;
+  bondcount[t] = bc;
+  if (check_multi && bc > 1) flags[FLAG_ERROR] = ERR_EXT_MULTI;
+}
+__device__ __forceinline__ double d2(const double4 &a, const double4 &b) {
+  double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return dx * dx + dy * dy + dz * dz;
+}
+__global__ void k_zero_int(int n, int *a) { int i = blockIdx.x * BLOCK + threadIdx.x; if (i < n) a[i] = 0; }
+
+// ========================================= ex_load ============================================
+// base(a): every test of the candidate scan that does not depend on earlier pairs (fix_ex_load.cpp:453-494)
+__global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, const double4 *__restrict__ xt,
+                                                       const int *__restrict__ bc,
+                                                       unsigned long long *__restrict__ bits,
+                                                       double *__restrict__ rsq_out) {
+  int a = blockIdx.x * BLOCK + threadIdx.x;   // pair a = (a, a+2); a = 0 is never valid
+  bool base = false;
+  if (a >= 1 && a + 2 <= tp.T) {
+    int i = a, j = a + 2, mid = a + 1;
+    int itype = tp.type_t[i], jtype = tp.type_t[j];
+    bool possible = false;
+    if (itype == P.iatomtype && jtype == P.jatomtype) {
+      if ((P.imaxbond == 0 || bc[i] < P.imaxbond) && (P.jmaxbond == 0 || bc[j] < P.jmaxbond)) possible = true;
+    } else if (itype == P.jatomtype && jtype == P.iatomtype) {
+      if ((P.jmaxbond == 0 || bc[i] < P.jmaxbond) && (P.imaxbond == 0 || bc[j] < P.imaxbond)) possible = true;
+    }
+    if (possible && tp.num_bond[i] == 2 && tp.num_bond[j] == 2 && tp.num_bond[mid] == 2) {
+      const int *sl = tp.special + (size_t)i * tp.ms;
+      int n1 = tp.nspecial[3 * (size_t)i];
+      for (int k = 0; k < n1; k++) if (sl[k] == j) possible = false;
+      if (possible) {
+        double rsq = d2(xt[i], xt[j]);   // stored coordinates, no minimum image (ghost entries are skipped)
+        rsq_out[a] = rsq;
+        base = rsq < P.cutsq;
+      }
+    }
+  }
+  unsigned long long m = __ballot(base);
+  if ((threadIdx.x & 63) == 0) bits[a >> 6] = m;
+}
+__device__ __forceinline__ bool bit_at(const unsigned long long *bits, int a) { return (bits[a >> 6] >> (a & 63)) & 1ull; }
+// accepted(a) = base(a) && (number of consecutive base bits directly below a is even)
+__device__ __forceinline__ bool accepted_at(const unsigned long long *__restrict__ bits, int a) {
+  if (a < 1 || !bit_at(bits, a)) return false;
+  int run = 0, pos = a - 1;
+  while (pos >= 0) {
+    int w = pos >> 6, b = pos & 63;                     // examine bits b..0 of word w, from the top
+    unsigned long long x = bits[w] << (63 - b);        // bit b moved to the MSB
+    unsigned long long inv = ~x;
+    int ones = inv ? __clzll((long long)inv) : 64;      // leading ones of x
+    if (ones > b + 1) ones = b + 1;
+    run += ones;
+    if (ones < b + 1) break;
+    pos -= ones;
+  }
+  return (run & 1) == 0;
+}
+__global__ __launch_bounds__(BLOCK) void k_exload_partner(int T, const unsigned long long *__restrict__ bits,
+                                                          const double *__restrict__ rsq, int *__restrict__ partner,
+                                                          int *__restrict__ haspartner) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > T + 1) return;
+  int p = 0;
+  if (t >= 1 && t <= T) {
+    bool lo = (t >= 3) && accepted_at(bits, t - 2);   // pair (t-2, t), visited first
+    bool hi = (t + 2 <= T) && accepted_at(bits, t);   // pair (t, t+2)
+    if (lo) p = t - 2;
+    if (hi && (!lo || rsq[t] < rsq[t - 2])) p = t + 2;
+  }
+  partner[t] = p;
+  haspartner[t] = p != 0;
+}
+__global__ __launch_bounds__(BLOCK) void k_exload_create(Topo tp, ExLoadParams P, const int *__restrict__ partner,
+                                                         const int *__restrict__ didx,
+                                                         const uint32_t *__restrict__ draws, int *__restrict__ bc,
+                                                         int *__restrict__ fin, double4 *__restrict__ pos,
+                                                         const int *__restrict__ map, int *__restrict__ flags) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > tp.T + 1) return;
+  int f = 0;
+  if (t >= 1 && t <= tp.T) {
+    int j = partner[t];
+    if (j && partner[j] == t) {
+      bool ok = true;
+      if (P.fraction < 1.0) {
+        int lo = t < j ? t : j;
+        double prob = (double)draws[didx[lo]] * (1.0 / 16777216.0);
+        if (prob >= P.fraction) ok = false;
+      }
+      if (ok) {
+        int nb = tp.num_bond[t];
+        if (nb == tp.bpa) { flags[FLAG_ERROR] = ERR_BPA; }
+        else {
+          tp.bond_type[(size_t)t * tp.bpa + nb] = P.btype;
+          tp.bond_atom[(size_t)t * tp.bpa + nb] = j;
+          tp.num_bond[t] = nb + 1;
+          if (!dev_special_insert12(tp, t, j)) flags[FLAG_ERROR] = ERR_SPECIAL;
+          int c = bc[t] + 1;
+          bc[t] = c;
+          int ty = tp.type_t[t], nty = ty;
+          if (ty == P.iatomtype) { if (c == P.imaxbond) nty = P.inewtype; }
+          else { if (c == P.jmaxbond) nty = P.jnewtype; }
+          if (nty != ty) { tp.type_t[t] = nty; pos[map[t]].w = (double)nty; }
+          f = j;
+          if (t < j) atomicAdd(&flags[FLAG_COUNT_A], 1);
+        }
+      }
+    }
+  }
+  fin[t] = f;
+}
+
+void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot) {
+  Topo tp = topo_of(d);
+  int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
+  hipStream_t st = d.stream;
+  int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
+  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.map, d.xt, P.btype, bc, 0, d.flags);
+  int nbw = ((nt + 63) / 64 * 64 + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL(k_exload_base, dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, d.le_bits, d.le_d[0]);
+  hipLaunchKernelGGL(k_exload_partner, dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], partner, has);
+  if (P.fraction < 1.0) {
+    scan_ex(d, has, didx, nt, FLAG_NDRAW);
+    launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
+  }
+  hipLaunchKernelGGL(k_exload_create, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, bc, fin, d.pos,
+                     d.map, d.flags);
+  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, d.flags);
+}
+
+// ========================================= ex_unload ==========================================
+__global__ __launch_bounds__(BLOCK) void k_exunload_partner(Topo tp, ExUnloadParams P, Box box,
+                                                            const double4 *__restrict__ xt,
+                                                            const double4 *__restrict__ xhold,
+                                                            const int *__restrict__ map, int *__restrict__ partner,
+                                                            int *__restrict__ haspartner) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > tp.T + 1) return;
+  int p = 0;
+  if (t >= 1 && t <= tp.T) {
+    double best = 0.0;
+    int nb = tp.num_bond[t];
+    double4 xi = xt[t], hi = xhold[map[t]];
+    for (int m = 0; m < nb; m++) {
+      if (tp.bond_type[(size_t)t * tp.bpa + m] != P.btype) continue;
+      int u = tp.bond_atom[(size_t)t * tp.bpa + m];
+      double4 xj = xt[u], hj = xhold[map[u]];
+      // partner image frozen at the last reneighbor (closest image then; ntopo_bond_all.cpp:53,64)
+      double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
+      double s0 = (h0 > box.half[0]) ? 1.0 : (h0 < -box.half[0]) ? -1.0 : 0.0;
+      double s1 = (h1 > box.half[1]) ? 1.0 : (h1 < -box.half[1]) ? -1.0 : 0.0;
+      double s2 = (h2 > box.half[2]) ? 1.0 : (h2 < -box.half[2]) ? -1.0 : 0.0;
+      double dx = xi.x - (xj.x + s0 * box.prd[0]), dy = xi.y - (xj.y + s1 * box.prd[1]),
+             dz = xi.z - (xj.z + s2 * box.prd[2]);
+      double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq <= P.cutsq) continue;
+      if (rsq > best) { best = rsq; p = u; }
+    }
+  }
+  partner[t] = p;
+  haspartner[t] = p != 0;
+}
+__global__ __launch_bounds__(BLOCK) void k_exunload_break(Topo tp, ExUnloadParams P, const int *__restrict__ partner,
+                                                          const int *__restrict__ didx,
+                                                          const uint32_t *__restrict__ draws, int *__restrict__ fin,
+                                                          int *__restrict__ flags) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > tp.T + 1) return;
+  int f = 0;
+  if (t >= 1 && t <= tp.T) {
+    int j = partner[t];
+    if (j && partner[j] == t) {
+      bool ok = true;
+      if (P.fraction < 1.0) {
+        int lo = t < j ? t : j;
+        double prob = (double)draws[didx[lo]] * (1.0 / 16777216.0);
+        if (prob >= P.fraction) ok = false;
+      }
+      if (ok) {
+        dev_delete_bond(tp, t, j);
+        dev_special_remove12(tp, t, j);
+        f = j;
+        if (t < j) atomicAdd(&flags[FLAG_COUNT_A], 1);
+      }
+    }
+  }
+  fin[t] = f;
+}
+void launch_ex_unload(DeviceState &d, const ExUnloadParams &P, int slot) {
+  Topo tp = topo_of(d);
+  int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
+  hipStream_t st = d.stream;
+  int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));
+  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.map, d.xt, P.btype, bc, 0, d.flags);
+  hipLaunchKernelGGL(k_exunload_partner, dim3(nb), dim3(BLOCK), 0, st, tp, P, d.box, d.xt, d.xhold, d.map, partner,
+                     has);
+  if (P.fraction < 1.0) {
+    scan_ex(d, has, didx, nt, FLAG_NDRAW);
+    launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
+  }
+  hipLaunchKernelGGL(k_exunload_break, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, fin, d.flags);
+  hipLaunchKernelGGL(k_topo_broken, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, d.flags);
+}
+
+// ========================================= extrusion ==========================================
+enum { LF_VALID = 1, LF_SL = 2, LF_SR = 4, LF_DL = 8, LF_DR = 16 };
+enum { CASE_NONE = 0, CASE_BOTH = 1, CASE_LEFT = 2, CASE_RIGHT = 3 };
+
+// which beads head a bond-list entry of type btype (ntopo_bond_all.cpp:52-73 with newton_bond off):
+// from t if t < partner (local index = ID-1), or from both ends if the bond straddled a face at the last build
+__global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box box, const double4 *__restrict__ xhold,
+                                                        const int *__restrict__ map, int *__restrict__ lflag,
+                                                        int *__restrict__ lpart) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > tp.T + 1) return;
+  int fl = 0, u = 0;
+  if (t >= 1 && t <= tp.T) {
+    int nb = tp.num_bond[t];
+    for (int m = 0; m < nb; m++)
+      if (tp.bond_type[(size_t)t * tp.bpa + m] == btype) { u = tp.bond_atom[(size_t)t * tp.bpa + m]; break; }
+    if (u) {
+      double4 hi = xhold[map[t]], hj = xhold[map[u]];
+      double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
+      bool straddle = fabs(h0) > box.half[0] || fabs(h1) > box.half[1] || fabs(h2) > box.half[2];
+      fl = (straddle || t < u) ? 1 : 0;
+    }
+  }
+  lflag[t] = fl;
+  lpart[t] = u;
+}
+// per listing: skip test, structural part of can(L)/can(R), number of RNG draws (fix_extrusion.cpp:398-429)
+__global__ __launch_bounds__(BLOCK) void k_ext_prepare(Topo tp, ExtrusionParams P, const int *__restrict__ lflag,
+                                                       const int *__restrict__ lidx, const int *__restrict__ lpart,
+                                                       const int *__restrict__ bc, int *__restrict__ list_l,
+                                                       int *__restrict__ list_r, int *__restrict__ list_f,
+                                                       int *__restrict__ ndraw) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t < 1 || t > tp.T || !lflag[t]) return;
+  int k = lidx[t], u = lpart[t];
+  int l = t < u ? t : u, r = t < u ? u : t;
+  int f = 0, nd = 0;
+  int nbl = tp.num_bond[l], nbr = tp.num_bond[r];
+  if (!(nbl == 1 || nbr == 1 || nbl == 0 || nbr == 0 || bc[l] != 1 || bc[r] != 1)) {
+    f |= LF_VALID;
+    int L = l - 1, R = r + 1;   // sentinels 0 and T+1 have num_bond = 0 -> structural test fails
+    int tyL = tp.type_t[L], tyR = tp.type_t[R];
+    bool sL = (tp.num_bond[L] - bc[L] == 2) && bc[L] == 0 &&
+              (tyL == P.ctcf_left || tyL == P.ctcf_right || tyL == P.ctcf_lr || tyL == P.neutral);
+    bool sR = (tp.num_bond[R] - bc[R] == 2) && bc[R] == 0 &&
+              (tyR == P.ctcf_left || tyR == P.ctcf_right || tyR == P.ctcf_lr || tyR == P.neutral);
+    if (sL) { f |= LF_SL; if (tyL == P.ctcf_left || tyL == P.ctcf_lr) { f |= LF_DL; nd++; } }
+    if (sR) { f |= LF_SR; if (tyR == P.ctcf_right || tyR == P.ctcf_lr) { f |= LF_DR; nd++; } }
+  }
+  list_l[k] = l; list_r[k] = r; list_f[k] = f; ndraw[k] = nd;
+}
+// per listing: barrier draws -> case and claim distance; register claim events on the free target beads
+__global__ __launch_bounds__(BLOCK) void k_ext_claims(int T, ExtrusionParams P, const int *__restrict__ nlist_ptr,
+                                                      const int *__restrict__ list_l, const int *__restrict__ list_r,
+                                                      const int *__restrict__ list_f, const int *__restrict__ doff,
+                                                      const uint32_t *__restrict__ draws,
+                                                      const double4 *__restrict__ xt, int *__restrict__ kcase,
+                                                      double *__restrict__ kq, int *__restrict__ ev_cnt,
+                                                      int *__restrict__ ev_k) {
+  int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= *nlist_ptr) return;
+  int f = list_f[k], c = CASE_NONE;
+  double q = BIGD;
+  if (f & LF_VALID) {
+    int l = list_l[k], r = list_r[k], L = l - 1, R = r + 1, o = doff[k];
+    const double inv = 1.0 / 16777216.0;
+    bool canL = (f & LF_SL) != 0, canR = (f & LF_SR) != 0;
+    if (f & LF_DL) { if (!(P.through_prob > (double)draws[o] * inv)) canL = false; o++; }
+    if (f & LF_DR) { if (!(P.through_prob > (double)draws[o] * inv)) canR = false; }
+    if (canL && canR) { c = CASE_BOTH; q = d2(xt[L], xt[R]); }
+    else if (canL) { c = CASE_LEFT; q = d2(xt[L], xt[r]); }
+    else if (canR) { c = CASE_RIGHT; q = d2(xt[l], xt[R]); }
+    if (c == CASE_BOTH || c == CASE_LEFT) { int s = atomicAdd(&ev_cnt[L], 1); if (s < 4) ev_k[(size_t)s * (T + 2) + L] = k; }
+    if (c == CASE_BOTH || c == CASE_RIGHT) { int s = atomicAdd(&ev_cnt[R], 1); if (s < 4) ev_k[(size_t)s * (T + 2) + R] = k; }
+  }
+  kcase[k] = c;
+  kq[k] = q;
+}
+// dc[X] as listing k saw it = min q over earlier claim events on X (strict '<' updates, fix_extrusion.cpp:436-515)
+__device__ __forceinline__ double dc_before(int T, int X, int k, const int *ev_cnt, const int *ev_k, const double *kq) {
+  double m = BIGD;
+  int n = min(ev_cnt[X], 4);
+  for (int s = 0; s < n; s++) {
+    int e = ev_k[(size_t)s * (T + 2) + X];
+    if (e < k && kq[e] < m) m = kq[e];
+  }
+  return m;
+}
+__global__ __launch_bounds__(BLOCK) void k_ext_resolve(int T, const int *__restrict__ nlist_ptr,
+                                                       const int *__restrict__ list_l, const int *__restrict__ list_r,
+                                                       const int *__restrict__ kcase, const double *__restrict__ kq,
+                                                       const int *__restrict__ ev_cnt, const int *__restrict__ ev_k,
+                                                       int *__restrict__ to_add, int *__restrict__ to_remove) {
+  int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= *nlist_ptr) return;
+  int c = kcase[k];
+  if (c == CASE_NONE) return;
+  int l = list_l[k], r = list_r[k], L = l - 1, R = r + 1;
+  double q = kq[k];
+  bool proceed;
+  if (c == CASE_BOTH) proceed = !(q >= dc_before(T, L, k, ev_cnt, ev_k, kq) && q >= dc_before(T, R, k, ev_cnt, ev_k, kq));
+  else if (c == CASE_LEFT) proceed = !(q >= dc_before(T, L, k, ev_cnt, ev_k, kq));
+  else proceed = !(q >= dc_before(T, R, k, ev_cnt, ev_k, kq));
+  if (!proceed) return;
+  to_remove[l] = r;
+  to_remove[r] = l;
+  // the stationary anchor of a one-sided move records its new partner once (dc[anchor] == BIG test)
+  if (c == CASE_LEFT) to_add[r] = L;
+  if (c == CASE_RIGHT) to_add[l] = R;
+}
+// final to_add of a claimed free bead: the closest claim, earliest listing on ties
+__global__ __launch_bounds__(BLOCK) void k_ext_toadd(int T, const int *__restrict__ ev_cnt, const int *__restrict__ ev_k,
+                                                     const double *__restrict__ kq, const int *__restrict__ kcase,
+                                                     const int *__restrict__ list_l, const int *__restrict__ list_r,
+                                                     int *__restrict__ to_add) {
+  int X = blockIdx.x * BLOCK + threadIdx.x;
+  if (X < 1 || X > T) return;
+  int n = min(ev_cnt[X], 4);
+  if (n == 0) return;
+  int best = -1;
+  double bq = BIGD;
+  for (int s = 0; s < n; s++) {
+    int e = ev_k[(size_t)s * (T + 2) + X];
+    double q = kq[e];
+    if (q < bq || (q == bq && e < best)) { bq = q; best = e; }
+  }
+  if (best < 0) return;
+  int l = list_l[best], r = list_r[best], c = kcase[best];
+  int val;
+  if (X == l - 1) val = (c == CASE_BOTH) ? r + 1 : r;   // claimed as L
+  else val = (c == CASE_BOTH) ? l - 1 : l;              // claimed as R
+  to_add[X] = val;
+}
+// phase 2 (fix_extrusion.cpp:517-599): a bead whose chosen partner chose someone else cancels the removal
+// of its own extruder; patterns evaluated on the phase-1 snapshot tr0, zeros written to tr1
+__global__ __launch_bounds__(BLOCK) void k_ext_losers(int T, const int *__restrict__ to_add, const int *__restrict__ tr0,
+                                                      int *__restrict__ tr1) {
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i < 1 || i > T) return;
+  int j = to_add[i];
+  if (j == 0 || to_add[j] == i) return;
+  int lb, rb;
+  bool iisleft = i < j;
+  if (iisleft) { lb = i + 1; rb = j - 1; } else { lb = j + 1; rb = i - 1; }
+  if (iisleft) {
+    if (lb == tr0[rb] && tr0[lb] == rb) { tr1[lb] = 0; tr1[rb] = 0; }
+    else if (i == tr0[rb] && tr0[i] == rb) { tr1[i] = 0; tr1[rb] = 0; }
+    else if (lb == tr0[j] && tr0[lb] == j) { tr1[lb] = 0; tr1[j] = 0; }
+    else if (i == tr0[j] && j == tr0[i]) { tr1[i] = 0; tr1[j] = 0; }
+  } else {
+    if (lb == tr0[rb] && tr0[lb] == rb) { tr1[lb] = 0; tr1[rb] = 0; }
+    else if (i == tr0[lb] && tr0[i] == lb) { tr1[i] = 0; tr1[lb] = 0; }
+    else if (rb == tr0[j] && tr0[rb] == j) { tr1[rb] = 0; tr1[j] = 0; }
+    else if (i == tr0[j] && j == tr0[i]) { tr1[i] = 0; tr1[j] = 0; }
+  }
+}
+// phase 3 (:618-692): one thread per extruder (its lower end) merges two one-sided moves and deletes the bond
+__global__ __launch_bounds__(BLOCK) void k_ext_remove(Topo tp, const int *__restrict__ tr, int *__restrict__ to_add,
+                                                      int *__restrict__ fin_rm, int *__restrict__ flags) {
+  int lb = blockIdx.x * BLOCK + threadIdx.x;
+  if (lb < 1 || lb > tp.T) return;
+  int rb = tr[lb];
+  if (rb == 0 || rb < lb || tr[rb] != lb) return;
+  if (to_add[lb - 1] == rb && to_add[rb] == lb - 1 && to_add[lb] == rb + 1 && to_add[rb + 1] == lb) {
+    to_add[lb - 1] = rb + 1; to_add[rb + 1] = lb - 1; to_add[lb] = 0; to_add[rb] = 0;
+  }
+  if ((to_add[lb - 1] == rb && to_add[rb] == lb - 1) || (to_add[lb - 1] == rb + 1 && to_add[rb + 1] == lb - 1) ||
+      (to_add[lb] == rb + 1 && to_add[rb + 1] == lb)) {
+    dev_delete_bond(tp, lb, rb); dev_special_remove12(tp, lb, rb);
+    dev_delete_bond(tp, rb, lb); dev_special_remove12(tp, rb, lb);
+    fin_rm[lb] = rb; fin_rm[rb] = lb;
+    atomicAdd(&flags[FLAG_COUNT_A], 1);
+  }
+}
+// phase 4 (:699-786)
+__global__ __launch_bounds__(BLOCK) void k_ext_create(Topo tp, int btype, const int *__restrict__ tr,
+                                                      const int *__restrict__ to_add, int *__restrict__ bc,
+                                                      int *__restrict__ fin_add, int *__restrict__ flags) {
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i < 1 || i > tp.T) return;
+  int j = to_add[i];
+  if (j == 0 || to_add[j] != i) return;
+  int nb = tp.num_bond[i];
+  if (nb == tp.bpa) return;
+  int lb = i < j ? i : j, rb = i < j ? j : i;
+  if ((tr[lb + 1] == rb && tr[rb] == lb + 1) || (tr[lb + 1] == rb - 1 && tr[rb - 1] == lb + 1) ||
+      (tr[lb] == rb - 1 && tr[rb - 1] == lb)) {
+    tp.bond_type[(size_t)i * tp.bpa + nb] = btype;
+    tp.bond_atom[(size_t)i * tp.bpa + nb] = j;
+    tp.num_bond[i] = nb + 1;
+    if (!dev_special_insert12(tp, i, j)) flags[FLAG_ERROR] = ERR_SPECIAL;
+    bc[i]++;
+    fin_add[i] = j;
+    if (i < j) atomicAdd(&flags[FLAG_COUNT_B], 1);
+  }
+}
+
+void launch_extrusion(DeviceState &d, const ExtrusionParams &P, int slot) {
+  Topo tp = topo_of(d);
+  int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
+  hipStream_t st = d.stream;
+  int *bc = d.le_i[I_BC], *lflag = d.le_i[I_A], *lidx = d.le_i[I_B], *lpart = d.le_i[I_C], *list_l = d.le_i[I_D],
+      *list_r = d.le_i[I_E], *list_f = d.le_i[I_F], *ndraw = d.le_i[I_G], *doff = d.le_i[I_H], *kcase = d.le_i[I_J],
+      *ev_cnt = d.le_i[I_K], *to_add = d.le_i[I_L], *tr0 = d.le_i[I_M], *tr1 = d.le_i[I_N], *fin_rm = d.le_i[I_O],
+      *fin_add = d.le_i[I_P];
+  int *ev_k = d.le_list;
+  double *kq = d.le_d[0];
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));
+  for (int *a : {ndraw, ev_cnt, to_add, tr0, fin_rm, fin_add}) HIP_CHECK(hipMemsetAsync(a, 0, (size_t)nt * sizeof(int), st));
+  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.map, d.xt, P.btype, bc, 1, d.flags);
+  hipLaunchKernelGGL(k_ext_listflag, dim3(nb), dim3(BLOCK), 0, st, tp, P.btype, d.box, d.xhold, d.map, lflag, lpart);
+  scan_ex(d, lflag, lidx, nt, FLAG_NLIST);
+  hipLaunchKernelGGL(k_ext_prepare, dim3(nb), dim3(BLOCK), 0, st, tp, P, lflag, lidx, lpart, bc, list_l, list_r, list_f,
+                     ndraw);
+  scan_ex(d, ndraw, doff, nt, FLAG_NDRAW);    // ndraw is zero beyond the number of listings
+  launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
+  hipLaunchKernelGGL(k_ext_claims, dim3(nb), dim3(BLOCK), 0, st, T, P, d.flags + FLAG_NLIST, list_l, list_r, list_f, doff,
+                     d.le_draws, d.xt, kcase, kq, ev_cnt, ev_k);
+  hipLaunchKernelGGL(k_ext_resolve, dim3(nb), dim3(BLOCK), 0, st, T, d.flags + FLAG_NLIST, list_l, list_r, kcase, kq,
+                     ev_cnt, ev_k, to_add, tr0);
+  hipLaunchKernelGGL(k_ext_toadd, dim3(nb), dim3(BLOCK), 0, st, T, ev_cnt, ev_k, kq, kcase, list_l, list_r, to_add);
+  HIP_CHECK(hipMemcpyAsync(tr1, tr0, (size_t)nt * sizeof(int), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_ext_losers, dim3(nb), dim3(BLOCK), 0, st, T, to_add, tr0, tr1);
+  hipLaunchKernelGGL(k_ext_remove, dim3(nb), dim3(BLOCK), 0, st, tp, tr1, to_add, fin_rm, d.flags);
+  hipLaunchKernelGGL(k_ext_create, dim3(nb), dim3(BLOCK), 0, st, tp, P.btype, tr1, to_add, bc, fin_add, d.flags);
+  hipLaunchKernelGGL(k_topo_broken, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin_rm, d.flags);
+  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin_add, d.flags);
+}
+
+}  // namespace lmp_le

@@ -1,0 +1,149 @@
+"""GPU parity tests of the USER-LE fixes: bond topology must be BIT-EXACT against the CPU oracle's
+literal serial restatement of fix_extrusion / fix_ex_load / fix_ex_unload on identical RNG seeds
+(positions within FP tolerance).  Covers: adjacent-candidate runs in ex_load, extruder collisions and
+stalling, left/right/roadblock barriers with through_prob in {0, 0.5, 1}, chain ends (multi-chain),
+absent roadblock type, extruder bonds that straddle a periodic face (double bond-list entries)."""
+import numpy as np
+import pytest
+
+from systems import CHAIN_SCRIPT, lattice_chain, run_oracle, run_product
+
+pytestmark = pytest.mark.gpu
+
+_cache = {}
+
+
+def melted(n, nchains=1, seed=1, steps=1500, types=None):
+    """A relaxed configuration (oracle MD from the lattice start), cached per parameter set."""
+    key = (n, nchains, seed, steps)
+    if key not in _cache:
+        s = lattice_chain(n, nchains=nchains, seed=seed)
+        o = run_oracle(CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 %d\nrun %d\n" % (777 + seed, steps), s)
+        s["x"], s["v"], s["image"] = o.x(), o.v(), o.image()
+        _cache[key] = s
+    s = dict(_cache[key])
+    if types is not None:
+        s["type"] = np.asarray(types, dtype=np.int32)
+        s["ntypes"] = int(s["type"].max())
+        s["mass"] = [1.0] * s["ntypes"]
+    return s
+
+
+def special_sets(ns, sp):
+    out = []
+    for i in range(len(ns)):
+        a, b, c = ns[i]
+        out.append((frozenset(sp[i, :a]), frozenset(sp[i, a:b]), frozenset(sp[i, b:c])))
+    return out
+
+
+def compare(p, o, fix_ids):
+    assert p.bond_set() == o.bond_set()
+    nb_p, nb_o = p.gather("num_bond"), o.bond_table()[0]
+    assert (nb_p == nb_o).all()
+    # stored order of each bead's bond slots is part of the state the fixes read
+    assert (p.gather("bond_atom") * (np.arange(p.gather("bond_atom").shape[1])[None, :] < nb_p[:, None]) ==
+            o.bond_table()[2] * (np.arange(o.bond_table()[2].shape[1])[None, :] < nb_o[:, None])).all()
+    assert (p.gather("type") == o.types()).all()
+    ns_o, sp_o = o.special_table()
+    assert (p.gather("nspecial") == ns_o).all()
+    assert special_sets(p.gather("nspecial"), p.gather("special")) == special_sets(ns_o, sp_o)
+    assert p.get_thermo("bonds") == o.nbonds()
+    for fid in fix_ids:
+        assert p.extract_fix(fid, 0, 1, 0) == o.fix_vector(fid)[0], fid
+        assert p.extract_fix(fid, 0, 1, 1) == o.fix_vector(fid)[1], fid
+    err = np.abs(p.gather("x") - o.x()).max()
+    assert err < 1e-7, err
+
+
+LE = """fix 1 all nve
+fix 2 all langevin 1.0 1.0 1.0 904297
+fix loop all extrusion {n1} {neutral} {left} {right} {tp} 2 {lr}
+fix loading all ex_load {nl} 1 1 1.12 2 {lprob} iparam 1 1 jparam 1 1
+fix unloading all ex_unload {nu} 2 {rmax} {uprob}
+thermo 10
+"""
+
+
+def le_script(n1=10, nl=10, nu=10, neutral=1, left=2, right=3, tp=1.0, lr="4", lprob="prob 0.5 684474",
+              uprob="prob 0.3 456456", rmax=0.5):
+    return CHAIN_SCRIPT + LE.format(n1=n1, nl=nl, nu=nu, neutral=neutral, left=left, right=right, tp=tp, lr=lr,
+                                    lprob=lprob, uprob=uprob, rmax=rmax)
+
+
+def barrier_types(n, seed, frac=0.15):
+    rng = np.random.RandomState(seed)
+    t = np.ones(n, dtype=np.int32)
+    pick = rng.rand(n) < frac
+    t[pick] = rng.randint(2, 5, size=pick.sum())
+    t[0] = t[-1] = 1
+    return t
+
+
+@pytest.mark.parametrize("tp", [1.0, 0.5, 0.0])
+def test_le_cycle_with_barriers(tmp_path, tp):
+    """extrusion + ex_load + ex_unload over several firings each; 15% barrier beads of the three kinds."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 5))
+    script = le_script(tp=tp).replace("pair_coeff * * 1.0 1.0 1.12", "pair_coeff * * 1.0 1.0 1.12") + "run 64\n"
+    # ex_load only initiates between type-1 beads; barrier types still get LJ/FENE parameters via wildcards
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    assert len([b for b in o.bond_set() if b[0] == 2]) > 5
+
+
+def test_dense_extruders_collide_and_stall(tmp_path):
+    """No prob keyword -> every eligible (i,i+2) pair loads (first-order recurrence over runs of candidates);
+    extruders then collide head-on and stall; nothing unloads."""
+    n = 4000
+    s = melted(n, nchains=4, seed=2)
+    script = le_script(n1=5, nl=20, nu=1000, lprob="", uprob="", lr="") + "run 58\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    ext = [b for b in o.bond_set() if b[0] == 2]
+    assert len(ext) > 100 and max(b[2] - b[1] for b in ext) >= 6
+
+
+def test_small_periodic_box_straddling_bonds(tmp_path):
+    """~12 sigma box: many extruder bonds cross a periodic face -> listed from both ends
+    (ntopo_bond_all.cpp:66-67), barrier RNG drawn twice, raw-coordinate distances."""
+    n = 1500
+    s = melted(n, seed=3, types=barrier_types(n, 9, frac=0.3))
+    script = le_script(n1=4, nl=8, nu=8, tp=0.5, lprob="prob 0.8 684474", uprob="prob 0.2 456456", rmax=1.5) + "run 70\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+
+
+def test_step_by_step_runs(tmp_path):
+    """`run 1` repeated: every run re-runs setup() (Langevin draws, reneighbor) in both engines."""
+    n = 2000
+    s = melted(n, nchains=2, seed=4, types=barrier_types(n, 11))
+    script = le_script(n1=3, nl=6, nu=6, tp=0.5)
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    for step in range(30):
+        o.run(1)
+        p.command("run 1")
+        assert p.bond_set() == o.bond_set(), step + 1
+    compare(p, o, ("loop", "loading", "unloading"))
+
+
+def test_readme_parameters_short(tmp_path):
+    """README.md:17,33-34 parameter set (17500 / 7000 / prob 0.001): firings at steps 1, 2, 3."""
+    n = 20000
+    s = melted(n, seed=6, steps=600)
+    script = CHAIN_SCRIPT + """fix 1 all nve
+fix 2 all langevin 1.0 1.0 1.0 904297
+fix loop all extrusion 17500 1 2 3 1.0 2 4
+fix loading all ex_load 7000 1 1 1.12 2 prob 0.001 684474 iparam 1 1 jparam 1 1
+fix unloading all ex_unload 7000 2 0.5 prob 0.001 456456
+run 12
+""".replace("pair_coeff * * 1.0 1.0 1.12", "pair_coeff * * 1.0 1.0 1.12")
+    s["ntypes"] = 4
+    s["mass"] = [1.0] * 4
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
