@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py — MD timesteps/s of the bead-spring + loop-extrusion hot path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).  A "step" is one
+velocity-Verlet timestep of the whole system (pair lj/cut + bond fene + fix nve + fix langevin + the three
+USER-LE fixes on their firing steps, reneighboring included), inputs resident in HBM when timing starts.
+
+Default workload = BASELINE.json configs[3] at N=1 (the configuration the north-star target is quoted on):
+a 1M-bead single chain at melt density, barrier beads every 200, `extrusion 1000` / `ex_load 1000 prob 0.01` /
+`ex_unload 1000 prob 0.01` (the dense LE parameter set BASELINE.md measured the reference with), so that two
+firings of every LE fix fall inside the default 2000-step timed window.
+
+Extra objects on the JSON line:
+  roofline     — the fused pair+bond force kernel: algorithmic bytes (52*N + 8*P + 12*B, SURVEY §8d with a full
+                 list: P = half pairs, B = bonds) / mean kernel duration from HIP events recorded on the launch
+                 stream inside the engine over the timed region, vs the 8 TB/s HBM3E peak.
+  cpu_baseline — the CPU oracle (oracle/le_oracle.c, a serial port of the reference path) on 1 host core, on a
+                 bounded sample (first steps of the same system from the same state); reported, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (beads, chains, barrier_every, n1, nload, pload, tp)
+    "chain1m": (1000000, 1, 200, 1000, 1000, 0.01, 0.5),
+    "chains10x100k": (1000000, 10, 200, 1000, 1000, 0.01, 0.5),
+    "chain100k": (100000, 1, 0, 17500, 7000, 0.001, 1.0),     # README.md:17,33-34 parameters
+    "chain32k": (32000, 1, 0, 1000, 1000, 0.01, 1.0),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--workload", default="chain1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle sample length (0 = skip the CPU baseline)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    os.environ["LAMMPS_LE_KERNEL_TIMING"] = "1"
+    from lammps_le_amd import lammps
+    from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
+
+    nbeads, nchains, bar, n1, nload, pload, tp = WORKLOADS[args.workload]
+    # round 1: ranks > 0 run independent replicas of the per-GPU workload (spatial decomposition with RCCL halo
+    # exchange is the next §8e row); per-GPU work is fixed as N grows -> weak scaling
+    sysd = lattice_chains(nbeads, nchains=nchains, seed=1 + rank, barrier_every=bar)
+    ntypes = sysd["ntypes"]
+    tmp = tempfile.mkdtemp(prefix="le_bench_")
+    data = os.path.join(tmp, "data.r%d" % rank)
+    write_data(data, sysd)
+    left, right, lr = (2, 3, "4") if ntypes == 4 else (1, 1, "")
+    script = CHAIN_INPUT.format(data=data, n1=n1, left=left, right=right, tp=tp, lr=lr, nload=nload, pload=pload)
+
+    lmp = lammps(cmdargs=["-screen", "none"])
+    for ln in script.split("\n"):
+        lmp.command(ln)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lmp.command("run %d" % args.warmup)            # untimed: upload, melt from the lattice, first LE firings
+    x_state, v_state = lmp.gather("x"), lmp.gather("v")
+    barrier()
+    t0 = time.perf_counter()
+    lmp.command("run %d" % args.steps)             # `run` = Verlet::setup + K steps, synchronised at the end
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (k_force: pair lj/cut + bonds, one launch per step) ----
+    kms = lmp.stat("pair_kernel_ms")
+    full_entries = lmp.stat("neigh_pairs")          # stored full-list entries = 2 * half pairs
+    nbonds = lmp.get_thermo("bonds")
+    alg_bytes = 52.0 * nbeads + 4.0 * full_entries + 12.0 * nbonds
+    achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get("k_force_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_force (pair lj/cut + bond fene, fused)", "achieved": round(achieved, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kms, 5),
+                "launches_timed": int(lmp.stat("pair_kernel_launches"))}
+
+    # ---- CPU baseline: the oracle on a bounded sample, rank 0 at N=1 only ----
+    cpu = None
+    cpu_steps = args.cpu_steps
+    if cpu_steps < 0:
+        cpu_steps = max(10, int(4.0e6 * 15 / nbeads)) if nbeads >= 100000 else 2000
+    if rank == 0 and world == 1 and cpu_steps > 0:
+        from systems import OracleScript
+        s2 = dict(sysd)
+        s2["x"], s2["v"] = x_state, v_state          # the state the timed GPU window started from
+        osc = OracleScript(s2)
+        for ln in script.split("\n"):
+            if ln.startswith("thermo_style"):
+                continue
+            osc.line(ln)
+        tc = time.perf_counter()
+        osc.o.run(cpu_steps)
+        wall = time.perf_counter() - tc
+        tm = osc.o.timers()
+        cpu = {"value": round(cpu_steps / tm["total"], 3), "unit": "timesteps/s", "cores": 1, "kind": "port",
+               "sample": "%d steps of the same %d-bead system from the post-warmup state (setup excluded, as the "
+                         "reference's Loop time); wall incl. setup %.1f s" % (cpu_steps, nbeads, wall),
+               "split_pct": {k: round(100 * tm[k] / tm["total"], 1) for k in ("pair", "bond", "neigh", "modify")}}
+
+    if rank == 0:
+        out = {
+            "metric": "MD timesteps/sec, bead-spring LJ+FENE chain with loop extrusion",
+            "value": round(world * args.steps / elapsed, 2) if world > 1 else round(args.steps / elapsed, 2),
+            "unit": "timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d beads, %d chain(s), lj/cut 1.12 + fene + nve + langevin + extrusion %d / "
+                                   "ex_load %d prob %g / ex_unload %d prob %g" % (args.workload, nbeads, nchains, n1, nload,
+                                                                                 pload, nload, pload),
+                       "beads_per_gpu": nbeads,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent replicas (one system per GPU)" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "engine_loop_time_s": round(lmp.stat("loop_time"), 5), "neigh_builds": int(lmp.stat("neigh_builds")),
+            "extruders": int(nbonds - (nbeads - nchains)), "fene_warnings": int(lmp.stat("fene_warnings")),
+        }
+        print(json.dumps(out))
+    lmp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

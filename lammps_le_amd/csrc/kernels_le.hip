@@ -81,7 +81,6 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_lscan_add(int m, int *__restrict
                                                           const int *__restrict__ total_slot) {
   int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (i < m) out[i] += blocksum[blockIdx.x];
-  if (i == 0) out[m] = *total_slot;
 }
 static void scan_ex(DeviceState &d, const int *in, int *out, int m, int total_flag) {
   int sb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;

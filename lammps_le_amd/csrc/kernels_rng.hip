@@ -135,3 +135,33 @@ void le_rng_download(DeviceState &d, int slot, RanMarsInt &r) {
 }
 
 }  // namespace lmp_le
+
+// test hook: `count` draws of RanMars(seed) after skipping `skip`, generated by the device serial-stream
+// kernel in `ncalls` consecutive calls (exercises the state write-back)
+extern "C" int lammps_le_test_device_ranmars(int seed, long long skip, int count, int ncalls, double *out) {
+  using namespace lmp_le;
+  try {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return 1;
+    DeviceState d;
+    HIP_CHECK(hipStreamCreate(&d.stream));
+    HIP_CHECK(hipMalloc(&d.le_rng_state, 300 * sizeof(uint32_t)));
+    uint32_t *draws; int *cnt;
+    HIP_CHECK(hipMalloc(&draws, (size_t)count * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&cnt, sizeof(int)));
+    RanMarsInt r; r.seed(seed); r.jump((uint64_t)skip);
+    le_rng_upload(d, 1, r);
+    std::vector<uint32_t> h(count);
+    int done = 0;
+    for (int c = 0; c < ncalls; c++) {
+      int n = (c == ncalls - 1) ? count - done : count / ncalls;
+      HIP_CHECK(hipMemcpy(cnt, &n, sizeof(int), hipMemcpyHostToDevice));
+      launch_ranmars_gen(d, 1, cnt, draws, count);
+      HIP_CHECK(hipMemcpy(h.data() + done, draws, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      done += n;
+    }
+    for (int i = 0; i < count; i++) out[i] = h[i] * (1.0 / 16777216.0);
+    (void)hipFree(draws); (void)hipFree(cnt); (void)hipFree(d.le_rng_state); (void)hipStreamDestroy(d.stream);
+    return 0;
+  } catch (...) { return 2; }
+}

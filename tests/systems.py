@@ -200,7 +200,7 @@ class OracleScript:
                                 int(p[6]) if len(p) > 6 else -1, fid)
             elif style == "ex_load":
                 kw = dict(imax=0, inew=None, jmax=0, jnew=None, fraction=1.0, seed=12345)
-                k = 4
+                k = 5
                 while k < len(p):
                     if p[k] == "iparam":
                         kw["imax"], kw["inew"] = int(p[k + 1]), int(p[k + 2])

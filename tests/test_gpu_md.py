@@ -109,3 +109,18 @@ run 100
     assert p.stat("neigh_builds") == t["builds"]
     assert p.stat("neigh_pairs") == 2 * t["neighbors"]
     assert n == 32000
+
+
+def test_device_ranmars_serial_stream():
+    """The single-wavefront RanMars generator used by the LE fixes (33 values per dependent step)."""
+    import ctypes
+    from lammps_le_amd import library_path
+    from oracle import ranmars_stream
+    lib = ctypes.CDLL(library_path())
+    fn = lib.lammps_le_test_device_ranmars
+    fn.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    for seed, skip, count, ncalls in ((684474, 0, 5000, 1), (12345, 0, 100, 7), (456456, 777, 4001, 3), (12345, 0, 20, 20)):
+        out = np.zeros(count)
+        assert fn(seed, skip, count, ncalls, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
+        ref = ranmars_stream(seed, skip + count)[skip:]
+        assert np.array_equal(out, ref), (seed, skip, count, ncalls, np.nonzero(out != ref)[0][:5])
