@@ -72,18 +72,27 @@ struct DeviceState {
   int *numneigh = nullptr;   // [npad]
   int *bpart = nullptr;      // [bpa][npad] (type << 26) | partner p ; -1 = none
   double *pairtab = nullptr; // 6 * nt*nt : cutsq lj1 lj2 lj3 lj4 offset
+  int pair_uniform = 0;      // every type pair has the same coefficients
+  double pair_u[6] = {0, 0, 0, 0, 0, 0};
+  double cutneigh = 0.0;
   // ---- thermo partial sums ----
   int nred_blocks = 0;
   double *partial = nullptr;     // [nblocks][16]
   double *partial_h = nullptr;   // pinned
   // ---- flags ----
   int *flags = nullptr;          // device
-  int *flags_h = nullptr;        // pinned host copy
+  int *flags_h = nullptr;        // pinned, mapped host copy
+  int *flags_h_dev = nullptr;    // device-side address of flags_h
   // ---- Langevin RNG (block-parallel RanMars) ----
   int rng_B = 0, rng_nblocks = 0;
   uint32_t *rng_state = nullptr;   // [nblocks][97]
   uint32_t *rng_jump = nullptr;    // [97] coefficients of x^(3N)
   uint32_t *rng_out = nullptr;     // [3N] 24-bit draws of the current call, canonical order
+  uint32_t *rng_buf[2] = {nullptr, nullptr};   // double buffer: the next call's draws are generated on rng_stream
+  int rng_cur = 0;
+  hipStream_t rng_stream = nullptr;
+  hipEvent_t rng_done[2] = {nullptr, nullptr}, rng_consumed[2] = {nullptr, nullptr};
+  bool rng_ahead = false;          // rng_buf[rng_cur ^ 1] already holds the draws of the next call
   // ---- LE fixes (tag order) ----
   double4 *xt = nullptr;           // [maxtag+2] stored coordinates by tag
   int *le_i[16] = {nullptr};       // integer scratch arrays [maxtag+2]
@@ -107,6 +116,8 @@ void dev_alloc_neigh(DeviceState &d, int maxneigh);
 // integrate (kernels_md.hip)
 void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check);
 void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4], bool eflag, bool has_pair);
+void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4], const TypeTables &tt, bool langevin,
+                 bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check);
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt);
 void launch_ke(DeviceState &d, const TypeTables &tt);
@@ -119,6 +130,7 @@ void launch_reneighbor(DeviceState &d, double cutneighsq, const double special_l
 // rng (kernels_rng.hip)
 void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms);
 void launch_rng_langevin(DeviceState &d, uint64_t first_raw);
+void rng_langevin_consumed(DeviceState &d);
 void launch_ranmars_gen(DeviceState &d, int slot, const int *count_ptr, uint32_t *out, int maxout);
 
 // LE fixes (kernels_le.hip)

@@ -184,6 +184,16 @@ void Engine::upload() {
       tab[3 * ntp * ntp + k] = lj3[k]; tab[4 * ntp * ntp + k] = lj4[k]; tab[5 * ntp * ntp + k] = offset[k];
     }
   up(d.pairtab, tab.data(), tab.size() * sizeof(double));
+  d.pair_uniform = pair_lj ? 1 : 0;
+  d.cutneigh = cutneighmax + skin;   // interior test margin: listed at build (within cutneigh) + drift since then
+  if (pair_lj) {
+    int ref = 1 * ntp + 1;
+    for (int i = 1; i <= ntypes; i++)
+      for (int j = 1; j <= ntypes; j++)
+        for (int q = 0; q < 6; q++)
+          if (tab[(size_t)q * ntp * ntp + i * ntp + j] != tab[(size_t)q * ntp * ntp + ref]) d.pair_uniform = 0;
+    for (int q = 0; q < 6; q++) d.pair_u[q] = tab[(size_t)q * ntp * ntp + ref];
+  }
   HIP_CHECK(hipMemsetAsync(d.flags, 0, NFLAGS * sizeof(int), d.stream));
   HIP_CHECK(hipStreamSynchronize(d.stream));
   dev_current = true;
@@ -361,19 +371,24 @@ static int count_nve(Engine *e) {
   return c;
 }
 
-void Engine::compute_forces(bool eflag) {
-  DeviceState &d = *dev;
-  bool timed = kernel_timing && !eflag && d.ev_used < 4096;
-  if (timed) {
-    if (d.ev0.size() <= d.ev_used) {
-      hipEvent_t a, b;
-      HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-      d.ev0.push_back(a); d.ev1.push_back(b);
-    }
-    HIP_CHECK(hipEventRecord(d.ev0[d.ev_used], d.stream));
+static bool timed_begin(Engine *e) {
+  DeviceState &d = *e->dev;
+  if (!e->kernel_timing || d.ev_used >= 4096) return false;
+  if (d.ev0.size() <= d.ev_used) {
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    d.ev0.push_back(a); d.ev1.push_back(b);
   }
-  launch_force(d, bondtab, special_lj, eflag, pair_lj);
+  HIP_CHECK(hipEventRecord(d.ev0[d.ev_used], d.stream));
+  return true;
+}
+static void timed_end(Engine *e, bool timed) {
+  DeviceState &d = *e->dev;
   if (timed) { HIP_CHECK(hipEventRecord(d.ev1[d.ev_used], d.stream)); d.ev_used++; }
+}
+
+void Engine::compute_forces(bool eflag) {
+  launch_force(*dev, bondtab, special_lj, eflag, pair_lj);
 }
 
 double Engine::stat_neigh_pairs() {
@@ -385,7 +400,8 @@ double Engine::stat_neigh_pairs() {
   return s;
 }
 
-static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
+// advance the Langevin stream by one post_force call: 3N draws into rng_out (canonical order)
+static void langevin_draws(Engine *e, FixLangevin *lg) {
   DeviceState &d = *e->dev;
   if (!lg->dev_ready) {
     // position a host generator at the first draw of this call and cut the stream into blocks
@@ -397,9 +413,12 @@ static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
   }
   launch_rng_langevin(d, lg->draws + 1);     // raw index of draw k is k+1 (constructor warm-up)
   lg->draws += 3ull * e->natoms;
+}
+static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
+  langevin_draws(e, lg);
   TypeTables tt = make_tables(e, lg);
-  bool ident = (e->sortfreq == 0);
-  launch_langevin(d, tt, ident, fuse_final);
+  launch_langevin(*e->dev, tt, e->sortfreq == 0, fuse_final);
+  rng_langevin_consumed(*e->dev);
 }
 
 ThermoRow Engine::eval_thermo() {
@@ -493,31 +512,51 @@ void Engine::setup() {
   print_thermo(last_thermo);
 }
 
-// Verlet::run (src/verlet.cpp:223-354)
+// Verlet::run (src/verlet.cpp:223-354).  With the standard fix set (one fix nve, at most one fix langevin) a
+// non-thermo step is ONE fused kernel: forces + post_force + final_integrate + the next step's
+// initial_integrate (k_step); LE fixes and the reneighbor decision run between two such kernels exactly
+// where the reference runs them (after initial_integrate, before the force computation).
 void Engine::iterate(long nsteps) {
   DeviceState &d = *dev;
   FixLangevin *lg = the_langevin(this);
   int nnve = count_nve(this);
   double triggersq = 0.25 * skin * skin;
+  bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
+  bool ident = (sortfreq == 0);
+  bool pre_integrated = false;
   for (long it = 0; it < nsteps; it++) {
     ntimestep++;
     bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
-    TypeTables tt = make_tables(this, nullptr);
-    bool will_check = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
-    for (int k = 0; k < nnve; k++) launch_initial_integrate(d, tt, dt, triggersq, will_check && k == nnve - 1);
+    TypeTables tt = make_tables(this, lg);
+    if (!pre_integrated) {
+      bool will_check = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
+      for (int k = 0; k < nnve; k++) launch_initial_integrate(d, tt, dt, triggersq, will_check && k == nnve - 1);
+    }
     for (auto &f : fixes) if (f->has_post_integrate) f->post_integrate();
     if (decide()) {
       reneighbor();
       if (sortfreq > 0 && ntimestep >= nextsort) emulate_atom_sort();
     }
-    compute_forces(eflag);
-    if (lg) langevin_post_force(this, lg, nnve == 1);
-    if (!(lg && nnve == 1))
-      for (int k = 0; k < nnve; k++) launch_final_integrate(d, tt);
-    if (eflag) {
-      last_thermo = eval_thermo();
-      thermo_log.push_back(last_thermo);
-      print_thermo(last_thermo);
+    if (fusable && !eflag) {
+      bool next = (it + 1 < nsteps);
+      bool check_next = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
+      if (lg) langevin_draws(this, lg);
+      bool timed = timed_begin(this);
+      launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next);
+      timed_end(this, timed);
+      if (lg) rng_langevin_consumed(d);
+      pre_integrated = next;
+    } else {
+      compute_forces(eflag);
+      if (lg) langevin_post_force(this, lg, nnve == 1);
+      if (!(lg && nnve == 1))
+        for (int k = 0; k < nnve; k++) launch_final_integrate(d, tt);
+      pre_integrated = false;
+      if (eflag) {
+        last_thermo = eval_thermo();
+        thermo_log.push_back(last_thermo);
+        print_thermo(last_thermo);
+      }
     }
   }
   HIP_CHECK(hipStreamSynchronize(d.stream));

@@ -48,7 +48,7 @@ void ranmars_jump_poly(uint64_t k, uint32_t a[97]);
 // device-side views (plain pointers; filled by Engine, consumed by the kernel launchers)
 // ---------------------------------------------------------------------------------------------
 struct Box {
-  double lo[3], hi[3], prd[3], half[3];
+  double lo[3], hi[3], prd[3], half[3], iprd[3];
 };
 
 struct TypeTables {  // by-value kernel argument

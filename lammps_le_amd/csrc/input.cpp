@@ -442,6 +442,7 @@ void Engine::read_data(const std::string &path) {
     if (box.lo[d] >= box.hi[d]) throw LammpsError("Box bounds are invalid or missing");
     box.prd[d] = box.hi[d] - box.lo[d];
     box.half[d] = 0.5 * box.prd[d];
+    box.iprd[d] = 1.0 / box.prd[d];
   }
   natoms = na;
   box_exist = true;

@@ -137,123 +137,255 @@ __global__ __launch_bounds__(BLOCK) void k_ke(int n, const double4 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// pair lj/cut over the full ELL neighbor list + per-atom bonds; one thread per bead, no atomics.
+// force on bead p: pair lj/cut over the full ELL neighbor list + its own bonds (no atomics: every pair
+// and bond is evaluated from both ends, which is also what keeps the summation order deterministic)
+struct ForceArgs {
+  int n, npad, nblocks, bpa, nt;
+  const double4 *pos;
+  const int *neigh, *numneigh, *bpart;
+  const double *pairtab;
+  double sl0, sl1, sl2, sl3;
+  // all type pairs share one coefficient set (pair_coeff * * ...): scalars instead of the LDS table
+  int uniform;
+  double u_cutsq, u_lj1, u_lj2, u_lj3, u_lj4, u_off;
+  int has_sb;            // some special weight is neither 0 nor 1 -> list entries carry special bits
+  double margin;         // beads farther than this from every box face need no minimum image
+  int nn_limit;          // diagnostics only (LAMMPS_LE_NN_LIMIT): cap on neighbors visited per bead
+};
+
+// one pair term.  The hot loop is written for issue-bound FP64 on CDNA4: branch-free minimum image
+// (v_rndne), reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp from the reference's IEEE divide),
+// FMA contraction allowed inside this function only (everything else is compiled -ffp-contract=off).
+template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB>
+__device__ __forceinline__ void pair_term(const ForceArgs &A, const Box &box, const double *__restrict__ s_tab,
+                                          int itype, const double4 &ri, int jraw, const double4 &rj, bool valid,
+                                          double &fxi, double &fyi, double &fzi, double (&e)[14]) {
+#pragma clang fp contract(fast)
+  double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
+  if (MINIMG) {
+    delx -= box.prd[0] * __builtin_rint(delx * box.iprd[0]);
+    dely -= box.prd[1] * __builtin_rint(dely * box.iprd[1]);
+    delz -= box.prd[2] * __builtin_rint(delz * box.iprd[2]);
+  }
+  double rsq = delx * delx + dely * dely + delz * delz;
+  double cutsq, lj1, lj2, lj3 = 0.0, lj4 = 0.0, offs = 0.0;
+  if (UNIFORM) { cutsq = A.u_cutsq; lj1 = A.u_lj1; lj2 = A.u_lj2; if (EFLAG) { lj3 = A.u_lj3; lj4 = A.u_lj4; offs = A.u_off; } }
+  else {
+    const int nt2 = A.nt * A.nt, ij = itype * A.nt + (int)rj.w;
+    cutsq = s_tab[ij]; lj1 = s_tab[nt2 + ij]; lj2 = s_tab[2 * nt2 + ij];
+    if (EFLAG) { lj3 = s_tab[3 * nt2 + ij]; lj4 = s_tab[4 * nt2 + ij]; offs = s_tab[5 * nt2 + ij]; }
+  }
+  if (rsq < cutsq && valid) {
+    double r2inv = __builtin_amdgcn_rcp(rsq);
+    r2inv = r2inv * (2.0 - rsq * r2inv);
+    r2inv = r2inv * (2.0 - rsq * r2inv);
+    double r6inv = r2inv * r2inv * r2inv;
+    double forcelj = r6inv * (lj1 * r6inv - lj2);
+    double fpair = forcelj * r2inv;
+    double factor_lj = 1.0;
+    if (HAS_SB) {
+      int sb = (jraw >> NEIGH_SB_SHIFT) & 3;
+      factor_lj = (sb == 0) ? A.sl0 : (sb == 1) ? A.sl1 : (sb == 2) ? A.sl2 : A.sl3;
+      fpair *= factor_lj;
+    }
+    fxi += delx * fpair; fyi += dely * fpair; fzi += delz * fpair;
+    if (EFLAG) {
+      double evdwl = r6inv * (lj3 * r6inv - lj4) - offs;
+      evdwl *= factor_lj;
+      e[0] += 0.5 * evdwl;
+      e[2] += 0.5 * delx * delx * fpair; e[3] += 0.5 * dely * dely * fpair; e[4] += 0.5 * delz * delz * fpair;
+      e[5] += 0.5 * delx * dely * fpair; e[6] += 0.5 * delx * delz * fpair; e[7] += 0.5 * dely * delz * fpair;
+    }
+  }
+}
+
+template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB>
+__device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, const double *__restrict__ s_tab, int p,
+                                          const double4 &ri, double &fxi, double &fyi, double &fzi,
+                                          double (&e)[14]) {
+  const int itype = (int)ri.w, npad = A.npad;
+  const int nn = min(A.numneigh[p], A.nn_limit);
+  const int *col = A.neigh + p;
+  // software pipeline, 4 neighbors per stage: while the four position gathers of the current stage are in
+  // flight the (coalesced) index loads of the next stage are issued, so a stage costs one exposed round trip.
+  // Lists are consumed in groups of 4; slots past the end are predicated off (index = own bead, cached).
+  int j0 = (0 < nn) ? col[0] : p, j1 = (1 < nn) ? col[(size_t)npad] : p, j2 = (2 < nn) ? col[(size_t)2 * npad] : p,
+      j3 = (3 < nn) ? col[(size_t)3 * npad] : p;
+  for (int k = 0; k < nn; k += 4) {
+    double4 r0 = A.pos[j0 & NEIGH_MASK], r1 = A.pos[j1 & NEIGH_MASK], r2 = A.pos[j2 & NEIGH_MASK],
+            r3 = A.pos[j3 & NEIGH_MASK];
+    const int c0 = j0, c1 = j1, c2 = j2, c3 = j3;
+    const int kn = k + 4;
+    j0 = (kn < nn) ? col[(size_t)kn * npad] : p;
+    j1 = (kn + 1 < nn) ? col[(size_t)(kn + 1) * npad] : p;
+    j2 = (kn + 2 < nn) ? col[(size_t)(kn + 2) * npad] : p;
+    j3 = (kn + 3 < nn) ? col[(size_t)(kn + 3) * npad] : p;
+    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c0, r0, true, fxi, fyi, fzi, e);
+    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c1, r1, k + 1 < nn, fxi, fyi, fzi, e);
+    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c2, r2, k + 2 < nn, fxi, fyi, fzi, e);
+    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c3, r3, k + 3 < nn, fxi, fyi, fzi, e);
+  }
+}
+
 template <bool EFLAG, bool HAS_PAIR>
-__global__ __launch_bounds__(BLOCK) void k_force(int n, int npad, int nblocks, const double4 *__restrict__ pos,
-                                                 const int *__restrict__ neigh, const int *__restrict__ numneigh,
-                                                 const int *__restrict__ bpart, int bpa,
-                                                 const double *__restrict__ pairtab, int nt, double sl0, double sl1,
-                                                 double sl2, double sl3, BondTable bt, Box box,
-                                                 double *__restrict__ fx, double *__restrict__ fy,
-                                                 double *__restrict__ fz, double *__restrict__ partial,
-                                                 int *__restrict__ flags) {
+__device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &bt, const Box &box,
+                                           const double *__restrict__ s_tab, int p, const double4 &ri,
+                                           double &fxi, double &fyi, double &fzi, double (&e)[14],
+                                           int *__restrict__ flags) {
+  const int npad = A.npad;
+  const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
+  const double px = box.prd[0], py = box.prd[1], pz = box.prd[2];
+  if (HAS_PAIR) {
+    // wave-uniform choice: a wavefront whose 64 beads all sit deeper than `margin` inside the box skips
+    // the minimum-image arithmetic (cell order makes most wavefronts interior)
+    const double m = A.margin;
+    bool interior = ri.x > box.lo[0] + m && ri.x < box.hi[0] - m && ri.y > box.lo[1] + m && ri.y < box.hi[1] - m &&
+                    ri.z > box.lo[2] + m && ri.z < box.hi[2] - m;
+    bool all_in = __all(interior);
+    if (A.uniform && !A.has_sb) {
+      if (all_in) pair_loop<EFLAG, false, true, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+      else pair_loop<EFLAG, true, true, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+    } else if (!A.has_sb) {
+      if (all_in) pair_loop<EFLAG, false, false, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+      else pair_loop<EFLAG, true, false, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+    } else {
+      pair_loop<EFLAG, true, false, true>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+    }
+  }
+  for (int m = 0; m < A.bpa; m++) {
+    int eb = A.bpart[(size_t)m * npad + p];
+    if (eb < 0) continue;
+    int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
+    int style = bt.style[type];
+    if (style == 0) continue;
+    double4 rj = A.pos[q];
+    double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
+    if (delx > hx) delx -= px; else if (delx < -hx) delx += px;
+    if (dely > hy) dely -= py; else if (dely < -hy) dely += py;
+    if (delz > hz) delz -= pz; else if (delz < -hz) delz += pz;
+    double rsq = delx * delx + dely * dely + delz * delz;
+    double fbond, ebond = 0.0;
+    if (style == 1) {
+      double K = bt.p0[type], R0 = bt.p1[type], epsb = bt.p2[type], sigb = bt.p3[type];
+      double r0sq = R0 * R0;
+      double rlogarg = 1.0 - rsq / r0sq;
+      double sr6 = 0.0;
+      if (rlogarg < 0.1) {
+        // each bond is visited from both ends: count the warning once (lower index)
+        if (p < q) atomicAdd(&flags[FLAG_FENE_WARN], 1);
+        if (rlogarg <= -3.0) flags[FLAG_ERROR] = ERR_BAD_FENE;
+        rlogarg = 0.1;
+      }
+      fbond = -K / rlogarg;
+      if (rsq < TWO_1_3 * sigb * sigb) {
+        double sr2 = sigb * sigb / rsq;
+        sr6 = sr2 * sr2 * sr2;
+        fbond += 48.0 * epsb * sr6 * (sr6 - 0.5) / rsq;
+      }
+      if (EFLAG) {
+        ebond = -0.5 * K * r0sq * log(rlogarg);
+        if (rsq < TWO_1_3 * sigb * sigb) ebond += 4.0 * epsb * sr6 * (sr6 - 1.0) + epsb;
+      }
+    } else {
+      double r = sqrt(rsq);
+      double dr = r - bt.p1[type];
+      double rk = bt.p0[type] * dr;
+      fbond = (r > 0.0) ? -2.0 * rk / r : 0.0;
+      if (EFLAG) ebond = rk * dr;
+    }
+    fxi += delx * fbond; fyi += dely * fbond; fzi += delz * fbond;
+    if (EFLAG) {
+      e[1] += 0.5 * ebond;
+      e[8] += 0.5 * delx * delx * fbond; e[9] += 0.5 * dely * dely * fbond; e[10] += 0.5 * delz * delz * fbond;
+      e[11] += 0.5 * delx * dely * fbond; e[12] += 0.5 * delx * delz * fbond; e[13] += 0.5 * dely * delz * fbond;
+    }
+  }
+}
+
+// forces only (setup, thermo steps, runs without the standard nve+langevin pair of fixes)
+template <bool EFLAG, bool HAS_PAIR>
+__global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box box, double *__restrict__ fx,
+                                                 double *__restrict__ fy, double *__restrict__ fz,
+                                                 double *__restrict__ partial, int *__restrict__ flags) {
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
-  int nt2 = nt * nt;
   if (HAS_PAIR)
-    for (int k = threadIdx.x; k < 6 * nt2; k += BLOCK) s_tab[k] = pairtab[k];
+    for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
   __syncthreads();
-  int lb = logical_block(nblocks);
+  int lb = logical_block(A.nblocks);
   int p = lb * BLOCK + threadIdx.x;
   double e[14];
 #pragma unroll
   for (int k = 0; k < 14; k++) e[k] = 0.0;
-  bool active = (lb < nblocks) && (p < n);
-  if (active) {
-    double4 ri = pos[p];
-    int itype = (int)ri.w;
+  if (lb < A.nblocks && p < A.n) {
+    double4 ri = A.pos[p];
     double fxi = 0.0, fyi = 0.0, fzi = 0.0;
-    const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
-    const double px = box.prd[0], py = box.prd[1], pz = box.prd[2];
-    if (HAS_PAIR) {
-      const double *cutsq = s_tab, *lj1 = s_tab + nt2, *lj2 = s_tab + 2 * nt2, *lj3 = s_tab + 3 * nt2,
-                   *lj4 = s_tab + 4 * nt2, *offs = s_tab + 5 * nt2;
-      int nn = numneigh[p];
-      const int *col = neigh + p;
-      int jnext = (nn > 0) ? col[0] : 0;
-      for (int k = 0; k < nn; k++) {
-        int jraw = jnext;
-        if (k + 1 < nn) jnext = col[(size_t)(k + 1) * npad];
-        int j = jraw & NEIGH_MASK;
-        int sb = (jraw >> NEIGH_SB_SHIFT) & 3;
-        double factor_lj = (sb == 0) ? sl0 : (sb == 1) ? sl1 : (sb == 2) ? sl2 : sl3;
-        double4 rj = pos[j];
-        double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
-        if (delx > hx) delx -= px; else if (delx < -hx) delx += px;
-        if (dely > hy) dely -= py; else if (dely < -hy) dely += py;
-        if (delz > hz) delz -= pz; else if (delz < -hz) delz += pz;
-        double rsq = delx * delx + dely * dely + delz * delz;
-        int ij = itype * nt + (int)rj.w;
-        if (rsq < cutsq[ij]) {
-          double r2inv = 1.0 / rsq;
-          double r6inv = r2inv * r2inv * r2inv;
-          double forcelj = r6inv * (lj1[ij] * r6inv - lj2[ij]);
-          double fpair = factor_lj * forcelj * r2inv;
-          fxi += delx * fpair;
-          fyi += dely * fpair;
-          fzi += delz * fpair;
-          if (EFLAG) {
-            double evdwl = r6inv * (lj3[ij] * r6inv - lj4[ij]) - offs[ij];
-            evdwl *= factor_lj;
-            e[0] += 0.5 * evdwl;
-            e[2] += 0.5 * delx * delx * fpair; e[3] += 0.5 * dely * dely * fpair; e[4] += 0.5 * delz * delz * fpair;
-            e[5] += 0.5 * delx * dely * fpair; e[6] += 0.5 * delx * delz * fpair; e[7] += 0.5 * dely * delz * fpair;
-          }
-        }
-      }
-    }
-    for (int m = 0; m < bpa; m++) {
-      int eb = bpart[(size_t)m * npad + p];
-      if (eb < 0) continue;
-      int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
-      int style = bt.style[type];
-      if (style == 0) continue;
-      double4 rj = pos[q];
-      double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
-      if (delx > hx) delx -= px; else if (delx < -hx) delx += px;
-      if (dely > hy) dely -= py; else if (dely < -hy) dely += py;
-      if (delz > hz) delz -= pz; else if (delz < -hz) delz += pz;
-      double rsq = delx * delx + dely * dely + delz * delz;
-      double fbond, ebond = 0.0;
-      if (style == 1) {
-        double K = bt.p0[type], R0 = bt.p1[type], epsb = bt.p2[type], sigb = bt.p3[type];
-        double r0sq = R0 * R0;
-        double rlogarg = 1.0 - rsq / r0sq;
-        double sr6 = 0.0;
-        if (rlogarg < 0.1) {
-          // each bond is visited from both ends: count the warning once (lower index)
-          if (p < q) atomicAdd(&flags[FLAG_FENE_WARN], 1);
-          if (rlogarg <= -3.0) flags[FLAG_ERROR] = ERR_BAD_FENE;
-          rlogarg = 0.1;
-        }
-        fbond = -K / rlogarg;
-        if (rsq < TWO_1_3 * sigb * sigb) {
-          double sr2 = sigb * sigb / rsq;
-          sr6 = sr2 * sr2 * sr2;
-          fbond += 48.0 * epsb * sr6 * (sr6 - 0.5) / rsq;
-        }
-        if (EFLAG) {
-          ebond = -0.5 * K * r0sq * log(rlogarg);
-          if (rsq < TWO_1_3 * sigb * sigb) ebond += 4.0 * epsb * sr6 * (sr6 - 1.0) + epsb;
-        }
-      } else {
-        double r = sqrt(rsq);
-        double dr = r - bt.p1[type];
-        double rk = bt.p0[type] * dr;
-        fbond = (r > 0.0) ? -2.0 * rk / r : 0.0;
-        if (EFLAG) ebond = rk * dr;
-      }
-      fxi += delx * fbond;
-      fyi += dely * fbond;
-      fzi += delz * fbond;
-      if (EFLAG) {
-        e[1] += 0.5 * ebond;
-        e[8] += 0.5 * delx * delx * fbond; e[9] += 0.5 * dely * dely * fbond; e[10] += 0.5 * delz * delz * fbond;
-        e[11] += 0.5 * delx * dely * fbond; e[12] += 0.5 * delx * delz * fbond; e[13] += 0.5 * dely * delz * fbond;
-      }
-    }
+    bead_force<EFLAG, HAS_PAIR>(A, bt, box, s_tab, p, ri, fxi, fyi, fzi, e, flags);
     fx[p] = fxi; fy[p] = fyi; fz[p] = fzi;
   }
-  if (EFLAG && lb < nblocks) block_reduce_store<14>(e, partial, lb, 0);
+  if (EFLAG && lb < A.nblocks) block_reduce_store<14>(e, partial, lb, 0);
+}
+
+// the whole force-side of a timestep in ONE pass over the beads:
+//   f(x_n) -> [+ Langevin drag/random, 3 draws by canonical rank] -> final half-kick (FixNVE::final_integrate)
+//   -> [NEXT: first half-kick + drift of step n+1 (FixNVE::initial_integrate) into the second position
+//       buffer + the skin/2 displacement test of Neighbor::check_distance]
+// x, v never round-trip through HBM between these stages and f is only stored when a later kernel needs it.
+template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR>
+__global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
+                                                const int *__restrict__ tag, const int *__restrict__ crank,
+                                                const uint32_t *__restrict__ draws, double *__restrict__ vx,
+                                                double *__restrict__ vy, double *__restrict__ vz,
+                                                double *__restrict__ fx, double *__restrict__ fy,
+                                                double *__restrict__ fz, double4 *__restrict__ pos_next,
+                                                const double4 *__restrict__ xhold, double dtv, double triggersq,
+                                                int check, int *__restrict__ flags) {
+  __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
+  if (HAS_PAIR)
+    for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
+  __syncthreads();
+  int lb = logical_block(A.nblocks);
+  int p = lb * BLOCK + threadIdx.x;
+  if (lb >= A.nblocks || p >= A.n) return;
+  double4 ri = A.pos[p];
+  // streaming operands first: their latency overlaps the neighbor loop
+  double a = vx[p], b = vy[p], c = vz[p];
+  uint32_t d0 = 0, d1 = 0, d2 = 0;
+  if (LANGEVIN) {
+    int t = tag[p];
+    int rank = IDENT ? (t - 1) : crank[t];
+    d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
+  }
+  double f0 = 0.0, f1 = 0.0, f2 = 0.0;
+  double e[14];
+  bead_force<false, HAS_PAIR>(A, bt, box, s_tab, p, ri, f0, f1, f2, e, flags);
+  const int type = (int)ri.w;
+  if (LANGEVIN) {
+    double gamma1 = tt.g1[type], gamma2 = tt.g2[type];
+    const double inv = 1.0 / 16777216.0;
+    double r0 = (double)d0 * inv;
+    double r1 = (double)d1 * inv;
+    double r2 = (double)d2 * inv;
+    double fran0 = gamma2 * (r0 - 0.5), fran1 = gamma2 * (r1 - 0.5), fran2 = gamma2 * (r2 - 0.5);
+    double fdrag0 = gamma1 * a, fdrag1 = gamma1 * b, fdrag2 = gamma1 * c;
+    f0 += fdrag0 + fran0;
+    f1 += fdrag1 + fran1;
+    f2 += fdrag2 + fran2;
+  }
+  const double dtfm = tt.dtfm[type];
+  a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;          // final_integrate of this step
+  if (NEXT) {
+    a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;        // initial_integrate of the next step
+    ri.x += dtv * a; ri.y += dtv * b; ri.z += dtv * c;
+    pos_next[p] = ri;
+    if (check) {
+      double4 h = xhold[p];
+      double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
+      if (dx * dx + dy * dy + dz * dz > triggersq) flags[FLAG_MOVED] = 1;
+    }
+  } else {
+    fx[p] = f0; fy[p] = f1; fz[p] = f2;
+  }
+  vx[p] = a; vy[p] = b; vz[p] = c;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -280,17 +412,52 @@ void launch_ke(DeviceState &d, const TypeTables &tt) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(k_ke, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2], tt, d.partial);
 }
+static ForceArgs force_args(DeviceState &d, const double sl[4]) {
+  ForceArgs A;
+  A.n = d.n; A.npad = d.npad; A.nblocks = (d.n + BLOCK - 1) / BLOCK; A.bpa = d.bpa; A.nt = d.ntypes + 1;
+  A.pos = d.pos; A.neigh = d.neigh; A.numneigh = d.numneigh; A.bpart = d.bpart; A.pairtab = d.pairtab;
+  A.sl0 = sl[0]; A.sl1 = sl[1]; A.sl2 = sl[2]; A.sl3 = sl[3];
+  A.uniform = d.pair_uniform; A.u_cutsq = d.pair_u[0]; A.u_lj1 = d.pair_u[1]; A.u_lj2 = d.pair_u[2];
+  A.u_lj3 = d.pair_u[3]; A.u_lj4 = d.pair_u[4]; A.u_off = d.pair_u[5];
+  A.has_sb = 0;
+  for (int k = 1; k <= 3; k++) if (sl[k] != 0.0 && sl[k] != 1.0) A.has_sb = 1;
+  A.margin = d.cutneigh;
+  static int lim = getenv("LAMMPS_LE_NN_LIMIT") ? atoi(getenv("LAMMPS_LE_NN_LIMIT")) : (1 << 30);
+  A.nn_limit = lim;
+  return A;
+}
 void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool eflag, bool has_pair) {
-  int nb = (d.n + BLOCK - 1) / BLOCK;
-  int grid = xcd_grid(nb);
-  int nt = d.ntypes + 1;
-#define FRC(E, P)                                                                                               \
-  hipLaunchKernelGGL((k_force<E, P>), dim3(grid), dim3(BLOCK), 0, d.stream, d.n, d.npad, nb, d.pos, d.neigh,   \
-                     d.numneigh, d.bpart, d.bpa, d.pairtab, nt, sl[0], sl[1], sl[2], sl[3], bt, d.box, d.f[0],  \
-                     d.f[1], d.f[2], d.partial, d.flags)
+  ForceArgs A = force_args(d, sl);
+  int grid = xcd_grid(A.nblocks);
+#define FRC(E, P)                                                                                            \
+  hipLaunchKernelGGL((k_force<E, P>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, d.f[0], d.f[1],   \
+                     d.f[2], d.partial, d.flags)
   if (eflag) { if (has_pair) FRC(true, true); else FRC(true, false); }
   else { if (has_pair) FRC(false, true); else FRC(false, false); }
 #undef FRC
+}
+// fused force + Langevin + final_integrate [+ next initial_integrate]; swaps the position buffers when `next`
+void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const TypeTables &tt, bool langevin,
+                 bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check) {
+  ForceArgs A = force_args(d, sl);
+  int grid = xcd_grid(A.nblocks);
+#define STP(L, N, I, P)                                                                                      \
+  hipLaunchKernelGGL((k_step<L, N, I, P>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, tt, d.tag,   \
+                     d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2], d.pos_tmp, d.xhold, \
+                     dtv, triggersq, check ? 1 : 0, d.flags)
+  int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
+  switch (key) {
+    case 0: STP(false, false, false, false); break;  case 1: STP(false, false, false, true); break;
+    case 2: STP(false, false, true, false); break;   case 3: STP(false, false, true, true); break;
+    case 4: STP(false, true, false, false); break;   case 5: STP(false, true, false, true); break;
+    case 6: STP(false, true, true, false); break;    case 7: STP(false, true, true, true); break;
+    case 8: STP(true, false, false, false); break;   case 9: STP(true, false, false, true); break;
+    case 10: STP(true, false, true, false); break;   case 11: STP(true, false, true, true); break;
+    case 12: STP(true, true, false, false); break;   case 13: STP(true, true, false, true); break;
+    case 14: STP(true, true, true, false); break;    case 15: STP(true, true, true, true); break;
+  }
+#undef STP
+  if (next) std::swap(d.pos, d.pos_tmp);
 }
 
 // sum the per-block partials on the host in block order (deterministic)

@@ -23,14 +23,15 @@ constexpr int SCAN_BLOCK = 1024;
 __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__ pos, int *__restrict__ img, int npad,
                                                     Box box, int ncx, int ncy, int ncz, double cix, double ciy,
                                                     double ciz, int *__restrict__ cell_of,
-                                                    int *__restrict__ cell_count, int *__restrict__ flags) {
+                                                    int *__restrict__ cell_count, int *__restrict__ rank,
+                                                    int *__restrict__ flags) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
   double4 r = pos[p];
   if (!(isfinite(r.x) && isfinite(r.y) && isfinite(r.z))) {
     flags[FLAG_ERROR] = ERR_NONFINITE;
     cell_of[p] = 0;
-    atomicAdd(&cell_count[0], 1);
+    rank[p] = atomicAdd(&cell_count[0], 1);
     return;
   }
   double *c = &r.x;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
   cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
   int cell = (cz * ncy + cy) * ncx + cx;
   cell_of[p] = cell;
-  atomicAdd(&cell_count[cell], 1);
+  rank[p] = atomicAdd(&cell_count[cell], 1);   // arrival order inside the cell; k_sort_cells makes it canonical
 }
 
 // ---- exclusive scan of cell_count[0..m) into cell_start[0..m], three small kernels ----
@@ -100,13 +101,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int m, int *__restrict_
 }
 
 __global__ __launch_bounds__(BLOCK) void k_scatter(int n, const int *__restrict__ cell_of,
-                                                   const int *__restrict__ cell_start, int *__restrict__ cell_fill,
+                                                   const int *__restrict__ cell_start, const int *__restrict__ rank,
                                                    int *__restrict__ perm) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
-  int c = cell_of[p];
-  int slot = cell_start[c] + atomicAdd(&cell_fill[c], 1);
-  perm[slot] = p;
+  perm[cell_start[cell_of[p]] + rank[p]] = p;
 }
 // one thread per cell: order the cell's entries by tag so the final order is deterministic
 __global__ __launch_bounds__(BLOCK) void k_sort_cells(int ncells, const int *__restrict__ cell_start,
@@ -162,63 +161,107 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, 
   }
 }
 
-// full neighbor list of atom s: sweep the 27 cells around its cell; entries in (stencil, index) order
+// full neighbor list of atom s.  The 27-cell sweep is done as 9 (dy,dz) row segments: the three x-cells of a
+// row are one contiguous index range of the cell-sorted arrays (two ranges when the row wraps around the box),
+// so a lane streams ~9 candidates per range with independent loads in flight.  Exclusions are tested on
+// physical indices (the bead's own special list is translated through map[] once), the minimum image is
+// branch-free and skipped by wavefronts that are wholly interior.  Entries come out in (row segment, index)
+// order, which depends only on the sorted positions -> deterministic.
+constexpr int SPMAX = 8;   // special entries translated to indices and kept in registers; longer lists use tags
+
+template <bool NOSPECIAL, bool MINIMG>
+__device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const double4 *__restrict__ pos,
+                                            const int *__restrict__ tag, const Box &box, double cutneighsq, int n1,
+                                            int n2, int n3, const int (&spi)[SPMAX], const int *__restrict__ slist,
+                                            int sf1, int sf2, int sf3, int npad, int maxneigh,
+                                            int *__restrict__ neigh, int &cnt) {
+#pragma clang fp contract(fast)
+  for (int q = b; q < e; q++) {
+    double4 rj = pos[q];
+    double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
+    if (MINIMG) {
+      delx -= box.prd[0] * __builtin_rint(delx * box.iprd[0]);
+      dely -= box.prd[1] * __builtin_rint(dely * box.iprd[1]);
+      delz -= box.prd[2] * __builtin_rint(delz * box.iprd[2]);
+    }
+    double rsq = delx * delx + dely * dely + delz * delz;
+    if (rsq > cutneighsq || q == s) continue;
+    int entry = q;
+    if (!NOSPECIAL && n3 > 0) {
+      int which = 0;
+      if (n3 <= SPMAX) {
+#pragma unroll
+        for (int k = 0; k < SPMAX; k++)
+          if (k < n3 && spi[k] == q && which == 0) which = (k < n1) ? 1 : (k < n2) ? 2 : 3;
+      } else {
+        int tq = tag[q];
+        for (int k = 0; k < n3; k++)
+          if (slist[k] == tq) { which = (k < n1) ? 1 : (k < n2) ? 2 : 3; break; }
+      }
+      if (which) {
+        int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
+        if (sf == 0) continue;                       // weight 0.0: excluded from the list
+        if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
+      }
+    }
+    if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
+    cnt++;
+  }
+}
+
 template <bool NOSPECIAL>
 __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
-                                                       const int *__restrict__ tag,
+                                                       const int *__restrict__ tag, const int *__restrict__ map,
                                                        const int *__restrict__ cell_start, int ncx, int ncy, int ncz,
                                                        double cix, double ciy, double ciz, Box box, double cutneighsq,
-                                                       const int *__restrict__ nspecial,
+                                                       double margin, const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
-  if (s >= n) return;
-  double4 ri = pos[s];
+  bool active = s < n;
+  double4 ri = pos[active ? s : 0];
   int cx = (int)((ri.x - box.lo[0]) * cix), cy = (int)((ri.y - box.lo[1]) * ciy), cz = (int)((ri.z - box.lo[2]) * ciz);
   cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
   int n1 = 0, n2 = 0, n3 = 0;
   const int *slist = nullptr;
-  if (!NOSPECIAL) {
+  int spi[SPMAX];
+#pragma unroll
+  for (int k = 0; k < SPMAX; k++) spi[k] = -1;
+  if (!NOSPECIAL && active) {
     int t = tag[s];
     n1 = nspecial[3 * (size_t)t]; n2 = nspecial[3 * (size_t)t + 1]; n3 = nspecial[3 * (size_t)t + 2];
     slist = special + (size_t)t * ms;
+    if (n3 <= SPMAX) {
+#pragma unroll
+      for (int k = 0; k < SPMAX; k++) if (k < n3) spi[k] = map[slist[k]];
+    }
   }
-  const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
+  // positions were wrapped into the box just before this kernel: interior = farther than cutneigh from all faces
+  bool interior = ri.x > box.lo[0] + margin && ri.x < box.hi[0] - margin && ri.y > box.lo[1] + margin &&
+                  ri.y < box.hi[1] - margin && ri.z > box.lo[2] + margin && ri.z < box.hi[2] - margin;
+  bool all_in = __all(interior || !active);
+  if (!active) return;
   int cnt = 0;
+  int x0 = cx - 1, x1 = cx + 1;   // x-cell range, may stick out of [0, ncx)
   for (int dz = -1; dz <= 1; dz++) {
     int az = cz + dz; if (az < 0) az += ncz; else if (az >= ncz) az -= ncz;
     for (int dy = -1; dy <= 1; dy++) {
       int ay = cy + dy; if (ay < 0) ay += ncy; else if (ay >= ncy) ay -= ncy;
-      for (int dx = -1; dx <= 1; dx++) {
-        int ax = cx + dx; if (ax < 0) ax += ncx; else if (ax >= ncx) ax -= ncx;
-        int c = (az * ncy + ay) * ncx + ax;
-        int b = cell_start[c], e = cell_start[c + 1];
-        for (int q = b; q < e; q++) {
-          if (q == s) continue;
-          double4 rj = pos[q];
-          double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
-          if (delx > hx) delx -= box.prd[0]; else if (delx < -hx) delx += box.prd[0];
-          if (dely > hy) dely -= box.prd[1]; else if (dely < -hy) dely += box.prd[1];
-          if (delz > hz) delz -= box.prd[2]; else if (delz < -hz) delz += box.prd[2];
-          double rsq = delx * delx + dely * dely + delz * delz;
-          if (rsq > cutneighsq) continue;
-          int entry = q;
-          if (!NOSPECIAL && n3 > 0) {
-            int tq = tag[q];
-            int which = 0;
-            for (int k = 0; k < n3; k++)
-              if (slist[k] == tq) { which = (k < n1) ? 1 : (k < n2) ? 2 : 3; break; }
-            if (which) {
-              int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
-              if (sf == 0) continue;                       // weight 0.0: excluded from the list
-              if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
-            }
-          }
-          if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
-          cnt++;
-        }
-      }
+      int row = (az * ncy + ay) * ncx;
+      // up to three pieces: wrapped low part, main part, wrapped high part (in increasing cell order)
+      int lo = max(x0, 0), hi = min(x1, ncx - 1);
+#define RANGE(B, E)                                                                                              \
+  do {                                                                                                            \
+    if (all_in) neigh_range<NOSPECIAL, false>(s, B, E, ri, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist,   \
+                                              sf1, sf2, sf3, npad, maxneigh, neigh, cnt);                         \
+    else neigh_range<NOSPECIAL, true>(s, B, E, ri, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2,  \
+                                      sf3, npad, maxneigh, neigh, cnt);                                           \
+  } while (0)
+      if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + 1]);                      // cell 0 (image of ncx)
+      RANGE(cell_start[row + lo], cell_start[row + hi + 1]);
+      if (x0 < 0) RANGE(cell_start[row + ncx - 1], cell_start[row + ncx]);             // cell ncx-1 (image of -1)
+#undef RANGE
     }
   }
   numneigh[s] = min(cnt, maxneigh);
@@ -230,16 +273,15 @@ void launch_reneighbor(DeviceState &d, double cutneighsq, const double sl[4], bo
   int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
   hipStream_t st = d.stream;
   HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(d.ncells + 1) * sizeof(int), st));
-  HIP_CHECK(hipMemsetAsync(d.cell_fill, 0, (size_t)(d.ncells + 1) * sizeof(int), st));
   hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.img, d.npad, d.box, d.ncell[0],
                      d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.cell_of, d.cell_count,
-                     d.flags);
+                     d.tag_tmp, d.flags);
   int sb = (d.ncells + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, d.ncells, d.cell_count, d.cell_start,
                      d.scan_tmp);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sb, d.scan_tmp);
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, st, d.ncells, d.cell_start, d.scan_tmp, n);
-  hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, n, d.cell_of, d.cell_start, d.cell_fill, d.perm);
+  hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, n, d.cell_of, d.cell_start, d.tag_tmp, d.perm);
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
                      d.cell_start, d.perm, d.tag);
   hipLaunchKernelGGL(k_permute, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.perm, d.pos, d.pos_tmp, d.xhold, d.v[0],
@@ -254,16 +296,17 @@ void launch_reneighbor(DeviceState &d, double cutneighsq, const double sl[4], bo
     auto sflag = [](double w) { return w == 0.0 ? 0 : (w == 1.0 ? 1 : 2); };
     int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
     HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), st));
+    double margin = sqrt(cutneighsq) * (1.0 + 1e-12);
     if (sf1 == 1 && sf2 == 1 && sf3 == 1)
       hipLaunchKernelGGL((k_build_neigh<true>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag,
-                         d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2],
-                         d.box, cutneighsq, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3, d.neigh, d.numneigh,
-                         d.flags);
+                         d.map, d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1],
+                         d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3,
+                         d.neigh, d.numneigh, d.flags);
     else
       hipLaunchKernelGGL((k_build_neigh<false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag,
-                         d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2],
-                         d.box, cutneighsq, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3, d.neigh, d.numneigh,
-                         d.flags);
+                         d.map, d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1],
+                         d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3,
+                         d.neigh, d.numneigh, d.flags);
   }
 }
 

@@ -37,8 +37,16 @@ __global__ __launch_bounds__(64) void k_rng_langevin(int B, long long total, uns
     if (lane < 33 && i < G) buf[97 + i] = (buf[i] - buf[i + 64]) & M24;
     __syncthreads();
   }
-  for (int i = lane; i < nout; i += 64)
-    out[off + i] = (buf[97 + i] - c_of_dev(first_raw + (unsigned long long)(off + i))) & M24;
+  {
+    // arithmetic sequence term: one exact evaluation per lane, then steps of 64 draws (c -= 64*cd mod cm)
+    const int CM = 16777213, STEP64 = (int)((64ull * 7654321ull) % 16777213ull);
+    int c = (int)c_of_dev(first_raw + (unsigned long long)(off + lane));
+    for (int i = lane; i < nout; i += 64) {
+      out[off + i] = (buf[97 + i] - (uint32_t)c) & M24;
+      c -= STEP64;
+      if (c < 0) c += CM;
+    }
+  }
   // window for the next call: y'[i] = sum_j a[j] * y[i + j]
   uint32_t acc0 = 0, acc1 = 0;
   int i1 = lane + 64;
@@ -57,10 +65,19 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
   d.rng_nblocks = (int)((total + d.rng_B - 1) / d.rng_B);
   if (d.rng_state) { (void)hipFree(d.rng_state); d.rng_state = nullptr; }
   if (d.rng_jump) { (void)hipFree(d.rng_jump); d.rng_jump = nullptr; }
-  if (d.rng_out) { (void)hipFree(d.rng_out); d.rng_out = nullptr; }
+  for (int k = 0; k < 2; k++) if (d.rng_buf[k]) { (void)hipFree(d.rng_buf[k]); d.rng_buf[k] = nullptr; }
+  d.rng_out = nullptr;
   HIP_CHECK(hipMalloc(&d.rng_state, (size_t)d.rng_nblocks * 97 * sizeof(uint32_t)));
   HIP_CHECK(hipMalloc(&d.rng_jump, 97 * sizeof(uint32_t)));
-  HIP_CHECK(hipMalloc(&d.rng_out, (size_t)total * sizeof(uint32_t)));
+  for (int k = 0; k < 2; k++) HIP_CHECK(hipMalloc(&d.rng_buf[k], (size_t)total * sizeof(uint32_t)));
+  d.rng_cur = 0; d.rng_out = d.rng_buf[0]; d.rng_ahead = false;
+  if (!d.rng_stream) {
+    HIP_CHECK(hipStreamCreateWithFlags(&d.rng_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+      HIP_CHECK(hipEventCreateWithFlags(&d.rng_done[k], hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&d.rng_consumed[k], hipEventDisableTiming));
+    }
+  }
   std::vector<uint32_t> st((size_t)d.rng_nblocks * 97);
   RanMarsInt r = host_rng;   // positioned at the first draw of the next call
   for (int b = 0; b < d.rng_nblocks; b++) {
@@ -74,11 +91,29 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
   HIP_CHECK(hipStreamSynchronize(d.stream));
 }
 
-void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
+// Draws for the call whose first raw index is `first_raw` end up in d.rng_out before the consumer kernel runs
+// on d.stream.  The generator runs on its own stream one call AHEAD (the stream is deterministic: the next
+// call always starts 3N draws later), so it overlaps the force kernel of the previous step; the two draw
+// buffers alternate and events order producer / consumer.
+static void rng_generate(DeviceState &d, int buf, uint64_t first_raw) {
   long long total = 3ll * d.n;
-  hipLaunchKernelGGL(k_rng_langevin, dim3(d.rng_nblocks), dim3(64), 0, d.stream, d.rng_B, total,
-                     (unsigned long long)first_raw, d.rng_state, d.rng_jump, d.rng_out);
+  // the buffer may still be read by the consumer of two calls ago
+  HIP_CHECK(hipStreamWaitEvent(d.rng_stream, d.rng_consumed[buf], 0));
+  hipLaunchKernelGGL(k_rng_langevin, dim3(d.rng_nblocks), dim3(64), 0, d.rng_stream, d.rng_B, total,
+                     (unsigned long long)first_raw, d.rng_state, d.rng_jump, d.rng_buf[buf]);
+  HIP_CHECK(hipEventRecord(d.rng_done[buf], d.rng_stream));
 }
+void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
+  if (!d.rng_ahead) rng_generate(d, d.rng_cur, first_raw);
+  else d.rng_cur ^= 1;                                   // generated ahead during the previous call
+  d.rng_out = d.rng_buf[d.rng_cur];
+  HIP_CHECK(hipStreamWaitEvent(d.stream, d.rng_done[d.rng_cur], 0));
+  // run ahead: the following call's draws
+  rng_generate(d, d.rng_cur ^ 1, first_raw + 3ull * (uint64_t)d.n);
+  d.rng_ahead = true;
+}
+// to be called right after the consumer kernel of the current draws has been enqueued on d.stream
+void rng_langevin_consumed(DeviceState &d) { HIP_CHECK(hipEventRecord(d.rng_consumed[d.rng_cur], d.stream)); }
 
 // ------------------------------------------------------------------------------------------
 // serial-stream generator for the LE fixes: `count` (device-resident) draws from one RanMars state,
