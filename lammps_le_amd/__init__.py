@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liblammps_le.so")
 
-__all__ = ["lammps", "LammpsError", "library_path"]
+__all__ = ["lammps", "LammpsError", "library_path", "comm_unique_id", "init_from_torch_distributed"]
 
 
 class LammpsError(Exception):
@@ -185,3 +185,38 @@ class lammps(object):
 
     def stat(self, name):
         return self.lib.lammps_le_stat(self.lmp, name.encode())
+
+    # -- ranks: one process per GPU, z-slab spatial decomposition (engine extension) --
+    def comm_init(self, backend, rank, world, unique_id=b"", session="default"):
+        """Join a group of `world` engine instances.  backend "rccl": unique_id = the 128-byte ncclUniqueId
+        created on rank 0 by `comm_unique_id()` and broadcast by the launcher; backend "shm": file mailbox under
+        /dev/shm (test transport).  Must be called before the first run; every rank then issues the same commands."""
+        self.lib.lammps_le_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        buf = C.create_string_buffer(bytes(unique_id).ljust(128, b"\0"), 128)
+        self.lib.lammps_le_comm_init(self.lmp, backend.encode(), rank, world, buf, session.encode())
+        self._check()
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, the launcher broadcasts it)."""
+    lib = _load()
+    buf = C.create_string_buffer(128)
+    if lib.lammps_le_comm_unique_id(buf) != 0:
+        raise LammpsError("could not create an RCCL unique id")
+    return buf.raw
+
+
+def init_from_torch_distributed(lmp):
+    """Give every rank of an initialised torch.distributed group the same RCCL unique id and join the engine's
+    own communicator (RANK / WORLD_SIZE from the process group).  Used by bench.py."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if world == 1:
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).to(dev)
+    dist.broadcast(t, src=0)
+    lmp.comm_init("rccl", rank, world, bytes(t.cpu().numpy().tobytes()))

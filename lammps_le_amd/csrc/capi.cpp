@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "../../include/lammps_le.h"
+#include "comm.h"
 #include "device.h"
 
 using namespace lmp_le;
@@ -265,4 +266,35 @@ extern "C" void lammps_le_test_ranmars(int seed, long long skip, int n, double *
   r.seed(seed);
   r.jump((uint64_t)skip);
   for (int i = 0; i < n; i++) out[i] = r.uniform();
+}
+
+// ---- ranks: one process per GPU (bench.py passes the ncclUniqueId it broadcast with torch.distributed) ----
+extern "C" int lammps_le_comm_unique_id(char *out128) {
+  try { lmp_le::comm_unique_id(out128); return 0; } catch (const std::exception &ex) { fprintf(stderr, "%s\n", ex.what()); return 1; }
+}
+extern "C" void lammps_le_comm_init(void *handle, const char *backend, int rank, int world, const char *unique_id,
+                                    const char *session) {
+  BEGIN_CAPTURE e->comm_init(backend, rank, world, unique_id, session ? session : "default"); END_CAPTURE
+}
+// transport self-test without a GPU ("shm" backend): ring exchange + all-gather + max-reduce; returns 0 on success
+extern "C" int lammps_le_comm_selftest(const char *session, int rank, int world) {
+  using namespace lmp_le;
+  try {
+    Comm c;
+    c.init("shm", rank, world, nullptr, session);
+    int up = (rank + 1) % world, dn = (rank + world - 1) % world;
+    double sendv[4] = {rank + 0.25, rank + 0.5, 0, 0}, recvv[4] = {0, 0, 0, 0};
+    c.exchange_host({{&sendv[0], sizeof(double), dn}, {&sendv[1], sizeof(double), up}},
+                    {{&recvv[1], sizeof(double), up}, {&recvv[0], sizeof(double), dn}});
+    if (recvv[1] != up + 0.25 || recvv[0] != dn + 0.5) return 2;
+    std::vector<int> all(world);
+    int mine = 100 + rank;
+    c.allgather_host(&mine, all.data(), sizeof(int));
+    for (int r = 0; r < world; r++) if (all[r] != 100 + r) return 3;
+    if (c.allreduce_host_max(rank * 7) != (world - 1) * 7) return 4;
+    double s = c.allreduce_host_sum((double)rank);
+    if (s != world * (world - 1) / 2.0) return 5;
+    c.barrier();
+    return 0;
+  } catch (const std::exception &ex) { fprintf(stderr, "%s\n", ex.what()); return 1; }
 }

@@ -1,0 +1,238 @@
+// comm.cpp — inter-rank transport for the spatially decomposed engine (one process per GPU).
+//
+// Replaces the reference's MPI call sites on the hot path (CommBrick forward/exchange/borders,
+// the 1-int MPI_Allreduce of Neighbor::check_distance, the LE fixes' counters) with:
+//   * backend "rccl": grouped ncclSend/ncclRecv between slab neighbours over xGMI, ncclAllReduce on 4-byte
+//     flags, ncclAllGather for the rare whole-system gathers.  librccl is dlopen'ed on first use so that
+//     single-GPU runs and CPU-only hosts never touch it.  The ncclUniqueId travels through whatever launched
+//     the ranks (bench.py broadcasts it with torch.distributed).
+//   * backend "shm": a file mailbox under /dev/shm with host staging.  Test transport only — it lets several
+//     ranks share ONE GPU (RCCL refuses duplicate devices) so that the decomposition is verified against the
+//     oracle on the single-GPU box, and it runs without any GPU for the transport self-test.
+#include "comm.h"
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace lmp_le {
+
+// ---------------------------------------------------------------------------------------------
+// RCCL through dlopen
+// ---------------------------------------------------------------------------------------------
+namespace {
+typedef struct ncclComm *ncclComm_t;
+struct ncclUniqueId_ { char internal[128]; };
+enum { ncclInt32 = 2, ncclInt8 = 0, ncclFloat64 = 8 };
+enum { ncclSum = 0, ncclMax = 2 };
+struct Rccl {
+  void *h = nullptr;
+  int (*GetUniqueId)(ncclUniqueId_ *) = nullptr;
+  int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId_, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  void load() {
+    if (h) return;
+    h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) throw LammpsError(std::string("cannot load librccl.so: ") + dlerror());
+#define SYM(f) *(void **)(&f) = dlsym(h, "nccl" #f); if (!f) throw LammpsError("librccl.so lacks nccl" #f)
+    SYM(GetUniqueId); SYM(CommInitRank); SYM(CommDestroy); SYM(GroupStart); SYM(GroupEnd); SYM(Send); SYM(Recv);
+    SYM(AllReduce); SYM(AllGather); SYM(GetErrorString);
+#undef SYM
+  }
+} rccl;
+ncclComm_t g_comm = nullptr;
+#define NCCL_CHECK(x) do { int r_ = (x); if (r_ != 0) throw LammpsError(std::string("RCCL error: ") + rccl.GetErrorString(r_)); } while (0)
+}  // namespace
+
+void comm_unique_id(char out[128]) {
+  rccl.load();
+  ncclUniqueId_ id;
+  NCCL_CHECK(rccl.GetUniqueId(&id));
+  memcpy(out, id.internal, 128);
+}
+
+// ---------------------------------------------------------------------------------------------
+// file mailbox (test transport)
+// ---------------------------------------------------------------------------------------------
+static std::string box_path(const std::string &dir, int src, int dst, long seq) {
+  return dir + "/m_" + std::to_string(src) + "_" + std::to_string(dst) + "_" + std::to_string(seq);
+}
+void Comm::shm_send(int dst, const void *buf, size_t bytes) {
+  long seq = shm_sent[dst]++;
+  std::string fin = box_path(shm_dir, rank, dst, seq), tmp = fin + ".tmp";
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) throw LammpsError("shm transport: cannot write " + tmp);
+  if (bytes) fwrite(buf, 1, bytes, f);
+  fclose(f);
+  if (rename(tmp.c_str(), fin.c_str()) != 0) throw LammpsError("shm transport: rename failed");
+}
+void Comm::shm_recv(int src, void *buf, size_t bytes) {
+  long seq = shm_rcvd[src]++;
+  std::string fin = box_path(shm_dir, src, rank, seq);
+  struct stat st;
+  long waited = 0;
+  while (stat(fin.c_str(), &st) != 0) {
+    usleep(50);
+    if ((waited += 50) > 120L * 1000000L) throw LammpsError("shm transport: timeout waiting for " + fin);
+  }
+  if ((size_t)st.st_size != bytes)
+    throw LammpsError("shm transport: size mismatch on " + fin + " (" + std::to_string(st.st_size) + " vs " + std::to_string(bytes) + ")");
+  FILE *f = fopen(fin.c_str(), "rb");
+  if (bytes && fread(buf, 1, bytes, f) != bytes) { fclose(f); throw LammpsError("shm transport: short read"); }
+  fclose(f);
+  unlink(fin.c_str());
+}
+
+// ---------------------------------------------------------------------------------------------
+void Comm::init(const std::string &backend_name, int rank_, int world_, const void *id, const std::string &session) {
+  rank = rank_; world = world_;
+  if (world <= 1) { backend = NONE; return; }
+  if (backend_name == "rccl") {
+    rccl.load();
+    ncclUniqueId_ uid;
+    memcpy(uid.internal, id, 128);
+    NCCL_CHECK(rccl.CommInitRank(&g_comm, world, uid, rank));
+    backend = RCCL;
+  } else if (backend_name == "shm") {
+    shm_dir = "/dev/shm/le_" + session;
+    mkdir(shm_dir.c_str(), 0777);
+    shm_sent.assign(world, 0); shm_rcvd.assign(world, 0);
+    backend = SHM;
+  } else throw LammpsError("unknown comm backend " + backend_name);
+}
+void Comm::finalize() {
+  if (backend == RCCL && g_comm) { rccl.CommDestroy(g_comm); g_comm = nullptr; }
+  backend = NONE;
+}
+
+// host collectives (small, rebuild-time only)
+void Comm::allgather_host(const void *send, void *recv, size_t bytes) {
+  if (backend == NONE) { memcpy(recv, send, bytes); return; }
+  if (backend == SHM) {
+    for (int r = 0; r < world; r++) if (r != rank) shm_send(r, send, bytes);
+    for (int r = 0; r < world; r++) {
+      if (r == rank) memcpy((char *)recv + (size_t)r * bytes, send, bytes);
+      else shm_recv(r, (char *)recv + (size_t)r * bytes, bytes);
+    }
+    return;
+  }
+  // RCCL: through a small device bounce buffer
+  ensure_bounce(bytes * world + bytes);
+  HIP_CHECK(hipMemcpy(bounce, send, bytes, hipMemcpyHostToDevice));
+  NCCL_CHECK(rccl.AllGather(bounce, (char *)bounce + bytes, bytes, ncclInt8, g_comm, nullptr));
+  HIP_CHECK(hipStreamSynchronize(nullptr));
+  HIP_CHECK(hipMemcpy(recv, (char *)bounce + bytes, bytes * world, hipMemcpyDeviceToHost));
+}
+void Comm::ensure_bounce(size_t bytes) {
+  if (bytes <= bounce_bytes) return;
+  if (bounce) (void)hipFree(bounce);
+  HIP_CHECK(hipMalloc(&bounce, bytes));
+  bounce_bytes = bytes;
+}
+void Comm::ensure_hbuf(size_t bytes) {
+  if (hbuf.size() < bytes) hbuf.resize(bytes);
+}
+double Comm::allreduce_host_sum(double v) {
+  std::vector<double> all(world);
+  allgather_host(&v, all.data(), sizeof(double));
+  double s = 0.0;
+  for (double x : all) s += x;
+  return s;
+}
+void Comm::allreduce_host_sum(double *v, int n) {
+  std::vector<double> all((size_t)world * n);
+  allgather_host(v, all.data(), n * sizeof(double));
+  for (int k = 0; k < n; k++) { double s = 0.0; for (int r = 0; r < world; r++) s += all[(size_t)r * n + k]; v[k] = s; }
+}
+long Comm::allreduce_host_max(long v) {
+  std::vector<long> all(world);
+  allgather_host(&v, all.data(), sizeof(long));
+  long m = all[0];
+  for (long x : all) m = x > m ? x : m;
+  return m;
+}
+
+// device collectives
+void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
+  if (backend == NONE) return;
+  if (backend == RCCL) { NCCL_CHECK(rccl.AllReduce(dev, dev, n, ncclInt32, ncclMax, g_comm, st)); return; }
+  std::vector<int> h(n), all((size_t)world * n);
+  HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  allgather_host(h.data(), all.data(), n * sizeof(int));
+  for (int k = 0; k < n; k++) for (int r = 0; r < world; r++) h[k] = std::max(h[k], all[(size_t)r * n + k]);
+  HIP_CHECK(hipMemcpyAsync(dev, h.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+}
+void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_t bytes) {
+  if (backend == NONE) { HIP_CHECK(hipMemcpyAsync(recv_dev, send_dev, bytes, hipMemcpyDeviceToDevice, st)); return; }
+  if (backend == RCCL) { NCCL_CHECK(rccl.AllGather(send_dev, recv_dev, bytes, ncclInt8, g_comm, st)); return; }
+  ensure_hbuf(bytes * (world + 1));
+  HIP_CHECK(hipMemcpyAsync(hbuf.data(), send_dev, bytes, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  allgather_host(hbuf.data(), hbuf.data() + bytes, bytes);
+  HIP_CHECK(hipMemcpyAsync(recv_dev, hbuf.data() + bytes, bytes * world, hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+}
+// grouped point-to-point: all sends and receives of one halo / migration phase
+void Comm::exchange(hipStream_t st, const std::vector<Msg> &sends, const std::vector<Msg> &recvs) {
+  if (backend == NONE) return;
+  if (backend == RCCL) {
+    NCCL_CHECK(rccl.GroupStart());
+    for (auto &m : sends) if (m.bytes) NCCL_CHECK(rccl.Send(m.dev, m.bytes, ncclInt8, m.peer, g_comm, st));
+    for (auto &m : recvs) if (m.bytes) NCCL_CHECK(rccl.Recv(m.dev, m.bytes, ncclInt8, m.peer, g_comm, st));
+    NCCL_CHECK(rccl.GroupEnd());
+    return;
+  }
+  size_t mx = 0;
+  for (auto &m : sends) mx = std::max(mx, m.bytes);
+  for (auto &m : recvs) mx = std::max(mx, m.bytes);
+  ensure_hbuf(mx);
+  for (auto &m : sends) {
+    if (m.bytes) { HIP_CHECK(hipMemcpyAsync(hbuf.data(), m.dev, m.bytes, hipMemcpyDeviceToHost, st)); HIP_CHECK(hipStreamSynchronize(st)); }
+    shm_send(m.peer, hbuf.data(), m.bytes);
+  }
+  for (auto &m : recvs) {
+    shm_recv(m.peer, hbuf.data(), m.bytes);
+    if (m.bytes) { HIP_CHECK(hipMemcpyAsync(m.dev, hbuf.data(), m.bytes, hipMemcpyHostToDevice, st)); HIP_CHECK(hipStreamSynchronize(st)); }
+  }
+}
+// host-memory variant of exchange (counts; also the GPU-less transport self-test)
+void Comm::exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &recvs) {
+  if (backend == NONE) return;
+  if (backend == SHM) {
+    for (auto &m : sends) shm_send(m.peer, m.dev, m.bytes);
+    for (auto &m : recvs) shm_recv(m.peer, m.dev, m.bytes);
+    return;
+  }
+  size_t tot = 0;
+  for (auto &m : sends) tot += m.bytes;
+  for (auto &m : recvs) tot += m.bytes;
+  ensure_bounce(tot + 64);
+  char *p = (char *)bounce;
+  std::vector<Msg> ds, dr;
+  for (auto &m : sends) { HIP_CHECK(hipMemcpy(p, m.dev, m.bytes, hipMemcpyHostToDevice)); ds.push_back({p, m.bytes, m.peer}); p += m.bytes; }
+  for (auto &m : recvs) { dr.push_back({p, m.bytes, m.peer}); p += m.bytes; }
+  exchange(nullptr, ds, dr);
+  HIP_CHECK(hipStreamSynchronize(nullptr));
+  for (size_t k = 0; k < recvs.size(); k++) HIP_CHECK(hipMemcpy(recvs[k].dev, dr[k].dev, recvs[k].bytes, hipMemcpyDeviceToHost));
+}
+void Comm::barrier() {
+  int x = 1;
+  std::vector<int> all(world);
+  allgather_host(&x, all.data(), sizeof(int));
+}
+
+}  // namespace lmp_le

@@ -1,0 +1,43 @@
+// comm.h — inter-rank transport of the decomposed engine (see comm.cpp)
+#pragma once
+#include <string>
+#include <vector>
+
+#include "device.h"
+
+namespace lmp_le {
+
+struct Msg { void *dev; size_t bytes; int peer; };
+
+struct Comm {
+  enum Backend { NONE, RCCL, SHM } backend = NONE;
+  int rank = 0, world = 1;
+  void init(const std::string &backend_name, int rank, int world, const void *unique_id, const std::string &session);
+  void finalize();
+  // device buffers
+  void exchange(hipStream_t st, const std::vector<Msg> &sends, const std::vector<Msg> &recvs);
+  void allreduce_int_max(hipStream_t st, int *dev, int n);
+  void allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+  // host buffers (rebuild-time counts, thermo sums)
+  void exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &recvs);
+  void allgather_host(const void *send, void *recv, size_t bytes_per_rank);
+  double allreduce_host_sum(double v);
+  void allreduce_host_sum(double *v, int n);
+  long allreduce_host_max(long v);
+  void barrier();
+
+ private:
+  std::string shm_dir;
+  std::vector<long> shm_sent, shm_rcvd;
+  void shm_send(int dst, const void *buf, size_t bytes);
+  void shm_recv(int src, void *buf, size_t bytes);
+  void *bounce = nullptr;
+  size_t bounce_bytes = 0;
+  std::vector<char> hbuf;
+  void ensure_bounce(size_t bytes);
+  void ensure_hbuf(size_t bytes);
+};
+
+void comm_unique_id(char out[128]);
+
+}  // namespace lmp_le

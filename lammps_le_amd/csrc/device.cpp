@@ -1,6 +1,7 @@
 // device.cpp — HBM allocation for one engine instance (288 GB per MI355X: everything stays resident).
 #include "device.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace lmp_le {
@@ -32,6 +33,8 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   d.bpa = bpa;
   d.maxspecial = maxspecial;
   d.box = box;
+  d.ntotal = maxtag;
+  if (!d.dd) d.zlo_ext = box.lo[2];
   size_t np = d.npad, nt = (size_t)maxtag + 2;
   dalloc(d.pos, np); dalloc(d.pos_tmp, np); dalloc(d.xhold, np);
   for (int k = 0; k < 3; k++) { dalloc(d.v[k], np); dalloc(d.v_tmp[k], np); dalloc(d.f[k], np); }
@@ -43,10 +46,11 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   // cells of edge >= cutneigh
   d.ncells = 1;
   for (int k = 0; k < 3; k++) {
-    d.ncell[k] = cutneigh > 0.0 ? (int)(box.prd[k] / cutneigh) : 1;
+    double extent = (k == 2 && d.dd) ? (d.slab_hi - d.slab_lo) + 2.0 * d.cutghost : box.prd[k];
+    d.ncell[k] = cutneigh > 0.0 ? (int)(extent / cutneigh) : 1;
     if (d.ncell[k] < 1) d.ncell[k] = 1;
     // keep cells from getting needlessly tiny for bond-only runs
-    d.cellinv[k] = d.ncell[k] / box.prd[k];
+    d.cellinv[k] = d.ncell[k] / extent;
     d.ncells *= d.ncell[k];
   }
   dalloc(d.cell_of, np); dalloc(d.cell_count, (size_t)d.ncells + 1); dalloc(d.cell_start, (size_t)d.ncells + 1);
@@ -67,13 +71,14 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   HIP_CHECK(hipHostGetDevicePointer((void **)&d.flags_h_dev, d.flags_h, 0));
   // LE fix scratch
   dalloc(d.xt, nt);
+  dalloc(d.xht, nt);
   for (int k = 0; k < 16; k++) dalloc(d.le_i[k], nt);
   for (int k = 0; k < 2; k++) dalloc(d.le_d[k], nt);
   dalloc(d.le_bits, nt / 64 + 16);
   dalloc(d.le_rng_state, 3 * 100);
   dalloc(d.le_draws, nt);
   dalloc(d.le_list, 4 * nt);
-  dalloc(d.le_scan, nt / 1024 + 16);
+  dalloc(d.le_scan, std::max(nt, (size_t)d.ncells + 2) / 1024 + 16);
 }
 
 void dev_free(DeviceState &d) {
@@ -90,7 +95,10 @@ void dev_free(DeviceState &d) {
   if (d.flags_h) (void)hipHostFree(d.flags_h);
   d.flags_h = nullptr;
   dfree(d.rng_state); dfree(d.rng_jump); dfree(d.rng_buf[0]); dfree(d.rng_buf[1]); d.rng_out = nullptr;
-  dfree(d.xt);
+  dfree(d.xt); dfree(d.xht);
+  dfree(d.gcell_start); dfree(d.gcell_count); dfree(d.sendlist[0]); dfree(d.sendlist[1]); dfree(d.migbuf[0]);
+  dfree(d.migbuf[1]); dfree(d.migin); dfree(d.sendbuf); dfree(d.recvbuf); dfree(d.gdest); dfree(d.gtag_in);
+  dfree(d.gather_send); d.gather_recv = nullptr; d.gather_cap = 0;
   for (int k = 0; k < 16; k++) dfree(d.le_i[k]);
   for (int k = 0; k < 2; k++) dfree(d.le_d[k]);
   dfree(d.le_bits); dfree(d.le_rng_state); dfree(d.le_draws); dfree(d.le_list); dfree(d.le_scan);

@@ -102,6 +102,21 @@ struct DeviceState {
   uint32_t *le_draws = nullptr;       // [maxtag+2]
   int *le_list = nullptr;             // extruder listings [4][maxtag+2]
   int *le_scan = nullptr;
+  // ---- spatial decomposition (z slabs; world > 1) ----
+  int dd = 0;                      // 1 = this rank owns a z slab, ghosts at [n, n + nghost)
+  int nghost = 0;
+  int ntotal = 0;                  // beads in the whole system
+  double slab_lo = 0.0, slab_hi = 0.0, cutghost = 0.0, zlo_ext = 0.0;
+  int *gcell_start = nullptr, *gcell_count = nullptr;   // ghost ranges per cell (relative to n)
+  int *sendlist[2] = {nullptr, nullptr};                // owned indices sent down / up every step
+  int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
+  double4 *sendbuf = nullptr, *recvbuf = nullptr;       // halo staging
+  int *gdest = nullptr;                                 // arrival order -> sorted ghost slot
+  int *gtag_in = nullptr;                               // ghost tags in arrival order
+  double *migbuf[2] = {nullptr, nullptr}, *migin = nullptr;   // migrating beads (MIG_W doubles each)
+  double4 *xht = nullptr;                               // [maxtag+2] xhold by tag (LE fixes)
+  double *gather_send = nullptr, *gather_recv = nullptr;      // whole-system gathers
+  size_t gather_cap = 0;
   // ---- kernel timing (HIP events on the launch stream) ----
   std::vector<hipEvent_t> ev0, ev1;
   size_t ev_used = 0;
@@ -126,6 +141,8 @@ void reduce_partials(DeviceState &d, double *out16);
 
 // neighbor (kernels_neigh.hip)
 void launch_reneighbor(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
+void launch_sort_owned(DeviceState &d);
+void launch_lists(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
 
 // rng (kernels_rng.hip)
 void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms);
@@ -153,5 +170,7 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
 void launch_ex_unload(DeviceState &d, const ExUnloadParams &p, int rng_slot);
 void launch_extrusion(DeviceState &d, const ExtrusionParams &p, int rng_slot);
 void sync_flags(DeviceState &d);   // copy flags to flags_h and wait
+void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);
+void dd_alloc(DeviceState &d, int world);
 
 }  // namespace lmp_le

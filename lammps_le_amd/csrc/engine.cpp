@@ -6,9 +6,15 @@
 #include <cmath>
 #include <cstring>
 
+#include "comm.h"
 #include "device.h"
 
 namespace lmp_le {
+
+void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair);
+void dd_halo(DeviceState &d, Comm &comm);
+void dd_gather_positions(DeviceState &d, Comm &comm);
+void dd_gather_all(DeviceState &d, Comm &comm, std::vector<double> &rows, int &stride);
 
 static double wall() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -40,8 +46,19 @@ Engine::~Engine() {
     try { dev_free(*dev); } catch (...) {}
     delete dev;
   }
+  if (comm) { try { comm->finalize(); } catch (...) {} delete comm; }
   if (logfile) fclose(logfile);
 }
+
+void Engine::comm_init(const std::string &backend, int rank_, int world_, const void *unique_id, const std::string &session) {
+  if (dev && dev->pos) throw LammpsError("comm must be initialised before the first run");
+  if (!comm) comm = new Comm();
+  if (world_ > 1) device_init();
+  comm->init(backend, rank_, world_, unique_id, session);
+  rank = rank_; world = world_;
+  if (rank != 0) screen = nullptr;
+}
+void Engine::halo_exchange() { if (world > 1) dd_halo(*dev, *comm); }
 
 void Engine::say(const std::string &s) {
   if (screen) { fputs(s.c_str(), screen); fflush(screen); }
@@ -124,14 +141,30 @@ void Engine::upload() {
                         "not supported by the MI355X engine (minimum-image cell lists)");
   }
   DeviceState &d = *dev;
-  bool realloc = (d.n != natoms || d.bpa != bpa || d.maxspecial != maxspecial || d.ntypes != ntypes || !d.pos);
+  bool realloc = (d.ntotal != natoms || d.bpa != bpa || d.maxspecial != maxspecial || d.ntypes != ntypes || !d.pos);
   double cellcut = cutneighmax > 0.0 ? cutneighmax : std::max({box.prd[0], box.prd[1], box.prd[2]}) / 3.0;
+  if (world > 1) {
+    // z-slab decomposition: rank r owns z in [lo + r*w, lo + (r+1)*w); ghost shell = max(neighbor cutoff, comm cutoff)
+    if (sortfreq > 0) throw LammpsError("spatial decomposition needs atom_modify sort 0 0 (canonical draw order)");
+    d.dd = 1;
+    double w = box.prd[2] / world;
+    d.slab_lo = box.lo[2] + rank * w;
+    d.slab_hi = d.slab_lo + w;
+    d.cutghost = std::max(cutneighmax, comm_cutoff);
+    d.zlo_ext = d.slab_lo - d.cutghost;
+    if (w < 2.0 * d.cutghost)
+      throw LammpsError("slab thinner than two ghost cutoffs: use fewer GPUs or a smaller comm_modify cutoff");
+    if (w + 2.0 * d.cutghost > box.prd[2]) throw LammpsError("ghost shells of a slab overlap: box too small for this many GPUs");
+  }
   if (!realloc)
-    for (int k = 0; k < 3; k++)
-      if ((int)(box.prd[k] / cellcut) != d.ncell[k]) realloc = true;
+    for (int k = 0; k < 3; k++) {
+      double extent = (k == 2 && d.dd) ? (d.slab_hi - d.slab_lo) + 2.0 * d.cutghost : box.prd[k];
+      if ((int)(extent / cellcut) != d.ncell[k]) realloc = true;
+    }
   if (realloc) {
     if (d.pos) dev_free(d);
     dev_alloc(d, natoms, natoms, ntypes, bpa, maxspecial, box, cellcut);
+    if (d.dd) dd_alloc(d, world);
     for (auto &f : fixes)
       if (auto *l = dynamic_cast<FixLangevin *>(f.get())) l->dev_ready = false;
   }
@@ -141,15 +174,28 @@ void Engine::upload() {
   std::vector<double4> pos(np);
   std::vector<double> vv(3 * (size_t)np, 0.0), ff(3 * (size_t)np, 0.0);
   std::vector<int> tg(np, 0), im(3 * (size_t)np, 0), mp(nt, -1), ty(nt, 0), cr(nt, 0);
+  int nloc = 0;
   for (int i = 0; i < n; i++) {
-    pos[i] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], (double)type[i]);
-    for (int k = 0; k < 3; k++) {
-      vv[(size_t)k * np + i] = v[3 * i + k];
-      ff[(size_t)k * np + i] = f[3 * i + k];
-      im[(size_t)k * np + i] = image[3 * i + k];
+    ty[i + 1] = type[i]; cr[i + 1] = crank[i];
+    if (d.dd) {   // same owner expression as k_dd_classify
+      double zz = x[3 * i + 2];
+      if (zz < box.lo[2]) zz += box.prd[2];
+      if (zz >= box.hi[2]) zz -= box.prd[2];
+      int owner = (int)((zz - box.lo[2]) / (box.prd[2] / world));
+      owner = std::min(std::max(owner, 0), world - 1);
+      if (owner != rank) continue;
     }
-    tg[i] = i + 1; mp[i + 1] = i; ty[i + 1] = type[i]; cr[i + 1] = crank[i];
+    int q = nloc++;
+    pos[q] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], (double)type[i]);
+    for (int k = 0; k < 3; k++) {
+      vv[(size_t)k * np + q] = v[3 * i + k];
+      ff[(size_t)k * np + q] = f[3 * i + k];
+      im[(size_t)k * np + q] = image[3 * i + k];
+    }
+    tg[q] = i + 1; mp[i + 1] = q;
   }
+  d.n = nloc;
+  d.nghost = 0;
   auto up = [&](void *dst, const void *src, size_t bytes) {
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d.stream));
   };
@@ -203,6 +249,35 @@ void Engine::upload() {
 void Engine::download() {
   if (!dev || !dev_current || host_current) return;
   DeviceState &d = *dev;
+  if (d.dd) {
+    // collective: every rank ends up with the whole system (rows: tag x y z type vx vy vz fx fy fz ix iy iz)
+    std::vector<double> rows;
+    int stride = 0;
+    dd_gather_all(d, *comm, rows, stride);
+    for (size_t r = 0; r < rows.size() / 14; r++) {
+      const double *b = &rows[r * 14];
+      int t = (int)b[0];
+      if (t <= 0) continue;
+      int i = t - 1;
+      for (int k = 0; k < 3; k++) { x[3 * i + k] = b[1 + k]; v[3 * i + k] = b[5 + k]; f[3 * i + k] = b[8 + k]; image[3 * i + k] = (int)b[11 + k]; }
+    }
+    size_t nt = (size_t)natoms + 2;
+    std::vector<int> ty(nt), nb(nt), bt(nt * bpa), ba(nt * bpa), ns(nt * 3), sp(nt * (size_t)maxspecial);
+    HIP_CHECK(hipMemcpy(ty.data(), d.type_t, nt * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(nb.data(), d.num_bond, nt * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(bt.data(), d.bond_type, nt * bpa * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(ba.data(), d.bond_atom, nt * bpa * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(ns.data(), d.nspecial, nt * 3 * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(sp.data(), d.special, nt * (size_t)maxspecial * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < natoms; i++) type[i] = ty[i + 1];
+    std::copy(nb.begin() + 1, nb.begin() + 1 + natoms, num_bond.begin());
+    std::copy(bt.begin() + bpa, bt.begin() + bpa + (size_t)natoms * bpa, bond_type.begin());
+    std::copy(ba.begin() + bpa, ba.begin() + bpa + (size_t)natoms * bpa, bond_atom.begin());
+    std::copy(ns.begin() + 3, ns.begin() + 3 + (size_t)natoms * 3, nspecial.begin());
+    std::copy(sp.begin() + maxspecial, sp.begin() + maxspecial + (size_t)natoms * maxspecial, special.begin());
+    host_current = true;
+    return;
+  }
   int n = natoms, np = d.npad;
   size_t nt = (size_t)n + 2;
   std::vector<double4> pos(np);
@@ -269,7 +344,9 @@ void Engine::reneighbor() {
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MOVED, 0, sizeof(int), d.stream));
   for (int attempt = 0; attempt < 6; attempt++) {
     HIP_CHECK(hipMemsetAsync(d.flags + FLAG_NEIGH_OVERFLOW, 0, sizeof(int), d.stream));
-    launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
+    if (attempt > 0) launch_lists(d, cutneighmax * cutneighmax, special_lj, pair_lj);   // sorted already: lists only
+    else if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);
+    else launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
     sync_flags(d);
     check_device_error(this, d);
     if (!d.flags_h[FLAG_NEIGH_OVERFLOW]) break;
@@ -288,6 +365,7 @@ bool Engine::decide() {
   ago++;
   if (ago >= neigh_delay && ago % neigh_every == 0) {
     if (!neigh_check) return true;
+    if (world > 1) comm->allreduce_int_max(dev->stream, dev->flags, 2);   // FLAG_MOVED, FLAG_ERROR (neighbor.cpp:2011)
     sync_flags(*dev);
     check_device_error(this, *dev);
     bool moved = dev->flags_h[FLAG_MOVED] != 0;
@@ -393,10 +471,12 @@ void Engine::compute_forces(bool eflag) {
 
 double Engine::stat_neigh_pairs() {
   if (!dev || !dev->numneigh) return 0.0;
-  std::vector<int> nn(dev->n);
+  std::vector<int> nn(dev->n + 1);
   HIP_CHECK(hipMemcpy(nn.data(), dev->numneigh, (size_t)dev->n * sizeof(int), hipMemcpyDeviceToHost));
+  nn[dev->n] = 0;
   double s = 0.0;
   for (int v : nn) s += v;
+  if (world > 1) s = comm->allreduce_host_sum(s);
   return s;
 }
 
@@ -427,6 +507,7 @@ ThermoRow Engine::eval_thermo() {
   launch_ke(d, tt);
   double s[16];
   reduce_partials(d, s);
+  if (world > 1) comm->allreduce_host_sum(s, 16);
   ThermoRow r{};
   r.step = ntimestep;
   double dof = 3.0 * natoms - 3.0;                       // src/compute_temp.cpp:60-68
@@ -536,7 +617,7 @@ void Engine::iterate(long nsteps) {
     if (decide()) {
       reneighbor();
       if (sortfreq > 0 && ntimestep >= nextsort) emulate_atom_sort();
-    }
+    } else halo_exchange();     // ghosts follow their owners (CommBrick::forward_comm)
     if (fusable && !eflag) {
       bool next = (it + 1 < nsteps);
       bool check_next = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);

@@ -69,6 +69,7 @@ struct BondTable {  // by-value kernel argument
 };
 
 struct DeviceState;  // defined in device.h (HIP side)
+struct Comm;         // defined in comm.h
 
 // ---------------------------------------------------------------------------------------------
 // fixes (style registry mirrors src/modify.cpp:93-99 / style names of the reference)
@@ -236,6 +237,12 @@ class Engine {
   void write_data(const std::string &path);
   void build_special();               // src/special.cpp:55-
   void create_box_atoms_check();
+
+  // ---- ranks (one process per GPU; world > 1 = z-slab spatial decomposition) ----
+  Comm *comm = nullptr;
+  int world = 1, rank = 0;
+  void comm_init(const std::string &backend, int rank, int world, const void *unique_id, const std::string &session);
+  void halo_exchange();
 
   // ---- device ----
   DeviceState *dev = nullptr;

@@ -3,9 +3,12 @@
 // Argument grammars and error strings follow the reference constructors.
 #include <cstring>
 
+#include "comm.h"
 #include "device.h"
 
 namespace lmp_le {
+
+void dd_gather_positions(DeviceState &d, Comm &comm);
 
 static void need_all(const std::vector<std::string> &arg) {
   if (arg[1] != "all") throw LammpsError("MI355X engine: fix group must be 'all' (got " + arg[1] + ")");
@@ -188,6 +191,7 @@ void FixExtrusion::post_integrate() {
   int slot = le_slot(eng, this);
   if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
+  if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob};
   launch_extrusion(d, p, slot);
   sync_flags(d);
@@ -204,6 +208,7 @@ void FixExLoad::post_integrate() {
   int slot = le_slot(eng, this);
   if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
+  if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction};
   launch_ex_load(d, p, slot);
   sync_flags(d);
@@ -220,6 +225,7 @@ void FixExUnload::post_integrate() {
   int slot = le_slot(eng, this);
   if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
+  if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExUnloadParams p{btype, cutsq, fraction};
   launch_ex_unload(d, p, slot);
   sync_flags(d);

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_lscan_add(int m, int *__restrict
   int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (i < m) out[i] += blocksum[blockIdx.x];
 }
-static void scan_ex(DeviceState &d, const int *in, int *out, int m, int total_flag) {
+void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);
+static void scan_ex(DeviceState &d, const int *in, int *out, int m, int total_flag) { scan_exclusive(d, in, out, m, total_flag); }
+void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag) {
   int sb = (m + SCAN_BLOCK - 1) / SCAN_BLOCK;
   int *tmp = d.le_scan;
   hipLaunchKernelGGL(k_lscan_local, dim3(sb), dim3(SCAN_BLOCK), 0, d.stream, m, in, out, tmp);
@@ -197,13 +199,15 @@ __global__ __launch_bounds__(64) void k_topo_created(Topo tp, const int *__restr
 // ------------------------------------------------------------------------------------------
 // stored coordinates by tag + bondcount of `btype`
 __global__ __launch_bounds__(BLOCK) void k_le_gather(Topo tp, const double4 *__restrict__ pos,
-                                                     const int *__restrict__ map, double4 *__restrict__ xt, int btype,
-                                                     int *__restrict__ bondcount, int check_multi,
+                                                     const double4 *__restrict__ xhold, const int *__restrict__ map,
+                                                     int local, double4 *__restrict__ xt, double4 *__restrict__ xht,
+                                                     int btype, int *__restrict__ bondcount, int check_multi,
                                                      int *__restrict__ flags) {
   int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > tp.T + 1) return;
   if (t == 0 || t == tp.T + 1) { bondcount[t] = 0; return; }
-  xt[t] = pos[map[t]];
+  // one rank: every bead is local.  Decomposed: xt / xht were filled by the all-gather (dd_gather_positions)
+  if (local) { int p = map[t]; xt[t] = pos[p]; xht[t] = xhold[p]; }
   int bc = 0, nb = tp.num_bond[t];
   for (int m = 0; m < nb; m++) if (tp.bond_type[(size_t)t * tp.bpa + m] == btype) bc++;
   bondcount[t] = bc;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_create(Topo tp, ExLoadParams P
           int ty = tp.type_t[t], nty = ty;
           if (ty == P.iatomtype) { if (c == P.imaxbond) nty = P.inewtype; }
           else { if (c == P.jmaxbond) nty = P.jnewtype; }
-          if (nty != ty) { tp.type_t[t] = nty; pos[map[t]].w = (double)nty; }
+          if (nty != ty) { tp.type_t[t] = nty; int pp = map[t]; if (pp >= 0) pos[pp].w = (double)nty; }
           f = j;
           if (t < j) atomicAdd(&flags[FLAG_COUNT_A], 1);
         }
@@ -324,7 +328,7 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot) {
   hipStream_t st = d.stream;
   int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
-  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.map, d.xt, P.btype, bc, 0, d.flags);
+  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 0, d.flags);
   int nbw = ((nt + 63) / 64 * 64 + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(k_exload_base, dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, d.le_bits, d.le_d[0]);
   hipLaunchKernelGGL(k_exload_partner, dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], partner, has);
@@ -340,8 +344,7 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot) {
 // ========================================= ex_unload ==========================================
 __global__ __launch_bounds__(BLOCK) void k_exunload_partner(Topo tp, ExUnloadParams P, Box box,
                                                             const double4 *__restrict__ xt,
-                                                            const double4 *__restrict__ xhold,
-                                                            const int *__restrict__ map, int *__restrict__ partner,
+                                                            const double4 *__restrict__ xht, int *__restrict__ partner,
                                                             int *__restrict__ haspartner) {
   int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > tp.T + 1) return;
@@ -349,11 +352,11 @@ __global__ __launch_bounds__(BLOCK) void k_exunload_partner(Topo tp, ExUnloadPar
   if (t >= 1 && t <= tp.T) {
     double best = 0.0;
     int nb = tp.num_bond[t];
-    double4 xi = xt[t], hi = xhold[map[t]];
+    double4 xi = xt[t], hi = xht[t];
     for (int m = 0; m < nb; m++) {
       if (tp.bond_type[(size_t)t * tp.bpa + m] != P.btype) continue;
       int u = tp.bond_atom[(size_t)t * tp.bpa + m];
-      double4 xj = xt[u], hj = xhold[map[u]];
+      double4 xj = xt[u], hj = xht[u];
       // partner image frozen at the last reneighbor (closest image then; ntopo_bond_all.cpp:53,64)
       double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
       double s0 = (h0 > box.half[0]) ? 1.0 : (h0 < -box.half[0]) ? -1.0 : 0.0;
@@ -401,9 +404,8 @@ void launch_ex_unload(DeviceState &d, const ExUnloadParams &P, int slot) {
   hipStream_t st = d.stream;
   int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));
-  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.map, d.xt, P.btype, bc, 0, d.flags);
-  hipLaunchKernelGGL(k_exunload_partner, dim3(nb), dim3(BLOCK), 0, st, tp, P, d.box, d.xt, d.xhold, d.map, partner,
-                     has);
+  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 0, d.flags);
+  hipLaunchKernelGGL(k_exunload_partner, dim3(nb), dim3(BLOCK), 0, st, tp, P, d.box, d.xt, d.xht, partner, has);
   if (P.fraction < 1.0) {
     scan_ex(d, has, didx, nt, FLAG_NDRAW);
     launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
@@ -418,9 +420,8 @@ enum { CASE_NONE = 0, CASE_BOTH = 1, CASE_LEFT = 2, CASE_RIGHT = 3 };
 
 // which beads head a bond-list entry of type btype (ntopo_bond_all.cpp:52-73 with newton_bond off):
 // from t if t < partner (local index = ID-1), or from both ends if the bond straddled a face at the last build
-__global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box box, const double4 *__restrict__ xhold,
-                                                        const int *__restrict__ map, int *__restrict__ lflag,
-                                                        int *__restrict__ lpart) {
+__global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box box, const double4 *__restrict__ xht,
+                                                        int *__restrict__ lflag, int *__restrict__ lpart) {
   int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > tp.T + 1) return;
   int fl = 0, u = 0;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box 
     for (int m = 0; m < nb; m++)
       if (tp.bond_type[(size_t)t * tp.bpa + m] == btype) { u = tp.bond_atom[(size_t)t * tp.bpa + m]; break; }
     if (u) {
-      double4 hi = xhold[map[t]], hj = xhold[map[u]];
+      double4 hi = xht[t], hj = xht[u];
       double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
       bool straddle = fabs(h0) > box.half[0] || fabs(h1) > box.half[1] || fabs(h2) > box.half[2];
       fl = (straddle || t < u) ? 1 : 0;
@@ -621,8 +622,8 @@ void launch_extrusion(DeviceState &d, const ExtrusionParams &P, int slot) {
   double *kq = d.le_d[0];
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));
   for (int *a : {ndraw, ev_cnt, to_add, tr0, fin_rm, fin_add}) HIP_CHECK(hipMemsetAsync(a, 0, (size_t)nt * sizeof(int), st));
-  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.map, d.xt, P.btype, bc, 1, d.flags);
-  hipLaunchKernelGGL(k_ext_listflag, dim3(nb), dim3(BLOCK), 0, st, tp, P.btype, d.box, d.xhold, d.map, lflag, lpart);
+  hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 1, d.flags);
+  hipLaunchKernelGGL(k_ext_listflag, dim3(nb), dim3(BLOCK), 0, st, tp, P.btype, d.box, d.xht, lflag, lpart);
   scan_ex(d, lflag, lidx, nt, FLAG_NLIST);
   hipLaunchKernelGGL(k_ext_prepare, dim3(nb), dim3(BLOCK), 0, st, tp, P, lflag, lidx, lpart, bc, list_l, list_r, list_f,
                      ndraw);

@@ -20,9 +20,21 @@ namespace lmp_le {
 constexpr int BLOCK = 256;
 constexpr int SCAN_BLOCK = 1024;
 
+// cell of a (wrapped) position.  z cells are counted from zlo_ext (the bottom of this rank's slab + ghost shell;
+// = box.lo[2] on one rank) with a periodic wrap, so owned and ghost beads of a slab land in one local grid.
+__device__ __forceinline__ int cell_index(const double4 &r, const Box &box, int ncx, int ncy, int ncz, double cix,
+                                          double ciy, double ciz, double zlo_ext) {
+  double zrel = r.z - zlo_ext;
+  if (zrel < 0.0) zrel += box.prd[2];
+  if (zrel >= box.prd[2]) zrel -= box.prd[2];
+  int cx = (int)((r.x - box.lo[0]) * cix), cy = (int)((r.y - box.lo[1]) * ciy), cz = (int)(zrel * ciz);
+  cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
+  return (cz * ncy + cy) * ncx + cx;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__ pos, int *__restrict__ img, int npad,
                                                     Box box, int ncx, int ncy, int ncz, double cix, double ciy,
-                                                    double ciz, int *__restrict__ cell_of,
+                                                    double ciz, double zlo_ext, int *__restrict__ cell_of,
                                                     int *__restrict__ cell_count, int *__restrict__ rank,
                                                     int *__restrict__ flags) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
@@ -45,9 +57,7 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
     img[d * npad + p] = im;
   }
   pos[p] = r;
-  int cx = (int)((r.x - box.lo[0]) * cix), cy = (int)((r.y - box.lo[1]) * ciy), cz = (int)((r.z - box.lo[2]) * ciz);
-  cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
-  int cell = (cz * ncy + cy) * ncx + cx;
+  int cell = cell_index(r, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
   cell_of[p] = cell;
   rank[p] = atomicAdd(&cell_count[cell], 1);   // arrival order inside the cell; k_sort_cells makes it canonical
 }
@@ -212,17 +222,19 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
 template <bool NOSPECIAL>
 __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
-                                                       const int *__restrict__ cell_start, int ncx, int ncy, int ncz,
-                                                       double cix, double ciy, double ciz, Box box, double cutneighsq,
-                                                       double margin, const int *__restrict__ nspecial,
+                                                       const int *__restrict__ cell_start,
+                                                       const int *__restrict__ gcell_start, int dd, double zlo_ext,
+                                                       int ncx, int ncy, int ncz, double cix, double ciy, double ciz,
+                                                       Box box, double cutneighsq, double margin,
+                                                       const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
   double4 ri = pos[active ? s : 0];
-  int cx = (int)((ri.x - box.lo[0]) * cix), cy = (int)((ri.y - box.lo[1]) * ciy), cz = (int)((ri.z - box.lo[2]) * ciz);
-  cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
+  int cself = cell_index(ri, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
+  int cx = cself % ncx, cy = (cself / ncx) % ncy, cz = cself / (ncx * ncy);
   int n1 = 0, n2 = 0, n3 = 0;
   const int *slist = nullptr;
   int spi[SPMAX];
@@ -240,12 +252,14 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
   // positions were wrapped into the box just before this kernel: interior = farther than cutneigh from all faces
   bool interior = ri.x > box.lo[0] + margin && ri.x < box.hi[0] - margin && ri.y > box.lo[1] + margin &&
                   ri.y < box.hi[1] - margin && ri.z > box.lo[2] + margin && ri.z < box.hi[2] - margin;
-  bool all_in = __all(interior || !active);
+  bool all_in = __all(interior || !active) && !dd;
   if (!active) return;
   int cnt = 0;
   int x0 = cx - 1, x1 = cx + 1;   // x-cell range, may stick out of [0, ncx)
   for (int dz = -1; dz <= 1; dz++) {
-    int az = cz + dz; if (az < 0) az += ncz; else if (az >= ncz) az -= ncz;
+    int az = cz + dz;
+    if (dd) { if (az < 0 || az >= ncz) continue; }            // slab grid: ghosts pad the z direction
+    else { if (az < 0) az += ncz; else if (az >= ncz) az -= ncz; }
     for (int dy = -1; dy <= 1; dy++) {
       int ay = cy + dy; if (ay < 0) ay += ncy; else if (ay >= ncy) ay -= ncy;
       int row = (az * ncy + ay) * ncx;
@@ -261,6 +275,11 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
       if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + 1]);                      // cell 0 (image of ncx)
       RANGE(cell_start[row + lo], cell_start[row + hi + 1]);
       if (x0 < 0) RANGE(cell_start[row + ncx - 1], cell_start[row + ncx]);             // cell ncx-1 (image of -1)
+      if (dd) {   // ghost beads of the same cells, stored (cell-sorted) behind the owned beads
+        if (x1 >= ncx) RANGE(n + gcell_start[row], n + gcell_start[row + 1]);
+        RANGE(n + gcell_start[row + lo], n + gcell_start[row + hi + 1]);
+        if (x0 < 0) RANGE(n + gcell_start[row + ncx - 1], n + gcell_start[row + ncx]);
+      }
 #undef RANGE
     }
   }
@@ -269,13 +288,15 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
   atomicMax(&flags[FLAG_MAXNEIGH], cnt);
 }
 
-void launch_reneighbor(DeviceState &d, double cutneighsq, const double sl[4], bool has_pair) {
+// phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays
+void launch_sort_owned(DeviceState &d) {
   int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
+  if (nb == 0) nb = 1;
   hipStream_t st = d.stream;
   HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(d.ncells + 1) * sizeof(int), st));
   hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.img, d.npad, d.box, d.ncell[0],
-                     d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.cell_of, d.cell_count,
-                     d.tag_tmp, d.flags);
+                     d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of,
+                     d.cell_count, d.tag_tmp, d.flags);
   int sb = (d.ncells + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, d.ncells, d.cell_count, d.cell_start,
                      d.scan_tmp);
@@ -290,6 +311,13 @@ void launch_reneighbor(DeviceState &d, double cutneighsq, const double sl[4], bo
   for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
   std::swap(d.tag, d.tag_tmp);
   std::swap(d.img, d.img_tmp);
+}
+
+// phase 2: bond-partner table + full neighbor list of the owned beads (ghosts, if any, already in place)
+void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool has_pair) {
+  int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
+  if (nb == 0) nb = 1;
+  hipStream_t st = d.stream;
   hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.bpa, d.tag, d.map, d.num_bond,
                      d.bond_type, d.bond_atom, d.maxtag, d.bpart, d.flags);
   if (has_pair) {
@@ -297,17 +325,19 @@ void launch_reneighbor(DeviceState &d, double cutneighsq, const double sl[4], bo
     int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
     HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), st));
     double margin = sqrt(cutneighsq) * (1.0 + 1e-12);
-    if (sf1 == 1 && sf2 == 1 && sf3 == 1)
-      hipLaunchKernelGGL((k_build_neigh<true>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag,
-                         d.map, d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1],
-                         d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3,
-                         d.neigh, d.numneigh, d.flags);
-    else
-      hipLaunchKernelGGL((k_build_neigh<false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag,
-                         d.map, d.cell_start, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1],
-                         d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1, sf2, sf3,
-                         d.neigh, d.numneigh, d.flags);
+#define BUILD(NOSP)                                                                                                \
+  hipLaunchKernelGGL((k_build_neigh<NOSP>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag, d.map, \
+                     d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
+                     d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
+                     sf2, sf3, d.neigh, d.numneigh, d.flags)
+    if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true); else BUILD(false);
+#undef BUILD
   }
+}
+
+void launch_reneighbor(DeviceState &d, double cutneighsq, const double sl[4], bool has_pair) {
+  launch_sort_owned(d);
+  launch_lists(d, cutneighsq, sl, has_pair);
 }
 
 }  // namespace lmp_le

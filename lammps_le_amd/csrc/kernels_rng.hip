@@ -96,7 +96,7 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
 // call always starts 3N draws later), so it overlaps the force kernel of the previous step; the two draw
 // buffers alternate and events order producer / consumer.
 static void rng_generate(DeviceState &d, int buf, uint64_t first_raw) {
-  long long total = 3ll * d.n;
+  long long total = 3ll * d.ntotal;
   // the buffer may still be read by the consumer of two calls ago
   HIP_CHECK(hipStreamWaitEvent(d.rng_stream, d.rng_consumed[buf], 0));
   hipLaunchKernelGGL(k_rng_langevin, dim3(d.rng_nblocks), dim3(64), 0, d.rng_stream, d.rng_B, total,
@@ -109,7 +109,7 @@ void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
   d.rng_out = d.rng_buf[d.rng_cur];
   HIP_CHECK(hipStreamWaitEvent(d.stream, d.rng_done[d.rng_cur], 0));
   // run ahead: the following call's draws
-  rng_generate(d, d.rng_cur ^ 1, first_raw + 3ull * (uint64_t)d.n);
+  rng_generate(d, d.rng_cur ^ 1, first_raw + 3ull * (uint64_t)d.ntotal);
   d.rng_ahead = true;
 }
 // to be called right after the consumer kernel of the current draws has been enqueued on d.stream

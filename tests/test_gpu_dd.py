@@ -1,0 +1,76 @@
+"""Spatial decomposition (z slabs, one process per rank) against the CPU oracle.  The ranks share the single
+GPU of the test box and talk through the /dev/shm test transport (RCCL refuses duplicate devices); the device
+kernels, migration, ghost lists, halo updates and replicated LE fixes are exactly those of a multi-GPU run."""
+import os
+import pickle
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+from systems import CHAIN_SCRIPT, lattice_chain, run_oracle
+from test_gpu_le import LE, barrier_types, melted, special_sets
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_ranks(world, system, script, tmp_path):
+    session = uuid.uuid4().hex[:12]
+    sysfile, scriptfile, out = (os.path.join(str(tmp_path), n) for n in ("system.pkl", "script.txt", "out.npz"))
+    pickle.dump(system, open(sysfile, "wb"))
+    open(scriptfile, "w").write(script)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dd_worker.py"), str(r), str(world), session, sysfile,
+                               scriptfile, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return np.load(out)
+
+
+def bond_set(nb, bt, ba):
+    out = set()
+    for i in np.nonzero(nb)[0]:
+        for m in range(nb[i]):
+            a, b = int(i) + 1, int(ba[i, m])
+            out.add((int(bt[i, m]), min(a, b), max(a, b)))
+    return out
+
+
+@pytest.mark.parametrize("world,n", [(2, 6000), (3, 20000)])
+def test_md_across_slabs(tmp_path, world, n):
+    """NVE + Langevin for 60 steps incl. reneighbors with migration across slab faces."""
+    s = lattice_chain(n, nchains=2, seed=21)
+    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 30\nrun 60\n"
+    o = run_oracle(script, s)
+    r = run_ranks(world, s, script, tmp_path)
+    assert np.abs(r["x"] - o.x()).max() < 1e-9
+    assert np.abs(r["v"] - o.v()).max() < 1e-8
+    assert (r["image"] == o.image()).all()
+    to = o.thermo()
+    assert np.abs(r["thermo"][:5] - to[:5]).max() < 1e-9
+    assert r["neigh_pairs"][0] == 2 * o.neigh_pairs()
+    assert r["builds"][0] == o.neigh_builds()
+
+
+def test_le_fixes_across_slabs(tmp_path):
+    """Replicated extruder table: every rank runs the same deterministic LE kernels on all-gathered positions;
+    topology must be bit-exact against the 1-rank oracle."""
+    n = 8000
+    s = melted(n, nchains=2, seed=8, types=barrier_types(n, 13))
+    base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 4.0") \
+        .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 10.0 3.8 1.0 1.0")
+    script = base + LE.format(n1=6, nl=12, nu=12, neutral=1, left=2, right=3, tp=0.5, lr="4",
+                              lprob="prob 0.5 684474", uprob="prob 0.3 456456", rmax=0.5) + "run 50\n"
+    o = run_oracle(script, s)
+    r = run_ranks(2, s, script, tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+    ns_o, sp_o = o.special_table()
+    assert special_sets(r["nspecial"], r["special"]) == special_sets(ns_o, sp_o)
+    for fid in ("loop", "loading", "unloading"):
+        assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1]
+    assert r["thermo"][5] == o.nbonds()
+    assert np.abs(r["x"] - o.x()).max() < 1e-7
+    assert len([b for b in o.bond_set() if b[0] == 2]) > 20
