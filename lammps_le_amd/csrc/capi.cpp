@@ -254,6 +254,8 @@ double lammps_le_stat(void *handle, const char *name) {
   if (k == "pair_kernel_launches") return (double)e->kstat_n;
   if (k == "neigh_pairs") return e->stat_neigh_pairs();
   if (k == "maxneigh") return e->dev ? (double)e->dev->maxneigh : 0.0;
+  if (k == "nlocal") return e->dev ? (double)e->dev->n : 0.0;
+  if (k == "nghost") return e->dev ? (double)e->dev->nghost : 0.0;
   if (k == "fene_warnings") return e->dev && e->dev->flags_h ? (double)e->dev->flags_h[FLAG_FENE_WARN] : 0.0;
   return -1.0;
 }

@@ -130,10 +130,10 @@ void Comm::allgather_host(const void *send, void *recv, size_t bytes) {
   }
   // RCCL: through a small device bounce buffer
   ensure_bounce(bytes * world + bytes);
-  HIP_CHECK(hipMemcpy(bounce, send, bytes, hipMemcpyHostToDevice));
-  NCCL_CHECK(rccl.AllGather(bounce, (char *)bounce + bytes, bytes, ncclInt8, g_comm, nullptr));
-  HIP_CHECK(hipStreamSynchronize(nullptr));
-  HIP_CHECK(hipMemcpy(recv, (char *)bounce + bytes, bytes * world, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpyAsync(bounce, send, bytes, hipMemcpyHostToDevice, main_stream));
+  NCCL_CHECK(rccl.AllGather(bounce, (char *)bounce + bytes, bytes, ncclInt8, g_comm, main_stream));
+  HIP_CHECK(hipMemcpyAsync(recv, (char *)bounce + bytes, bytes * world, hipMemcpyDeviceToHost, main_stream));
+  HIP_CHECK(hipStreamSynchronize(main_stream));
 }
 void Comm::ensure_bounce(size_t bytes) {
   if (bytes <= bounce_bytes) return;
@@ -223,11 +223,12 @@ void Comm::exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &
   ensure_bounce(tot + 64);
   char *p = (char *)bounce;
   std::vector<Msg> ds, dr;
-  for (auto &m : sends) { HIP_CHECK(hipMemcpy(p, m.dev, m.bytes, hipMemcpyHostToDevice)); ds.push_back({p, m.bytes, m.peer}); p += m.bytes; }
+  for (auto &m : sends) { HIP_CHECK(hipMemcpyAsync(p, m.dev, m.bytes, hipMemcpyHostToDevice, main_stream)); ds.push_back({p, m.bytes, m.peer}); p += m.bytes; }
   for (auto &m : recvs) { dr.push_back({p, m.bytes, m.peer}); p += m.bytes; }
-  exchange(nullptr, ds, dr);
-  HIP_CHECK(hipStreamSynchronize(nullptr));
-  for (size_t k = 0; k < recvs.size(); k++) HIP_CHECK(hipMemcpy(recvs[k].dev, dr[k].dev, recvs[k].bytes, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipStreamSynchronize(main_stream));    // the host send buffers are stack variables of the caller
+  exchange(main_stream, ds, dr);
+  for (size_t k = 0; k < recvs.size(); k++) HIP_CHECK(hipMemcpyAsync(recvs[k].dev, dr[k].dev, recvs[k].bytes, hipMemcpyDeviceToHost, main_stream));
+  HIP_CHECK(hipStreamSynchronize(main_stream));
 }
 void Comm::barrier() {
   int x = 1;

@@ -12,6 +12,7 @@ struct Msg { void *dev; size_t bytes; int peer; };
 struct Comm {
   enum Backend { NONE, RCCL, SHM } backend = NONE;
   int rank = 0, world = 1;
+  hipStream_t main_stream = nullptr;   // every RCCL call is issued on the engine's stream: one total order per rank
   void init(const std::string &backend_name, int rank, int world, const void *unique_id, const std::string &session);
   void finalize();
   // device buffers

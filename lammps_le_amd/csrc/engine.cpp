@@ -169,6 +169,7 @@ void Engine::upload() {
       if (auto *l = dynamic_cast<FixLangevin *>(f.get())) l->dev_ready = false;
   }
   d.box = box;
+  if (comm) comm->main_stream = d.stream;
   int n = natoms, np = d.npad;
   size_t nt = (size_t)n + 2;
   std::vector<double4> pos(np);

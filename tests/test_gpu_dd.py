@@ -58,11 +58,12 @@ def test_md_across_slabs(tmp_path, world, n):
 def test_le_fixes_across_slabs(tmp_path):
     """Replicated extruder table: every rank runs the same deterministic LE kernels on all-gathered positions;
     topology must be bit-exact against the 1-rank oracle."""
-    n = 8000
+    n = 14000
     s = melted(n, nchains=2, seed=8, types=barrier_types(n, 13))
-    base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 4.0") \
-        .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 10.0 3.8 1.0 1.0")
-    script = base + LE.format(n1=6, nl=12, nu=12, neutral=1, left=2, right=3, tp=0.5, lr="4",
+    # ghost shell 6.2 > longest extruder bond of this (slow-stepping) scenario: partners stay reachable
+    base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 6.2") \
+        .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 10.0 6.0 1.0 1.0")
+    script = base + LE.format(n1=20, nl=10, nu=10, neutral=1, left=2, right=3, tp=0.5, lr="4",
                               lprob="prob 0.5 684474", uprob="prob 0.3 456456", rmax=0.5) + "run 50\n"
     o = run_oracle(script, s)
     r = run_ranks(2, s, script, tmp_path)
