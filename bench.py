@@ -6,13 +6,13 @@ velocity-Verlet timestep of the whole system (pair lj/cut + bond fene + fix nve 
 USER-LE fixes on their firing steps, reneighboring included), inputs resident in HBM when timing starts.
 
 Default workload = BASELINE.json configs[3] at N=1 (the configuration the north-star target is quoted on):
-a 1M-bead single chain at melt density, barrier beads every 200, `extrusion 1000` / `ex_load 1000 prob 0.01` /
+a 1M-bead single chain at melt density (strong scaling over N GPUs as z-slabs), barrier beads every 200, `extrusion 1000` / `ex_load 1000 prob 0.01` /
 `ex_unload 1000 prob 0.01` (the dense LE parameter set BASELINE.md measured the reference with), so that two
 firings of every LE fix fall inside the default 2000-step timed window.
 
 Extra objects on the JSON line:
-  roofline     — the fused pair+bond force kernel: algorithmic bytes (52*N + 8*P + 12*B, SURVEY §8d with a full
-                 list: P = half pairs, B = bonds) / mean kernel duration from HIP events recorded on the launch
+  roofline     — the fused step kernel k_step: algorithmic bytes (144*N + 4*F, F = stored full-list entries;
+                 DESIGN.md §3) / mean kernel duration from HIP events recorded on the launch
                  stream inside the engine over the timed region, vs the 8 TB/s HBM3E peak.
   cpu_baseline — the CPU oracle (oracle/le_oracle.c, a serial port of the reference path) on 1 host core, on a
                  bounded sample (first steps of the same system from the same state); reported, not the target.
@@ -65,9 +65,8 @@ def main():
     from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
 
     nbeads, nchains, bar, n1, nload, pload, tp = WORKLOADS[args.workload]
-    # round 1: ranks > 0 run independent replicas of the per-GPU workload (spatial decomposition with RCCL halo
-    # exchange is the next §8e row); per-GPU work is fixed as N grows -> weak scaling
-    sysd = lattice_chains(nbeads, nchains=nchains, seed=1 + rank, barrier_every=bar)
+    # N > 1: the SAME system is decomposed into N z-slabs (strong scaling); every rank builds the identical input
+    sysd = lattice_chains(nbeads, nchains=nchains, seed=1, barrier_every=bar)
     ntypes = sysd["ntypes"]
     tmp = tempfile.mkdtemp(prefix="le_bench_")
     data = os.path.join(tmp, "data.r%d" % rank)
@@ -76,6 +75,9 @@ def main():
     script = CHAIN_INPUT.format(data=data, n1=n1, left=left, right=right, tp=tp, lr=lr, nload=nload, pload=pload)
 
     lmp = lammps(cmdargs=["-screen", "none"])
+    if world > 1:
+        from lammps_le_amd import init_from_torch_distributed
+        init_from_torch_distributed(lmp)     # engine's own RCCL communicator (unique id broadcast by torch)
     for ln in script.split("\n"):
         lmp.command(ln)
 
@@ -99,18 +101,22 @@ def main():
 
     # ---- roofline of the dominant kernel (k_force: pair lj/cut + bonds, one launch per step) ----
     kms = lmp.stat("pair_kernel_ms")
-    full_entries = lmp.stat("neigh_pairs")          # stored full-list entries = 2 * half pairs
+    full_entries = lmp.stat("neigh_pairs")          # stored full-list entries (all ranks) = 2 * half pairs
     nbonds = lmp.get_thermo("bonds")
-    alg_bytes = 52.0 * nbeads + 4.0 * full_entries + 12.0 * nbonds
+    nlocal = lmp.stat("nlocal")
+    # k_step moves, per owned bead: pos 32 r + pos' 32 w + v 24 r + 24 w + tag 4 + draws 12 + bond table 12 +
+    # numneigh 4 = 144 B, plus 4 B per stored neighbor entry; this rank's share when decomposed
+    alg_bytes = 144.0 * nlocal + 4.0 * full_entries * (nlocal / nbeads)
     achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get("k_force_hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(args.workload, {}).get("k_step_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_force (pair lj/cut + bond fene, fused)", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "k_step (pair lj/cut + bond fene + langevin + nve final/initial, fused)",
+                "achieved": round(achieved, 1),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kms, 5),
                 "launches_timed": int(lmp.stat("pair_kernel_launches"))}
@@ -141,15 +147,16 @@ def main():
     if rank == 0:
         out = {
             "metric": "MD timesteps/sec, bead-spring LJ+FENE chain with loop extrusion",
-            "value": round(world * args.steps / elapsed, 2) if world > 1 else round(args.steps / elapsed, 2),
+            "value": round(args.steps / elapsed, 2),
             "unit": "timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d beads, %d chain(s), lj/cut 1.12 + fene + nve + langevin + extrusion %d / "
                                    "ex_load %d prob %g / ex_unload %d prob %g" % (args.workload, nbeads, nchains, n1, nload,
                                                                                  pload, nload, pload),
-                       "beads_per_gpu": nbeads,
-                       "parallelism": "1 GPU" if world == 1 else "%d independent replicas (one system per GPU)" % world},
+                       "beads_total": nbeads,
+                       "parallelism": "1 GPU" if world == 1 else
+                       "%d z-slabs, one rank per GPU, halo + migration over RCCL, replicated extruder table" % world},
             "roofline": roofline, "cpu_baseline": cpu,
             "engine_loop_time_s": round(lmp.stat("loop_time"), 5), "neigh_builds": int(lmp.stat("neigh_builds")),
             "extruders": int(nbonds - (nbeads - nchains)), "fene_warnings": int(lmp.stat("fene_warnings")),
