@@ -88,7 +88,8 @@ def main():
         torch.cuda.synchronize()
 
     lmp.command("run %d" % args.warmup)            # untimed: upload, melt from the lattice, first LE firings
-    x_state, v_state = lmp.gather("x"), lmp.gather("v")
+    if world == 1:
+        x_state, v_state = lmp.gather("x"), lmp.gather("v")   # the CPU baseline starts from the same state
     barrier()
     t0 = time.perf_counter()
     lmp.command("run %d" % args.steps)             # `run` = Verlet::setup + K steps, synchronised at the end

@@ -15,7 +15,19 @@ rank, world, session, sysfile, scriptfile, out = int(sys.argv[1]), int(sys.argv[
 system = pickle.load(open(sysfile, "rb"))
 script = open(scriptfile).read()
 lmp = lammps(cmdargs=["-screen", "none"])
-lmp.comm_init("shm", rank, world, session=session)
+if os.environ.get("LE_BACKEND") == "rccl":
+    # experiment only: RCCL normally refuses two ranks on one device
+    import time
+    from lammps_le_amd import comm_unique_id
+    idfile = "/dev/shm/le_id_" + session
+    if rank == 0:
+        open(idfile + ".tmp", "wb").write(comm_unique_id())
+        os.rename(idfile + ".tmp", idfile)
+    while not os.path.exists(idfile):
+        time.sleep(0.01)
+    lmp.comm_init("rccl", rank, world, open(idfile, "rb").read())
+else:
+    lmp.comm_init("shm", rank, world, session=session)
 tmp = os.path.dirname(out)
 for ln in script.split("\n"):
     w = ln.split("#")[0].split()
