@@ -36,7 +36,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   d.ntotal = maxtag;
   if (!d.dd) d.zlo_ext = box.lo[2];
   size_t np = d.npad, nt = (size_t)maxtag + 2;
-  dalloc(d.pos, np); dalloc(d.pos_tmp, np); dalloc(d.xhold, np);
+  dalloc(d.pos, np); dalloc(d.pos_tmp, np); dalloc(d.xhold, np); dalloc(d.posf, np);
   for (int k = 0; k < 3; k++) { dalloc(d.v[k], np); dalloc(d.v_tmp[k], np); dalloc(d.f[k], np); }
   dalloc(d.tag, np); dalloc(d.tag_tmp, np);
   dalloc(d.img, 3 * np); dalloc(d.img_tmp, 3 * np);
@@ -82,7 +82,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
 }
 
 void dev_free(DeviceState &d) {
-  dfree(d.pos); dfree(d.pos_tmp); dfree(d.xhold);
+  dfree(d.pos); dfree(d.pos_tmp); dfree(d.xhold); dfree(d.posf);
   for (int k = 0; k < 3; k++) { dfree(d.v[k]); dfree(d.v_tmp[k]); dfree(d.f[k]); }
   dfree(d.tag); dfree(d.tag_tmp); dfree(d.img); dfree(d.img_tmp);
   dfree(d.map); dfree(d.type_t); dfree(d.crank);

@@ -52,6 +52,7 @@ struct DeviceState {
   // ---- physical order ----
   double4 *pos = nullptr, *pos_tmp = nullptr;   // x y z type
   double4 *xhold = nullptr;                      // positions at the last build (same order)
+  float4 *posf = nullptr;                        // FP32 copy of xhold for the list build's prefilter
   double *v[3] = {nullptr, nullptr, nullptr}, *v_tmp[3] = {nullptr, nullptr, nullptr};
   double *f[3] = {nullptr, nullptr, nullptr};
   int *tag = nullptr, *tag_tmp = nullptr;

@@ -165,11 +165,13 @@ __global__ __launch_bounds__(BLOCK) void k_dd_ghost_sort(int ncells, const int *
 __global__ __launch_bounds__(BLOCK) void k_dd_ghost_place(int m, int base, const int *__restrict__ perm,
                                                           const double4 *__restrict__ in, const int *__restrict__ tag_in,
                                                           double4 *__restrict__ pos, int *__restrict__ tag,
-                                                          int *__restrict__ gdest, int *__restrict__ map) {
+                                                          int *__restrict__ gdest, int *__restrict__ map,
+                                                          float4 *__restrict__ posf) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= m) return;
   int i = perm[s];
-  pos[base + s] = in[i];
+  double4 r = in[i];
+  pos[base + s] = r;
   int t = tag_in[i];
   tag[base + s] = t;
   gdest[i] = s;
@@ -325,7 +327,7 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
     hipLaunchKernelGGL(k_dd_ghost_sort, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells, d.gcell_start,
                        gperm, tagrecv);
     hipLaunchKernelGGL(k_dd_ghost_place, dim3(gb), dim3(BLOCK), 0, st, m, n, gperm, d.recvbuf, tagrecv, d.pos, d.tag,
-                       d.gdest, d.map);
+                       d.gdest, d.map, d.posf);
   }
   // ---- 5. lists ----
   launch_lists(d, cutneighsq, sl, has_pair);

@@ -59,7 +59,22 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
   pos[p] = r;
   int cell = cell_index(r, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
   cell_of[p] = cell;
-  rank[p] = atomicAdd(&cell_count[cell], 1);   // arrival order inside the cell; k_sort_cells makes it canonical
+  // beads arrive nearly cell-sorted: one returning atomic per run of equal cells inside the wavefront
+  const int lane = threadIdx.x & 63;
+  int prev = __shfl_up(cell, 1, 64);
+  bool head = (lane == 0) || (prev != cell);
+  unsigned long long heads = __ballot(head);                  // all lanes of the wave are active here? no: tail
+  unsigned long long act = __ballot(true);
+  unsigned long long below = heads & ((2ull << lane) - 1ull);  // heads at or below my lane
+  int hl = 63 - __clzll((long long)below);                     // lane of my run's head
+  unsigned long long after = heads & ~((2ull << lane) - 1ull) ;
+  after &= act;
+  int endl = after ? (__ffsll((long long)after) - 1) : (64 - __clzll((long long)act));   // first lane past my run
+  // the run is [hl, endl) restricted to active lanes; runs are contiguous because inactive lanes only trail
+  int base = 0;
+  if (head) base = atomicAdd(&cell_count[cell], endl - hl);
+  base = __shfl(base, hl, 64);
+  rank[p] = base + (lane - hl);   // arrival order inside the cell; k_sort_cells makes it canonical
 }
 
 // ---- exclusive scan of cell_count[0..m) into cell_start[0..m], three small kernels ----
@@ -136,7 +151,8 @@ __global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *_
                                                    double *__restrict__ vxn, double *__restrict__ vyn,
                                                    double *__restrict__ vzn, const int *__restrict__ tag,
                                                    int *__restrict__ tagn, const int *__restrict__ img,
-                                                   int *__restrict__ imgn, int *__restrict__ map) {
+                                                   int *__restrict__ imgn, int *__restrict__ map,
+                                                   float4 *__restrict__ posf) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= n) return;
   int p = perm[s];
@@ -179,8 +195,11 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, 
 // order, which depends only on the sorted positions -> deterministic.
 constexpr int SPMAX = 8;   // special entries translated to indices and kept in registers; longer lists use tags
 
+// (An FP32 prefilter on a float4 copy of the positions was measured SLOWER here, 408 vs 337 us at 1M beads: some
+// lane of a wavefront survives the prefilter in almost every iteration, so both paths execute.)
 template <bool NOSPECIAL, bool MINIMG>
-__device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const double4 *__restrict__ pos,
+__device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const float4 *__restrict__ posf,
+                                            float cutf, const double4 *__restrict__ pos,
                                             const int *__restrict__ tag, const Box &box, double cutneighsq, int n1,
                                             int n2, int n3, const int (&spi)[SPMAX], const int *__restrict__ slist,
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
@@ -221,6 +240,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
 
 template <bool NOSPECIAL>
 __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+                                                       const float4 *__restrict__ posf, float cutf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
                                                        const int *__restrict__ cell_start,
                                                        const int *__restrict__ gcell_start, int dd, double zlo_ext,
@@ -267,9 +287,9 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
       int lo = max(x0, 0), hi = min(x1, ncx - 1);
 #define RANGE(B, E)                                                                                              \
   do {                                                                                                            \
-    if (all_in) neigh_range<NOSPECIAL, false>(s, B, E, ri, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist,   \
+    if (all_in) neigh_range<NOSPECIAL, false>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, \
                                               sf1, sf2, sf3, npad, maxneigh, neigh, cnt);                         \
-    else neigh_range<NOSPECIAL, true>(s, B, E, ri, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2,  \
+    else neigh_range<NOSPECIAL, true>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2, \
                                       sf3, npad, maxneigh, neigh, cnt);                                           \
   } while (0)
       if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + 1]);                      // cell 0 (image of ncx)
@@ -306,7 +326,7 @@ void launch_sort_owned(DeviceState &d) {
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
                      d.cell_start, d.perm, d.tag);
   hipLaunchKernelGGL(k_permute, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.perm, d.pos, d.pos_tmp, d.xhold, d.v[0],
-                     d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map);
+                     d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map, d.posf);
   std::swap(d.pos, d.pos_tmp);
   for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
   std::swap(d.tag, d.tag_tmp);
@@ -325,8 +345,11 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
     int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
     HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), st));
     double margin = sqrt(cutneighsq) * (1.0 + 1e-12);
+    // FP32 prefilter radius: float coordinates of a box this size carry ~|x| * 2^-23 error per component
+    double cn = sqrt(cutneighsq), ferr = 8.0 * std::max({d.box.prd[0], d.box.prd[1], d.box.prd[2]}) * 1.2e-7;
+    float cutf = (float)((cn + ferr) * (cn + ferr) * 1.0001);
 #define BUILD(NOSP)                                                                                                \
-  hipLaunchKernelGGL((k_build_neigh<NOSP>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.tag, d.map, \
+  hipLaunchKernelGGL((k_build_neigh<NOSP>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
                      sf2, sf3, d.neigh, d.numneigh, d.flags)

@@ -61,7 +61,10 @@ __global__ __launch_bounds__(64) void k_rng_langevin(int B, long long total, uns
 
 void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
   long long total = 3ll * natoms;
-  d.rng_B = 1536;
+  // block length: the per-block cost is (B/33 dependent generation steps) + (a fixed 97x97 jump); small systems
+  // are latency-bound -> short blocks, large ones amortise the jump over long blocks
+  d.rng_B = natoms < 200000 ? 192 : 3072;
+  if (getenv("LAMMPS_LE_RNG_B")) d.rng_B = std::min(RNG_MAXB, std::max(96, atoi(getenv("LAMMPS_LE_RNG_B"))));
   d.rng_nblocks = (int)((total + d.rng_B - 1) / d.rng_B);
   if (d.rng_state) { (void)hipFree(d.rng_state); d.rng_state = nullptr; }
   if (d.rng_jump) { (void)hipFree(d.rng_jump); d.rng_jump = nullptr; }
@@ -104,6 +107,14 @@ static void rng_generate(DeviceState &d, int buf, uint64_t first_raw) {
   HIP_CHECK(hipEventRecord(d.rng_done[buf], d.rng_stream));
 }
 void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
+  if (d.ntotal < 200000) {
+    // small systems are launch-bound: generate in order on the main stream (no events, no second stream)
+    long long total = 3ll * d.ntotal;
+    d.rng_out = d.rng_buf[0];
+    hipLaunchKernelGGL(k_rng_langevin, dim3(d.rng_nblocks), dim3(64), 0, d.stream, d.rng_B, total,
+                       (unsigned long long)first_raw, d.rng_state, d.rng_jump, d.rng_out);
+    return;
+  }
   if (!d.rng_ahead) rng_generate(d, d.rng_cur, first_raw);
   else d.rng_cur ^= 1;                                   // generated ahead during the previous call
   d.rng_out = d.rng_buf[d.rng_cur];
@@ -113,7 +124,10 @@ void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
   d.rng_ahead = true;
 }
 // to be called right after the consumer kernel of the current draws has been enqueued on d.stream
-void rng_langevin_consumed(DeviceState &d) { HIP_CHECK(hipEventRecord(d.rng_consumed[d.rng_cur], d.stream)); }
+void rng_langevin_consumed(DeviceState &d) {
+  if (d.ntotal < 200000) return;
+  HIP_CHECK(hipEventRecord(d.rng_consumed[d.rng_cur], d.stream));
+}
 
 // ------------------------------------------------------------------------------------------
 // serial-stream generator for the LE fixes: `count` (device-resident) draws from one RanMars state,
