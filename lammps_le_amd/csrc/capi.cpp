@@ -300,3 +300,11 @@ extern "C" int lammps_le_comm_selftest(const char *session, int rank, int world)
     return 0;
   } catch (const std::exception &ex) { fprintf(stderr, "%s\n", ex.what()); return 1; }
 }
+
+// debug hook (tests only): copy one of the tag-indexed LE scratch arrays (int) or the pair-distance array (double)
+extern "C" void lammps_le_debug_le_array(void *handle, int slot, int n, int *out_i, double *out_d) {
+  lmp_le::Engine *e = (lmp_le::Engine *)handle;
+  if (!e->dev) return;
+  if (out_i) (void)hipMemcpy(out_i, e->dev->le_i[slot], (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+  if (out_d) (void)hipMemcpy(out_d, e->dev->le_d[0], (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+}

@@ -34,6 +34,7 @@ enum FlagSlot {
   FLAG_NLIST = 8,       // number of extruder listings
   FLAG_MAXNEIGH = 9,    // largest neighbor count seen at the last build
   FLAG_AUX = 10,
+  FLAG_SPECIAL_ASYM = 11,   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
   NFLAGS = 16
 };
 enum DevErr {
@@ -63,6 +64,10 @@ struct DeviceState {
   int *crank = nullptr;                          // [maxtag+2] canonical (reference local) index
   int *num_bond = nullptr, *bond_type = nullptr, *bond_atom = nullptr;   // [(maxtag+2)], [*bpa]
   int *nspecial = nullptr, *special = nullptr;                            // [*3], [*maxspecial]
+  // bond tables as of the last reneighbor = the reference's neighbor->bondlist, which the LE fixes loop over
+  // even when another LE fix changed the topology earlier in the same step (fix_ex_unload.cpp:223, fix_extrusion.cpp:368)
+  int *num_bond0 = nullptr, *bond_type0 = nullptr, *bond_atom0 = nullptr;
+  int le_snapshot = 0;             // keep the snapshot (set when an LE fix exists)
   // ---- cells / neighbor list ----
   int ncell[3] = {0, 0, 0}, ncells = 0;
   double cellinv[3] = {0, 0, 0};

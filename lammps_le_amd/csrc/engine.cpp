@@ -242,6 +242,31 @@ void Engine::upload() {
     for (int q = 0; q < 6; q++) d.pair_u[q] = tab[(size_t)q * ntp * ntp + ref];
   }
   HIP_CHECK(hipMemsetAsync(d.flags, 0, NFLAGS * sizeof(int), d.stream));
+  {
+    // special lists that disagree between the two ends of a pair (possible after an ex_unload acted on a stale
+    // bond-list entry, kernels_le.hip dev_special_remove12) switch the list build to half-list semantics
+    auto level = [&](int i, int t) {
+      const int *sl = &special[(size_t)i * maxspecial];
+      int n1 = nspecial[3 * (size_t)i], n2 = nspecial[3 * (size_t)i + 1], n3 = nspecial[3 * (size_t)i + 2];
+      for (int k = 0; k < n3; k++)
+        if (sl[k] == t) { int l = k < n1 ? 1 : k < n2 ? 2 : 3; return special_lj[l] == 1.0 ? 0 : l; }
+      return 0;     // a level with weight 1 is the same as not special
+    };
+    int asym = 0;
+    for (int i = 0; i < natoms && !asym && maxspecial > 0; i++) {
+      int n1 = nspecial[3 * (size_t)i], n2 = nspecial[3 * (size_t)i + 1], n3 = nspecial[3 * (size_t)i + 2];
+      for (int k = 0; k < n3; k++) {
+        int j = special[(size_t)i * maxspecial + k] - 1;
+        int l = k < n1 ? 1 : k < n2 ? 2 : 3;
+        if (special_lj[l] == 1.0) continue;
+        if (j < 0 || j >= natoms || level(j, i + 1) != l) { asym = 1; break; }
+      }
+    }
+    if (asym) {
+      HIP_CHECK(hipMemcpyAsync(d.flags + FLAG_SPECIAL_ASYM, &asym, sizeof(int), hipMemcpyHostToDevice, d.stream));
+      d.flags_h[FLAG_SPECIAL_ASYM] = 1;
+    }
+  }
   HIP_CHECK(hipStreamSynchronize(d.stream));
   dev_current = true;
   host_current = true;
@@ -353,6 +378,12 @@ void Engine::reneighbor() {
     if (!d.flags_h[FLAG_NEIGH_OVERFLOW]) break;
     // grow the ELL table and rebuild (atoms are already wrapped and sorted: the rebuild is idempotent)
     dev_alloc_neigh(d, d.flags_h[FLAG_MAXNEIGH] + 16);
+  }
+  if (d.le_snapshot) {   // NTopoBond::build: the bond list the LE fixes will see until the next reneighbor
+    size_t nt = (size_t)d.maxtag + 2;
+    HIP_CHECK(hipMemcpyAsync(d.num_bond0, d.num_bond, nt * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
+    HIP_CHECK(hipMemcpyAsync(d.bond_type0, d.bond_type, nt * d.bpa * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
+    HIP_CHECK(hipMemcpyAsync(d.bond_atom0, d.bond_atom, nt * d.bpa * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
   }
   ago = 0;
   neigh_builds++;
@@ -652,6 +683,8 @@ void Engine::run(long nsteps) {
   init();
   if (!dev_current || !dev || !dev->pos) upload();
   le_reneigh_step.assign(fixes.size(), -1);
+  dev->le_snapshot = 0;
+  for (auto &f : fixes) if (f->force_reneighbor) dev->le_snapshot = 1;
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
   host_current = false;

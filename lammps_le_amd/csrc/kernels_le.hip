@@ -30,9 +30,11 @@ enum { I_BC = 0, I_A, I_B, I_C, I_D, I_E, I_F, I_G, I_H, I_J, I_K, I_L, I_M, I_N
 struct Topo {   // tag-indexed topology views
   int T, bpa, ms;
   int *num_bond, *bond_type, *bond_atom, *nspecial, *special, *type_t;
+  const int *num_bond0, *bond_type0, *bond_atom0;   // bond tables at the last reneighbor (= neighbor->bondlist)
 };
 static Topo topo_of(DeviceState &d) {
-  return Topo{d.maxtag, d.bpa, d.maxspecial, d.num_bond, d.bond_type, d.bond_atom, d.nspecial, d.special, d.type_t};
+  return Topo{d.maxtag, d.bpa, d.maxspecial, d.num_bond, d.bond_type, d.bond_atom, d.nspecial, d.special, d.type_t,
+              d.num_bond0, d.bond_type0, d.bond_atom0};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -106,10 +108,16 @@ __device__ __forceinline__ void dev_delete_bond(const Topo &tp, int i, int partn
       break;
     }
 }
-__device__ __forceinline__ void dev_special_remove12(const Topo &tp, int i, int partner) {   // :673-683
+// NOTE (reference behaviour, reproduced): when `partner` is NOT in the 1-2 block — an unload acting on a bond-list
+// entry that an extrusion moved earlier in the same step — the loop below still drops the entry at index n1 and
+// decrements all three counters, which can push a genuine 1-2 partner out of the 1-2 block of THIS bead only.
+// The reference's half neighbor list then takes the special status of a pair from the lower-index bead's list;
+// the flag tells the list build to do the same (k_build_neigh ASYM path).
+__device__ __forceinline__ void dev_special_remove12(const Topo &tp, int i, int partner, int *__restrict__ flags) {   // :673-683
   int *slist = tp.special + (size_t)i * tp.ms;
   int n1 = tp.nspecial[3 * (size_t)i], n3 = tp.nspecial[3 * (size_t)i + 2], m;
   for (m = 0; m < n1; m++) if (slist[m] == partner) break;
+  if (m == n1) flags[FLAG_SPECIAL_ASYM] = 1;
   for (; m < n3 - 1; m++) slist[m] = slist[m + 1];
   tp.nspecial[3 * (size_t)i]--; tp.nspecial[3 * (size_t)i + 1]--; tp.nspecial[3 * (size_t)i + 2]--;
 }
@@ -351,11 +359,11 @@ __global__ __launch_bounds__(BLOCK) void k_exunload_partner(Topo tp, ExUnloadPar
   int p = 0;
   if (t >= 1 && t <= tp.T) {
     double best = 0.0;
-    int nb = tp.num_bond[t];
+    int nb = tp.num_bond0[t];                       // the bond LIST (last reneighbor), not the current table
     double4 xi = xt[t], hi = xht[t];
     for (int m = 0; m < nb; m++) {
-      if (tp.bond_type[(size_t)t * tp.bpa + m] != P.btype) continue;
-      int u = tp.bond_atom[(size_t)t * tp.bpa + m];
+      if (tp.bond_type0[(size_t)t * tp.bpa + m] != P.btype) continue;
+      int u = tp.bond_atom0[(size_t)t * tp.bpa + m];
       double4 xj = xt[u], hj = xht[u];
       // partner image frozen at the last reneighbor (closest image then; ntopo_bond_all.cpp:53,64)
       double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(BLOCK) void k_exunload_break(Topo tp, ExUnloadParam
       }
       if (ok) {
         dev_delete_bond(tp, t, j);
-        dev_special_remove12(tp, t, j);
+        dev_special_remove12(tp, t, j, flags);
         f = j;
         if (t < j) atomicAdd(&flags[FLAG_COUNT_A], 1);
       }
@@ -426,9 +434,9 @@ __global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box 
   if (t > tp.T + 1) return;
   int fl = 0, u = 0;
   if (t >= 1 && t <= tp.T) {
-    int nb = tp.num_bond[t];
+    int nb = tp.num_bond0[t];                       // bond-list entries (last reneighbor)
     for (int m = 0; m < nb; m++)
-      if (tp.bond_type[(size_t)t * tp.bpa + m] == btype) { u = tp.bond_atom[(size_t)t * tp.bpa + m]; break; }
+      if (tp.bond_type0[(size_t)t * tp.bpa + m] == btype) { u = tp.bond_atom0[(size_t)t * tp.bpa + m]; break; }
     if (u) {
       double4 hi = xht[t], hj = xht[u];
       double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
@@ -581,8 +589,8 @@ __global__ __launch_bounds__(BLOCK) void k_ext_remove(Topo tp, const int *__rest
   }
   if ((to_add[lb - 1] == rb && to_add[rb] == lb - 1) || (to_add[lb - 1] == rb + 1 && to_add[rb + 1] == lb - 1) ||
       (to_add[lb] == rb + 1 && to_add[rb + 1] == lb)) {
-    dev_delete_bond(tp, lb, rb); dev_special_remove12(tp, lb, rb);
-    dev_delete_bond(tp, rb, lb); dev_special_remove12(tp, rb, lb);
+    dev_delete_bond(tp, lb, rb); dev_special_remove12(tp, lb, rb, flags);
+    dev_delete_bond(tp, rb, lb); dev_special_remove12(tp, rb, lb, flags);
     fin_rm[lb] = rb; fin_rm[rb] = lb;
     atomicAdd(&flags[FLAG_COUNT_A], 1);
   }

@@ -197,13 +197,14 @@ constexpr int SPMAX = 8;   // special entries translated to indices and kept in 
 
 // (An FP32 prefilter on a float4 copy of the positions was measured SLOWER here, 408 vs 337 us at 1M beads: some
 // lane of a wavefront survives the prefilter in almost every iteration, so both paths execute.)
-template <bool NOSPECIAL, bool MINIMG>
+template <bool NOSPECIAL, bool MINIMG, bool ASYM>
 __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const float4 *__restrict__ posf,
                                             float cutf, const double4 *__restrict__ pos,
                                             const int *__restrict__ tag, const Box &box, double cutneighsq, int n1,
                                             int n2, int n3, const int (&spi)[SPMAX], const int *__restrict__ slist,
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
-                                            int *__restrict__ neigh, int &cnt) {
+                                            int *__restrict__ neigh, const int *__restrict__ all_nspecial,
+                                            const int *__restrict__ all_special, int ms_, int &cnt) {
 #pragma clang fp contract(fast)
   for (int q = b; q < e; q++) {
     double4 rj = pos[q];
@@ -216,7 +217,26 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
     double rsq = delx * delx + dely * dely + delz * delz;
     if (rsq > cutneighsq || q == s) continue;
     int entry = q;
-    if (!NOSPECIAL && n3 > 0) {
+    bool own_list = true;
+    if (!NOSPECIAL && ASYM) {
+      // half-list semantics of the reference: the pair is stored under the lower local index (= lower ID at the
+      // canonical order), so ITS special list decides (npair_half_bin_newtoff.cpp:90-108)
+      int ts = tag[s], tq = tag[q];
+      if (tq < ts) {
+        own_list = false;
+        const int *ql = all_special + (size_t)tq * ms_;
+        int q1 = all_nspecial[3 * (size_t)tq], q2 = all_nspecial[3 * (size_t)tq + 1], q3 = all_nspecial[3 * (size_t)tq + 2];
+        int which = 0;
+        for (int k = 0; k < q3; k++)
+          if (ql[k] == ts) { which = (k < q1) ? 1 : (k < q2) ? 2 : 3; break; }
+        if (which) {
+          int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
+          if (sf == 0) continue;
+          if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
+        }
+      }
+    }
+    if (!NOSPECIAL && n3 > 0 && own_list) {
       int which = 0;
       if (n3 <= SPMAX) {
 #pragma unroll
@@ -238,7 +258,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
   }
 }
 
-template <bool NOSPECIAL>
+template <bool NOSPECIAL, bool ASYM>
 __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
                                                        const float4 *__restrict__ posf, float cutf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
@@ -287,10 +307,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
       int lo = max(x0, 0), hi = min(x1, ncx - 1);
 #define RANGE(B, E)                                                                                              \
   do {                                                                                                            \
-    if (all_in) neigh_range<NOSPECIAL, false>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, \
-                                              sf1, sf2, sf3, npad, maxneigh, neigh, cnt);                         \
-    else neigh_range<NOSPECIAL, true>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2, \
-                                      sf3, npad, maxneigh, neigh, cnt);                                           \
+    if (all_in) neigh_range<NOSPECIAL, false, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, \
+                                              sf1, sf2, sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt);   \
+    else neigh_range<NOSPECIAL, true, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2, \
+                                      sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt);                    \
   } while (0)
       if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + 1]);                      // cell 0 (image of ncx)
       RANGE(cell_start[row + lo], cell_start[row + hi + 1]);
@@ -348,12 +368,14 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
     // FP32 prefilter radius: float coordinates of a box this size carry ~|x| * 2^-23 error per component
     double cn = sqrt(cutneighsq), ferr = 8.0 * std::max({d.box.prd[0], d.box.prd[1], d.box.prd[2]}) * 1.2e-7;
     float cutf = (float)((cn + ferr) * (cn + ferr) * 1.0001);
-#define BUILD(NOSP)                                                                                                \
-  hipLaunchKernelGGL((k_build_neigh<NOSP>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, d.tag, d.map, \
+#define BUILD(NOSP, AS)                                                                                            \
+  hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
                      sf2, sf3, d.neigh, d.numneigh, d.flags)
-    if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true); else BUILD(false);
+    if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
+    else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
+    else BUILD(false, false);
 #undef BUILD
   }
 }

@@ -1260,3 +1260,10 @@ void leo_timers(leo_t *s, double *o) {
   o[0] = s->t_pair; o[1] = s->t_bond; o[2] = s->t_neigh; o[3] = s->t_modify;
   o[4] = s->t_total - s->t_pair - s->t_bond - s->t_neigh - s->t_modify; o[5] = s->t_total;
 }
+
+/* debug (tests only): scratch arrays of the last LE firing, local index order */
+void leo_debug_scratch(leo_t *s, int *ia, int *ib, double *da) {
+  if (ia) memcpy(ia, s->ia, s->n * sizeof(int));
+  if (ib) memcpy(ib, s->ib, s->n * sizeof(int));
+  if (da) memcpy(da, s->da, s->n * sizeof(double));
+}

@@ -1,0 +1,57 @@
+"""Randomised parity sweep of the LE fixes: product (GPU) vs oracle over seeded random parameter sets
+(firing periods, barrier densities and pass probabilities, load/unload probabilities and cutoffs, chain
+counts, box sizes small enough for periodic-face straddling).  Bond topology must be bit-exact every time."""
+import numpy as np
+import pytest
+
+from systems import CHAIN_SCRIPT, run_oracle, run_product
+from test_gpu_le import LE, barrier_types, melted
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_le_scenarios(tmp_path, seed):
+    rng = np.random.RandomState(1000 + seed)
+    n = int(rng.choice([1200, 2000, 3500]))
+    nchains = int(rng.choice([1, 2, 5]))
+    frac = float(rng.choice([0.0, 0.1, 0.4]))
+    types = barrier_types(n, 50 + seed, frac=frac) if frac > 0 else np.ones(n, dtype=np.int32)
+    s = melted(n, nchains=nchains, seed=20 + seed % 3, steps=800, types=types)
+    s["ntypes"], s["mass"] = 4, [1.0] * 4
+    n1, nl, nu = int(rng.randint(3, 9)), int(rng.randint(4, 11)), int(rng.randint(4, 11))
+    tp = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+    lp, up = float(rng.choice([0.2, 0.6, 1.0])), float(rng.choice([0.1, 0.5, 1.0]))
+    lprob = "" if lp >= 1.0 else "prob %g %d" % (lp, 100 + seed)
+    uprob = "" if up >= 1.0 else "prob %g %d" % (up, 200 + seed)
+    rmax = float(rng.choice([0.5, 1.3, 2.0]))
+    lr = "4" if rng.rand() < 0.7 else ""
+    base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 8.0 5.0 1.0 1.0")
+    script = base + LE.format(n1=n1, nl=nl, nu=nu, neutral=1, left=2, right=3, tp=tp, lr=lr, lprob=lprob, uprob=uprob,
+                              rmax=rmax) + "run 45\n"
+    try:
+        o = run_oracle(script, s)
+    except RuntimeError as e:      # the reference itself aborts on this parameter set (Bad FENE bond): the product must too
+        from lammps_le_amd import LammpsError
+        with pytest.raises(LammpsError):
+            run_product(script, s, tmp_path)
+        return
+    L = s["box"][0][1]
+    x = o.x()
+    ext = [b for b in o.bond_set() if b[0] == 2]
+    if ext:
+        d = max(np.linalg.norm((x[a - 1] - x[b - 1] + L / 2) % L - L / 2) for _, a, b in ext)
+        if d > 0.45 * L:
+            pytest.skip("a stretched extruder bond approaches half the box: image choice is reference-specific")
+    p = run_product(script, s, tmp_path)
+    assert p.bond_set() == o.bond_set()
+    assert (p.gather("num_bond") == o.bond_table()[0]).all()
+    for fid in ("loop", "loading", "unloading"):
+        assert p.extract_fix(fid, 0, 1, 0) == o.fix_vector(fid)[0]
+        assert p.extract_fix(fid, 0, 1, 1) == o.fix_vector(fid)[1]
+    nso, spo = o.special_table()
+    nsp, spp = p.gather("nspecial"), p.gather("special")
+    assert (nsp == nso).all()
+    for t in np.nonzero(nso[:, 2])[0]:
+        assert list(spp[t, :nsp[t, 2]]) == list(spo[t, :nso[t, 2]]), t + 1
+    assert np.abs(p.gather("x") - o.x()).max() < 1e-6

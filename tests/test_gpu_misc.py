@@ -1,0 +1,112 @@
+"""GPU edge cases of the script layer + kernels: non-uniform pair coefficients (table path), special_bonds
+lj 1 1 1 (no exclusions), ex_load type conversion, error propagation (Bad FENE bond), several runs with
+thermo fix keywords, write_data round trip, the lmp_le command-line driver."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from systems import CHAIN_SCRIPT, lattice_chain, run_oracle, run_product, write_data
+from test_gpu_le import LE, barrier_types, compare, melted
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def relerr(a, b, floor=1.0):
+    a, b = np.asarray(a), np.asarray(b)
+    return (np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), floor)).max()
+
+
+def test_nonuniform_pair_coefficients_and_mixing(tmp_path):
+    n = 5000
+    s = lattice_chain(n, seed=31, jitter=0.08, types=1 + (np.arange(n) % 3))
+    script = CHAIN_SCRIPT.replace("pair_coeff * * 1.0 1.0 1.12",
+                                  "pair_coeff 1 1 1.0 1.0 1.12\npair_coeff 2 2 0.8 0.9 1.2\npair_coeff 3 3 1.5 1.05 1.3\n"
+                                  "pair_coeff 1 3 0.5 1.0 1.0") + "fix 1 all nve\nrun 20\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert relerr(p.gather("x"), o.x()) < 1e-10
+    assert abs(p.get_thermo("epair") - o.thermo()[1]) < 1e-10
+    assert abs(p.get_thermo("press") - o.thermo()[4]) < 1e-9
+
+
+def test_special_bonds_all_ones(tmp_path):
+    s = lattice_chain(3000, seed=33, jitter=0.08)
+    script = CHAIN_SCRIPT.replace("special_bonds fene", "special_bonds lj 1.0 1.0 1.0") + "run 0\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert relerr(p.gather("f"), o.f()) < 1e-12
+    assert p.stat("neigh_pairs") == 2 * o.neigh_pairs()
+
+
+def test_ex_load_type_conversion(tmp_path):
+    """iparam 1 2 / jparam 1 2: a bead that reaches its bond limit becomes type 2 (fix_ex_load.cpp:593-598)."""
+    n = 3000
+    s = melted(n, seed=5)
+    s["ntypes"], s["mass"] = 2, [1.0, 1.0]
+    script = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0") + \
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n" \
+        "fix loading all ex_load 5 1 1 1.12 2 prob 0.7 684474 iparam 1 2 jparam 1 2\nrun 23\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert (p.gather("type") == o.types()).all() and (o.types() == 2).sum() > 10
+    assert p.bond_set() == o.bond_set()
+    assert relerr(p.gather("x"), o.x()) < 1e-8
+
+
+def test_bad_fene_bond_is_reported(tmp_path):
+    from lammps_le_amd import LammpsError
+    s = lattice_chain(2000, seed=35)
+    s["x"][1000] += np.array([3.2, 0.0, 0.0])          # stretch two backbone bonds far beyond 2*R0
+    script = CHAIN_SCRIPT + "fix 1 all nve\n"
+    p = run_product(script, s, tmp_path)
+    with pytest.raises(LammpsError, match="Bad FENE bond"):   # src/MOLECULE/bond_fene.cpp:90
+        p.command("run 5")
+    with pytest.raises(RuntimeError, match="Bad FENE bond"):
+        run_oracle(script + "run 5\n", s)
+
+
+def test_multiple_runs_thermo_keywords_and_write_data(tmp_path):
+    n = 4000
+    s = melted(n, nchains=2, seed=7, types=barrier_types(n, 3))
+    base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0")
+    script = base + LE.format(n1=10, nl=10, nu=10, neutral=1, left=2, right=3, tp=0.5, lr="4",
+                              lprob="prob 0.5 684474", uprob="prob 0.3 456456", rmax=0.5) + \
+        "thermo_style custom step temp epair emol press bonds f_loop[1] f_loading[1] f_loading[2] f_unloading[2]\n" \
+        "run 17\nrun 8\nrun 21\n"
+    o = run_oracle(script.replace("thermo_style", "#thermo_style"), s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    # write_data -> a fresh instance reads it back: same beads, same bonds (each once), same images
+    out = os.path.join(str(tmp_path), "out.data")
+    p.command("write_data " + out)
+    from lammps_le_amd import lammps
+    q = lammps(cmdargs=["-screen", "none"])
+    for ln in ("units lj", "atom_style bond", "special_bonds fene", "read_data " + out):
+        q.command(ln)
+    assert q.bond_set() == p.bond_set()
+    assert np.array_equal(q.gather("x"), p.gather("x")) and np.array_equal(q.gather("image"), p.gather("image"))
+    assert np.array_equal(q.gather("v"), p.gather("v")) and np.array_equal(q.gather("type"), p.gather("type"))
+
+
+def test_command_line_driver(tmp_path):
+    s = lattice_chain(1000, seed=41)
+    data = os.path.join(str(tmp_path), "data.chain")
+    write_data(data, s)
+    script = os.path.join(str(tmp_path), "in.chain")
+    open(script, "w").write(CHAIN_SCRIPT.replace("data.chain", data) +
+                            "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 25\nrun 50\n")
+    exe = os.path.join(ROOT, "lammps_le_amd", "lmp_le")
+    r = subprocess.run([exe, "-in", script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Loop time of" in r.stdout and "timesteps/s" in r.stdout
+    rows = [ln.split() for ln in r.stdout.split("\n") if ln.split()[:1] in (["0"], ["25"], ["50"])]
+    assert len(rows) == 3
+    o = run_oracle(CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 25\nrun 50\n", s)
+    h = o.thermo_history()
+    for row, ref in zip(rows, h):
+        assert abs(float(row[1]) - ref[1]) < 1e-6 and abs(float(row[5]) - ref[5]) < 1e-5
+    bad = subprocess.run([exe, "-in", "/nonexistent/in.x"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "Cannot open input script" in bad.stdout
