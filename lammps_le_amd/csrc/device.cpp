@@ -83,6 +83,13 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
 }
 
 void dev_free(DeviceState &d) {
+  if (d.rng_stream) {
+    (void)hipStreamSynchronize(d.rng_stream);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    for (int k = 0; k < 2; k++) { (void)hipEventDestroy(d.rng_done[k]); (void)hipEventDestroy(d.rng_consumed[k]); }
+    (void)hipStreamDestroy(d.rng_stream);
+    d.rng_stream = nullptr;
+  }
   dfree(d.pos); dfree(d.pos_tmp); dfree(d.xhold); dfree(d.posf);
   for (int k = 0; k < 3; k++) { dfree(d.v[k]); dfree(d.v_tmp[k]); dfree(d.f[k]); }
   dfree(d.tag); dfree(d.tag_tmp); dfree(d.img); dfree(d.img_tmp);
@@ -96,6 +103,7 @@ void dev_free(DeviceState &d) {
   if (d.flags_h) (void)hipHostFree(d.flags_h);
   d.flags_h = nullptr;
   dfree(d.rng_state); dfree(d.rng_jump); dfree(d.rng_buf[0]); dfree(d.rng_buf[1]); d.rng_out = nullptr;
+  dfree(d.rng_pool[0]); dfree(d.rng_pool[1]); dfree(d.rng_wstate); d.rng_W = 0; d.rng_batch_raw[0] = d.rng_batch_raw[1] = 0;
   dfree(d.xt); dfree(d.xht);
   dfree(d.gcell_start); dfree(d.gcell_count); dfree(d.sendlist[0]); dfree(d.sendlist[1]); dfree(d.migbuf[0]);
   dfree(d.migbuf[1]); dfree(d.migin); dfree(d.sendbuf); dfree(d.recvbuf); dfree(d.gdest); dfree(d.gtag_in);

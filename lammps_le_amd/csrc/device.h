@@ -53,7 +53,7 @@ struct DeviceState {
   // ---- physical order ----
   double4 *pos = nullptr, *pos_tmp = nullptr;   // x y z type
   double4 *xhold = nullptr;                      // positions at the last build (same order)
-  float4 *posf = nullptr;                        // FP32 copy of xhold for the list build's prefilter
+  float4 *posf = nullptr;                        // FP32 copy of the positions at the last reneighbor (list-build distance test)
   double *v[3] = {nullptr, nullptr, nullptr}, *v_tmp[3] = {nullptr, nullptr, nullptr};
   double *f[3] = {nullptr, nullptr, nullptr};
   int *tag = nullptr, *tag_tmp = nullptr;
@@ -68,6 +68,7 @@ struct DeviceState {
   // even when another LE fix changed the topology earlier in the same step (fix_ex_unload.cpp:223, fix_extrusion.cpp:368)
   int *num_bond0 = nullptr, *bond_type0 = nullptr, *bond_atom0 = nullptr;
   int le_snapshot = 0;             // keep the snapshot (set when an LE fix exists)
+  bool topo_dirty = true;          // bond tables changed since the snapshot was taken
   // ---- cells / neighbor list ----
   int ncell[3] = {0, 0, 0}, ncells = 0;
   double cellinv[3] = {0, 0, 0};
@@ -99,6 +100,15 @@ struct DeviceState {
   hipStream_t rng_stream = nullptr;
   hipEvent_t rng_done[2] = {nullptr, nullptr}, rng_consumed[2] = {nullptr, nullptr};
   bool rng_ahead = false;          // rng_buf[rng_cur ^ 1] already holds the draws of the next call
+  // batch generator (default): W whole calls per launch, one wavefront each, two pools alternating
+  int rng_mode = 1;                // 1 = batch (k_rng_calls), 0 = block-parallel per call (k_rng_langevin)
+  int rng_W = 0;
+  long long rng_total = 0;         // draws per call = 3 * beads in the system
+  uint32_t *rng_wstate = nullptr;  // [W][97] window in front of each wave's next call
+  uint32_t *rng_pool[2] = {nullptr, nullptr};   // [W][3N]
+  uint64_t rng_batch_raw[2] = {0, 0};           // raw index of the first draw held by each pool (0 = empty)
+  int rng_pool_cur = 0;
+  RanMarsInt rng_origin;           // host generator at the position given to rng_langevin_setup
   // ---- LE fixes (tag order) ----
   double4 *xt = nullptr;           // [maxtag+2] stored coordinates by tag
   int *le_i[16] = {nullptr};       // integer scratch arrays [maxtag+2]

@@ -379,7 +379,8 @@ void Engine::reneighbor() {
     // grow the ELL table and rebuild (atoms are already wrapped and sorted: the rebuild is idempotent)
     dev_alloc_neigh(d, d.flags_h[FLAG_MAXNEIGH] + 16);
   }
-  if (d.le_snapshot) {   // NTopoBond::build: the bond list the LE fixes will see until the next reneighbor
+  if (d.le_snapshot && d.topo_dirty) {   // NTopoBond::build: the bond list the LE fixes will see until the next reneighbor
+    d.topo_dirty = false;
     size_t nt = (size_t)d.maxtag + 2;
     HIP_CHECK(hipMemcpyAsync(d.num_bond0, d.num_bond, nt * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
     HIP_CHECK(hipMemcpyAsync(d.bond_type0, d.bond_type, nt * d.bpa * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
@@ -685,6 +686,7 @@ void Engine::run(long nsteps) {
   le_reneigh_step.assign(fixes.size(), -1);
   dev->le_snapshot = 0;
   for (auto &f : fixes) if (f->force_reneighbor) dev->le_snapshot = 1;
+  dev->topo_dirty = true;     // bond tables may have been edited between runs
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
   host_current = false;

@@ -194,6 +194,7 @@ void FixExtrusion::post_integrate() {
   if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob};
   launch_extrusion(d, p, slot);
+  d.topo_dirty = true;
   sync_flags(d);
   check_le_error(d, "extrusion");
   last_break = d.flags_h[FLAG_COUNT_A];
@@ -211,6 +212,7 @@ void FixExLoad::post_integrate() {
   if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction};
   launch_ex_load(d, p, slot);
+  d.topo_dirty = true;
   sync_flags(d);
   check_le_error(d, "ex_load");
   last_create = d.flags_h[FLAG_COUNT_A];
@@ -228,6 +230,7 @@ void FixExUnload::post_integrate() {
   if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExUnloadParams p{btype, cutsq, fraction};
   launch_ex_unload(d, p, slot);
+  d.topo_dirty = true;
   sync_flags(d);
   check_le_error(d, "ex_unload");
   last_break = d.flags_h[FLAG_COUNT_A];

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(BLOCK) void k_dd_ghost_place(int m, int base, const
   int i = perm[s];
   double4 r = in[i];
   pos[base + s] = r;
+  posf[base + s] = make_float4((float)r.x, (float)r.y, (float)r.z, 0.f);
   int t = tag_in[i];
   tag[base + s] = t;
   gdest[i] = s;

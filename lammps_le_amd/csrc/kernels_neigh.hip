@@ -164,6 +164,7 @@ __global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *_
   tagn[s] = t;
   imgn[s] = img[p]; imgn[npad + s] = img[npad + p]; imgn[2 * npad + s] = img[2 * npad + p];
   map[t] = s;
+  posf[s] = make_float4((float)r.x, (float)r.y, (float)r.z, 0.f);
 }
 __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, const int *__restrict__ tag,
                                                       const int *__restrict__ map, const int *__restrict__ num_bond,
@@ -195,27 +196,46 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, 
 // order, which depends only on the sorted positions -> deterministic.
 constexpr int SPMAX = 8;   // special entries translated to indices and kept in registers; longer lists use tags
 
-// (An FP32 prefilter on a float4 copy of the positions was measured SLOWER here, 408 vs 337 us at 1M beads: some
-// lane of a wavefront survives the prefilter in almost every iteration, so both paths execute.)
-template <bool NOSPECIAL, bool MINIMG, bool ASYM>
+// The distance test runs in FP32 on a float4 copy of the positions (half the bytes through the texture-address
+// path and a quarter of the FP64 issue cycles) and is DECISIVE outside an error band around cutneigh^2; inside the
+// band (a fraction ~1e-4 of the candidates) the FP64 test is repeated on the double positions, so the accepted set is
+// exactly the FP64 one.  (A variant that used FP32 only to reject, confirming every survivor in FP64, was slower:
+// some lane of a wavefront survives in almost every iteration, so both paths executed.)
+template <bool NOSPECIAL, bool MINIMG, bool ASYM, bool STAGE>
 __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const float4 *__restrict__ posf,
                                             float cutf, const double4 *__restrict__ pos,
                                             const int *__restrict__ tag, const Box &box, double cutneighsq, int n1,
                                             int n2, int n3, const int (&spi)[SPMAX], const int *__restrict__ slist,
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
                                             int *__restrict__ neigh, const int *__restrict__ all_nspecial,
-                                            const int *__restrict__ all_special, int ms_, int &cnt) {
+                                            const int *__restrict__ all_special, int ms_, int &cnt, float bandf,
+                                            int *__restrict__ stage) {
 #pragma clang fp contract(fast)
+  const float rix = (float)ri.x, riy = (float)ri.y, riz = (float)ri.z;
+  const float px = (float)box.prd[0], py = (float)box.prd[1], pz = (float)box.prd[2];
+  const float ipx = (float)box.iprd[0], ipy = (float)box.iprd[1], ipz = (float)box.iprd[2];
   for (int q = b; q < e; q++) {
-    double4 rj = pos[q];
-    double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
+    float4 rf = posf[q];
+    float dxf = rix - rf.x, dyf = riy - rf.y, dzf = riz - rf.z;
     if (MINIMG) {
-      delx -= box.prd[0] * __builtin_rint(delx * box.iprd[0]);
-      dely -= box.prd[1] * __builtin_rint(dely * box.iprd[1]);
-      delz -= box.prd[2] * __builtin_rint(delz * box.iprd[2]);
+      dxf -= px * __builtin_rintf(dxf * ipx);
+      dyf -= py * __builtin_rintf(dyf * ipy);
+      dzf -= pz * __builtin_rintf(dzf * ipz);
     }
-    double rsq = delx * delx + dely * dely + delz * delz;
-    if (rsq > cutneighsq || q == s) continue;
+    float rsqf = dxf * dxf + dyf * dyf + dzf * dzf;
+    bool reject = rsqf > cutf;
+    if (__builtin_fabsf(rsqf - cutf) <= bandf) {
+      double4 rj = pos[q];
+      double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
+      if (MINIMG) {
+        delx -= box.prd[0] * __builtin_rint(delx * box.iprd[0]);
+        dely -= box.prd[1] * __builtin_rint(dely * box.iprd[1]);
+        delz -= box.prd[2] * __builtin_rint(delz * box.iprd[2]);
+      }
+      double rsq = delx * delx + dely * dely + delz * delz;
+      reject = rsq > cutneighsq;
+    }
+    if (reject || q == s) continue;
     int entry = q;
     bool own_list = true;
     if (!NOSPECIAL && ASYM) {
@@ -253,14 +273,17 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
         if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
       }
     }
-    if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
+    if (cnt < maxneigh) {
+      if (STAGE) stage[cnt * BLOCK + threadIdx.x] = entry;
+      else neigh[(size_t)cnt * npad + s] = entry;
+    }
     cnt++;
   }
 }
 
-template <bool NOSPECIAL, bool ASYM>
+template <bool NOSPECIAL, bool ASYM, bool STAGE>
 __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
-                                                       const float4 *__restrict__ posf, float cutf,
+                                                       const float4 *__restrict__ posf, float cutf, float bandf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
                                                        const int *__restrict__ cell_start,
                                                        const int *__restrict__ gcell_start, int dd, double zlo_ext,
@@ -270,6 +293,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags) {
+  // STAGE: entries are collected in a per-lane LDS column and written out row by row at the end, so that every
+  // store instruction covers one contiguous row segment of the ELL table.  (Writing neigh[cnt][s] directly
+  // scatters each instruction over ~10 rows 4*npad bytes apart: partial cache lines, 5x write amplification.)
+  extern __shared__ int stage[];
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
   double4 ri = pos[active ? s : 0];
@@ -307,10 +334,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
       int lo = max(x0, 0), hi = min(x1, ncx - 1);
 #define RANGE(B, E)                                                                                              \
   do {                                                                                                            \
-    if (all_in) neigh_range<NOSPECIAL, false, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, \
-                                              sf1, sf2, sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt);   \
-    else neigh_range<NOSPECIAL, true, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2, \
-                                      sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt);                    \
+    if (all_in) neigh_range<NOSPECIAL, false, ASYM, STAGE>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, \
+                                              sf1, sf2, sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf, stage); \
+    else neigh_range<NOSPECIAL, true, ASYM, STAGE>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2, \
+                                      sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf, stage);      \
   } while (0)
       if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + 1]);                      // cell 0 (image of ncx)
       RANGE(cell_start[row + lo], cell_start[row + hi + 1]);
@@ -322,6 +349,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
       }
 #undef RANGE
     }
+  }
+  if (STAGE) {
+    int m = min(cnt, maxneigh);
+    for (int k = 0; k < m; k++) neigh[(size_t)k * npad + s] = stage[k * BLOCK + threadIdx.x];
   }
   numneigh[s] = min(cnt, maxneigh);
   if (cnt > maxneigh) flags[FLAG_NEIGH_OVERFLOW] = 1;
@@ -365,18 +396,28 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
     int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
     HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), st));
     double margin = sqrt(cutneighsq) * (1.0 + 1e-12);
-    // FP32 prefilter radius: float coordinates of a box this size carry ~|x| * 2^-23 error per component
-    double cn = sqrt(cutneighsq), ferr = 8.0 * std::max({d.box.prd[0], d.box.prd[1], d.box.prd[2]}) * 1.2e-7;
-    float cutf = (float)((cn + ferr) * (cn + ferr) * 1.0001);
-#define BUILD(NOSP, AS)                                                                                            \
-  hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, d.tag, d.map, \
+    // FP32 test: a float coordinate is off by <= M * 2^-24 (M = largest |coordinate|), a separation component
+    // (difference, periodic shift with a float box length) by e_d <= 8 * M * 2^-24, the squared distance of a pair
+    // near the cutoff by <= 2 * sqrt(3) * r * e_d + rounding; pairs beyond 1.5 * cutneigh are far outside any band
+    double cn = sqrt(cutneighsq), M = 0.0;
+    for (int k = 0; k < 3; k++) M = std::max({M, fabs(d.box.lo[k]), fabs(d.box.hi[k])});
+    double e_d = 8.0 * M * 5.97e-8;
+    float cutf = (float)cutneighsq;
+    float bandf = (float)(4.0 * 1.5 * cn * e_d + 3.0 * e_d * e_d + 1e-5 * cutneighsq);
+    if (getenv("LAMMPS_LE_BUILD_FP64")) bandf = 1e30f;     // diagnostic: every candidate takes the FP64 test
+#define BUILD1(NOSP, AS, STG, LDS)                                                                                 \
+  hipLaunchKernelGGL((k_build_neigh<NOSP, AS, STG>), dim3(nb), dim3(BLOCK), LDS, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
                      sf2, sf3, d.neigh, d.numneigh, d.flags)
-    if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
+    size_t lds = (size_t)d.maxneigh * BLOCK * sizeof(int);
+    bool stage = lds <= 64 * 1024 && getenv("LAMMPS_LE_BUILD_STAGE");
+#define BUILD(NOSP, AS) do { if (stage) BUILD1(NOSP, AS, true, lds); else BUILD1(NOSP, AS, false, 0); } while (0)
+    if ((sf1 == 1 && sf2 == 1 && sf3 == 1) || getenv("LAMMPS_LE_DIAG_NOSPECIAL")) BUILD(true, false);
     else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
     else BUILD(false, false);
 #undef BUILD
+#undef BUILD1
   }
 }
 

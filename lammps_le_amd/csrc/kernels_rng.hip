@@ -8,6 +8,9 @@
 // (b) writes them as 24-bit integers, (c) advances its window by the fixed per-call jump 3N with
 // the precomputed polynomial x^(3N) mod (x^97 + x^64 - 1) (97 dot products of length 97).
 #include "device.h"
+#include <cstring>
+#include <vector>
+#include <algorithm>
 
 namespace lmp_le {
 
@@ -59,8 +62,102 @@ __global__ __launch_bounds__(64) void k_rng_langevin(int B, long long total, uns
   if (i1 < 97) state[(size_t)b * 97 + i1] = acc1 & M24;
 }
 
+// ------------------------------------------------------------------------------------------
+// Batch generator (default).  The draw stream does not depend on the simulation state, so it is produced W calls
+// ahead: wavefront w of a batch generates ALL 3N draws of call (base + w) serially — no per-block jump — with the
+// twice-substituted recurrence  y_n = y_{n-97} - y_{n-130} + y_{n-66}  (min lag 66 >= 64: one full wavefront per
+// dependent step), then moves its window (W-1) calls ahead with x^((W-1)*3N) mod (x^97 + x^64 - 1).  A batch is a
+// latency-bound trickle (one wave per block, ~1 KB LDS) that runs on rng_stream underneath the step kernels of
+// the previous batch; per consumed call nothing is launched at all.
+// ring index of y_i (i = draw index within this wave's call) is (i + 97) & 255.
+__global__ __launch_bounds__(64) void k_rng_calls(long long total, unsigned long long base_raw,
+                                                  uint32_t *__restrict__ wstate, const uint32_t *__restrict__ jump,
+                                                  uint32_t *__restrict__ pool) {
+  __shared__ uint32_t ring[256];
+  __shared__ uint32_t a[97];
+  const int CM = 16777213, STEP64 = (int)((64ull * 7654321ull) % 16777213ull);
+  int w = blockIdx.x, lane = threadIdx.x;
+  uint32_t *st = wstate + (size_t)w * 97;
+  uint32_t *out = pool + (size_t)w * total;
+  unsigned long long raw0 = base_raw + (unsigned long long)w * (unsigned long long)total;
+  for (int k = lane; k < 97; k += 64) { ring[k] = st[k]; a[k] = jump[k]; }
+  __syncthreads();
+  if (lane < 33) {   // draws 0..32 with the plain recurrence (the 64-wide form needs y_{i-130}, i >= 33)
+    uint32_t y = (ring[lane] - ring[lane + 64]) & M24;
+    ring[lane + 97] = y;
+    if (lane < total) out[lane] = (y - c_of_dev(raw0 + lane)) & M24;
+  }
+  __syncthreads();
+  long long G = total + 96;   // 96 values past the end feed the jump below
+  int c = (int)c_of_dev(raw0 + 33ull + (unsigned long long)lane);
+  for (long long base = 33; base < G; base += 64) {
+    long long i = base + lane;
+    int r = (int)(i & 255);
+    uint32_t y = (ring[r] - ring[(r - 33) & 255] + ring[(r + 31) & 255]) & M24;   // y_{i-97} - y_{i-130} + y_{i-66}
+    ring[(r + 97) & 255] = y;
+    if (i < total) out[i] = (y - (uint32_t)c) & M24;
+    c -= STEP64;
+    if (c < 0) c += CM;
+    __syncthreads();
+  }
+  // window (W-1) calls ahead: y'[k] = sum_j a[j] * y_{total - 97 + k + j}; ring index of y_{total-97+m} is (total+m)&255
+  int t0 = (int)(total & 255);
+  uint32_t acc0 = 0, acc1 = 0;
+  int i1 = lane + 64;
+  for (int j = 0; j < 97; j++) {
+    uint32_t aj = a[j];
+    acc0 += aj * ring[(t0 + lane + j) & 255];
+    if (i1 < 97) acc1 += aj * ring[(t0 + i1 + j) & 255];
+  }
+  st[lane] = acc0 & M24;
+  if (i1 < 97) st[i1] = acc1 & M24;
+}
+
+static void rng_free_batch(DeviceState &d) {
+  for (int k = 0; k < 2; k++) if (d.rng_pool[k]) { (void)hipFree(d.rng_pool[k]); d.rng_pool[k] = nullptr; }
+  if (d.rng_wstate) { (void)hipFree(d.rng_wstate); d.rng_wstate = nullptr; }
+  d.rng_batch_raw[0] = d.rng_batch_raw[1] = 0;
+}
+
 void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
   long long total = 3ll * natoms;
+  if (!d.rng_stream) {
+    // lowest priority: the generator is a background trickle and must not delay the step kernels' workgroups
+    int prio_lo = 0, prio_hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_CHECK(hipStreamCreateWithPriority(&d.rng_stream, hipStreamNonBlocking, prio_lo));
+    for (int k = 0; k < 2; k++) {
+      HIP_CHECK(hipEventCreateWithFlags(&d.rng_done[k], hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&d.rng_consumed[k], hipEventDisableTiming));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(d.rng_stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+  d.rng_origin = host_rng;
+  d.rng_out = nullptr;
+  const char *mode = getenv("LAMMPS_LE_RNG_MODE");
+  d.rng_mode = (mode && !strcmp(mode, "block")) ? 0 : 1;
+  if (d.rng_mode == 1) {
+    // calls per batch: as many wavefronts as hide each other's latency, bounded by 2 pools of W*3N draws <= 16 GiB
+    long long w = (16ll << 30) / (8 * total);
+    int W = (int)std::min<long long>(512, std::max<long long>(8, w));
+    if (getenv("LAMMPS_LE_RNG_W")) W = std::max(2, atoi(getenv("LAMMPS_LE_RNG_W")));
+    if (W != d.rng_W || total != d.rng_total) {
+      rng_free_batch(d);
+      d.rng_W = W; d.rng_total = total;
+      for (int k = 0; k < 2; k++) HIP_CHECK(hipMalloc(&d.rng_pool[k], (size_t)W * total * sizeof(uint32_t)));
+      HIP_CHECK(hipMalloc(&d.rng_wstate, (size_t)W * 97 * sizeof(uint32_t)));
+      if (!d.rng_jump) HIP_CHECK(hipMalloc(&d.rng_jump, 97 * sizeof(uint32_t)));
+      uint32_t a[97];
+      ranmars_jump_poly((uint64_t)total * (uint64_t)(W - 1), a);
+      HIP_CHECK(hipMemcpyAsync(d.rng_jump, a, sizeof a, hipMemcpyHostToDevice, d.stream));
+      HIP_CHECK(hipStreamSynchronize(d.stream));
+    }
+    d.rng_batch_raw[0] = d.rng_batch_raw[1] = 0;   // the first call seeds the wave windows from rng_origin
+    return;
+  }
+  rng_free_batch(d);
+  d.rng_W = 0;
   // block length: the per-block cost is (B/33 dependent generation steps) + (a fixed 97x97 jump); small systems
   // are latency-bound -> short blocks, large ones amortise the jump over long blocks
   d.rng_B = natoms < 200000 ? 192 : 3072;
@@ -74,13 +171,6 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
   HIP_CHECK(hipMalloc(&d.rng_jump, 97 * sizeof(uint32_t)));
   for (int k = 0; k < 2; k++) HIP_CHECK(hipMalloc(&d.rng_buf[k], (size_t)total * sizeof(uint32_t)));
   d.rng_cur = 0; d.rng_out = d.rng_buf[0]; d.rng_ahead = false;
-  if (!d.rng_stream) {
-    HIP_CHECK(hipStreamCreateWithFlags(&d.rng_stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) {
-      HIP_CHECK(hipEventCreateWithFlags(&d.rng_done[k], hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&d.rng_consumed[k], hipEventDisableTiming));
-    }
-  }
   std::vector<uint32_t> st((size_t)d.rng_nblocks * 97);
   RanMarsInt r = host_rng;   // positioned at the first draw of the next call
   for (int b = 0; b < d.rng_nblocks; b++) {
@@ -106,7 +196,66 @@ static void rng_generate(DeviceState &d, int buf, uint64_t first_raw) {
                      (unsigned long long)first_raw, d.rng_state, d.rng_jump, d.rng_buf[buf]);
   HIP_CHECK(hipEventRecord(d.rng_done[buf], d.rng_stream));
 }
+static void rng_gen_batch(DeviceState &d, int pool, uint64_t base_raw, bool wait_consumed) {
+  if (wait_consumed) HIP_CHECK(hipStreamWaitEvent(d.rng_stream, d.rng_consumed[pool], 0));
+  hipLaunchKernelGGL(k_rng_calls, dim3(d.rng_W), dim3(64), 0, d.rng_stream, d.rng_total, (unsigned long long)base_raw,
+                     d.rng_wstate, d.rng_jump, d.rng_pool[pool]);
+  HIP_CHECK(hipEventRecord(d.rng_done[pool], d.rng_stream));
+  d.rng_batch_raw[pool] = base_raw;
+}
+// wave windows in front of calls first_raw + w*3N, w = 0..W-1, from the host generator; then two batches
+static void rng_seed_batches(DeviceState &d, uint64_t first_raw) {
+  HIP_CHECK(hipStreamSynchronize(d.rng_stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+  RanMarsInt r = d.rng_origin;
+  if (first_raw < r.n) throw LammpsError("internal: Langevin stream asked to go backwards");
+  r.jump(first_raw - r.n);
+  uint32_t a[97], y[193];
+  ranmars_jump_poly((uint64_t)d.rng_total, a);
+  std::vector<uint32_t> st((size_t)d.rng_W * 97);
+  for (int w = 0; w < d.rng_W; w++) {
+    for (int k = 0; k < 97; k++) st[(size_t)w * 97 + k] = r.w[k];
+    if (w + 1 == d.rng_W) break;
+    std::memcpy(y, r.w, sizeof r.w);
+    for (int i = 97; i < 193; i++) y[i] = (y[i - 97] - y[i - 33]) & M24;
+    for (int i = 0; i < 97; i++) {
+      uint32_t acc = 0;
+      for (int j = 0; j < 97; j++) acc += a[j] * y[i + j];
+      r.w[i] = acc & M24;
+    }
+  }
+  HIP_CHECK(hipMemcpyAsync(d.rng_wstate, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.rng_stream));
+  HIP_CHECK(hipStreamSynchronize(d.rng_stream));
+  uint64_t span = (uint64_t)d.rng_total * (uint64_t)d.rng_W;
+  rng_gen_batch(d, 0, first_raw, false);
+  rng_gen_batch(d, 1, first_raw + span, false);
+  d.rng_pool_cur = 0;
+  HIP_CHECK(hipStreamWaitEvent(d.stream, d.rng_done[0], 0));
+}
 void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
+  if (d.rng_mode == 1) {
+    uint64_t total = (uint64_t)d.rng_total, span = total * (uint64_t)d.rng_W;
+    auto inside = [&](int q) {
+      uint64_t b = d.rng_batch_raw[q];
+      return b && first_raw >= b && first_raw < b + span && (first_raw - b) % total == 0;
+    };
+    int p = d.rng_pool_cur;
+    if (!inside(p)) {
+      int q = p ^ 1;
+      if (inside(q)) {
+        // every consumer of pool p is already enqueued on d.stream: refill it with the batch after q
+        HIP_CHECK(hipEventRecord(d.rng_consumed[p], d.stream));
+        rng_gen_batch(d, p, d.rng_batch_raw[q] + span, true);
+        HIP_CHECK(hipStreamWaitEvent(d.stream, d.rng_done[q], 0));
+        d.rng_pool_cur = p = q;
+      } else {
+        rng_seed_batches(d, first_raw);
+        p = 0;
+      }
+    }
+    d.rng_out = d.rng_pool[p] + (first_raw - d.rng_batch_raw[p]);
+    return;
+  }
   if (d.ntotal < 200000) {
     // small systems are launch-bound: generate in order on the main stream (no events, no second stream)
     long long total = 3ll * d.ntotal;
@@ -125,7 +274,7 @@ void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
 }
 // to be called right after the consumer kernel of the current draws has been enqueued on d.stream
 void rng_langevin_consumed(DeviceState &d) {
-  if (d.ntotal < 200000) return;
+  if (d.rng_mode == 1 || d.ntotal < 200000) return;
   HIP_CHECK(hipEventRecord(d.rng_consumed[d.rng_cur], d.stream));
 }
 

@@ -110,3 +110,18 @@ def test_command_line_driver(tmp_path):
         assert abs(float(row[1]) - ref[1]) < 1e-6 and abs(float(row[5]) - ref[5]) < 1e-5
     bad = subprocess.run([exe, "-in", "/nonexistent/in.x"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "Cannot open input script" in bad.stdout
+
+
+@pytest.mark.parametrize("env", [{"LAMMPS_LE_RNG_MODE": "block"}, {"LAMMPS_LE_RNG_W": "3"}, {"LAMMPS_LE_RNG_W": "64"}])
+def test_langevin_generators_agree(tmp_path, env, monkeypatch):
+    """The Langevin stream is one serial RanMars (fix_langevin.cpp:670-674); the batch generator (whole calls per
+    wavefront, W calls ahead), the same with tiny batches (many pool switches, several runs) and the block-parallel
+    per-call generator must all hand the step kernel the same draws as the oracle's serial generator."""
+    s = lattice_chain(2500, seed=41, jitter=0.08)
+    script = CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
+    o = run_oracle(script + "run 37\nrun 5\nrun 1\n", s)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p = run_product(script + "run 37\nrun 5\nrun 1\n", s, tmp_path)
+    assert relerr(p.gather("x"), o.x()) < 1e-9
+    assert relerr(p.gather("v"), o.v()) < 1e-8
