@@ -56,9 +56,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    # rehearsal of the N > 1 path on a one-GPU box (every rank on device 0, file-mailbox transport instead of RCCL,
+    # which refuses two ranks on one device): LAMMPS_LE_BENCH_SHM=1.  Never used for reported numbers.
+    shm_rehearsal = world > 1 and os.environ.get("LAMMPS_LE_BENCH_SHM") == "1"
+    if shm_rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shm_rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     os.environ["LAMMPS_LE_KERNEL_TIMING"] = "1"
     from lammps_le_amd import lammps
@@ -75,7 +83,9 @@ def main():
     script = CHAIN_INPUT.format(data=data, n1=n1, left=left, right=right, tp=tp, lr=lr, nload=nload, pload=pload)
 
     lmp = lammps(cmdargs=["-screen", "none"])
-    if world > 1:
+    if world > 1 and shm_rehearsal:
+        lmp.comm_init("shm", rank, world, session="bench%s" % os.environ.get("MASTER_PORT", "0"))
+    elif world > 1:
         from lammps_le_amd import init_from_torch_distributed
         init_from_torch_distributed(lmp)     # engine's own RCCL communicator (unique id broadcast by torch)
     for ln in script.split("\n"):
@@ -96,7 +106,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device="cpu" if shm_rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -157,7 +167,8 @@ def main():
                                                                                  pload, nload, pload),
                        "beads_total": nbeads,
                        "parallelism": "1 GPU" if world == 1 else
-                       "%d z-slabs, one rank per GPU, halo + migration over RCCL, replicated extruder table" % world},
+                       "%d z-slabs, one rank per GPU, halo + migration over %s, replicated extruder table"
+                       % (world, "a file mailbox on ONE shared GPU (rehearsal, not a result)" if shm_rehearsal else "RCCL")},
             "roofline": roofline, "cpu_baseline": cpu,
             "engine_loop_time_s": round(lmp.stat("loop_time"), 5), "neigh_builds": int(lmp.stat("neigh_builds")),
             "extruders": int(nbonds - (nbeads - nchains)), "fene_warnings": int(lmp.stat("fene_warnings")),

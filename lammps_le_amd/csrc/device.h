@@ -148,7 +148,8 @@ void dev_alloc_neigh(DeviceState &d, int maxneigh);
 void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check);
 void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4], bool eflag, bool has_pair);
 void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4], const TypeTables &tt, bool langevin,
-                 bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check);
+                 bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start = nullptr,
+                 hipEvent_t ev_stop = nullptr);
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt);
 void launch_ke(DeviceState &d, const TypeTables &tt);

@@ -484,21 +484,16 @@ static int count_nve(Engine *e) {
 
 static bool timed_begin(Engine *e) {
   DeviceState &d = *e->dev;
-  // sample: every launch of the first 64, then every 16th (two event records cost ~5 us of host time each step)
+  // sample every 16th launch (uniform over the run)
   static long counter = 0;
   long c = counter++;
-  if (!e->kernel_timing || d.ev_used >= 4096 || (c >= 64 && (c & 15) != 0)) return false;
+  if (!e->kernel_timing || d.ev_used >= 4096 || (c & 15) != 0) return false;
   if (d.ev0.size() <= d.ev_used) {
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
     d.ev0.push_back(a); d.ev1.push_back(b);
   }
-  HIP_CHECK(hipEventRecord(d.ev0[d.ev_used], d.stream));
   return true;
-}
-static void timed_end(Engine *e, bool timed) {
-  DeviceState &d = *e->dev;
-  if (timed) { HIP_CHECK(hipEventRecord(d.ev1[d.ev_used], d.stream)); d.ev_used++; }
 }
 
 void Engine::compute_forces(bool eflag) {
@@ -659,8 +654,9 @@ void Engine::iterate(long nsteps) {
       bool check_next = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
       if (lg) langevin_draws(this, lg);
       bool timed = timed_begin(this);
-      launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next);
-      timed_end(this, timed);
+      launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
+                  timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr);
+      if (timed) d.ev_used++;
       if (lg) rng_langevin_consumed(d);
       pre_integrated = next;
     } else {

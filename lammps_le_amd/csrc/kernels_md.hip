@@ -11,6 +11,7 @@
 //   FixLangevin::post_force_templated<0,...>      src/fix_langevin.cpp:585-778
 //   Neighbor::check_distance                      src/neighbor.cpp:1962-2014
 #include "device.h"
+#include <hip/hip_ext.h>
 
 namespace lmp_le {
 
@@ -438,13 +439,16 @@ void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool 
 }
 // fused force + Langevin + final_integrate [+ next initial_integrate]; swaps the position buffers when `next`
 void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const TypeTables &tt, bool langevin,
-                 bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check) {
+                 bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
+                 hipEvent_t ev_stop) {
   ForceArgs A = force_args(d, sl);
   int grid = xcd_grid(A.nblocks);
+  // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
+  // the same clock rocprofv3 --kernel-trace reports
 #define STP(L, N, I, P)                                                                                      \
-  hipLaunchKernelGGL((k_step<L, N, I, P>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, tt, d.tag,   \
-                     d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2], d.pos_tmp, d.xhold, \
-                     dtv, triggersq, check ? 1 : 0, d.flags)
+  hipExtLaunchKernelGGL((k_step<L, N, I, P>), dim3(grid), dim3(BLOCK), 0, d.stream, ev_start, ev_stop, 0, A, bt, \
+                        d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],    \
+                        d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags)
   int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
   switch (key) {
     case 0: STP(false, false, false, false); break;  case 1: STP(false, false, false, true); break;

@@ -194,28 +194,27 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, 
 // physical indices (the bead's own special list is translated through map[] once), the minimum image is
 // branch-free and skipped by wavefronts that are wholly interior.  Entries come out in (row segment, index)
 // order, which depends only on the sorted positions -> deterministic.
-constexpr int SPMAX = 8;   // special entries translated to indices and kept in registers; longer lists use tags
+constexpr int SPMAX = 4;   // special entries THAT MATTER (weight != 1) translated to indices and kept in registers
 
 // The distance test runs in FP32 on a float4 copy of the positions (half the bytes through the texture-address
 // path and a quarter of the FP64 issue cycles) and is DECISIVE outside an error band around cutneigh^2; inside the
 // band (a fraction ~1e-4 of the candidates) the FP64 test is repeated on the double positions, so the accepted set is
 // exactly the FP64 one.  (A variant that used FP32 only to reject, confirming every survivor in FP64, was slower:
 // some lane of a wavefront survives in almost every iteration, so both paths executed.)
-template <bool NOSPECIAL, bool MINIMG, bool ASYM, bool STAGE>
+template <bool NOSPECIAL, bool MINIMG, bool ASYM>
 __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const float4 *__restrict__ posf,
                                             float cutf, const double4 *__restrict__ pos,
                                             const int *__restrict__ tag, const Box &box, double cutneighsq, int n1,
-                                            int n2, int n3, const int (&spi)[SPMAX], const int *__restrict__ slist,
+                                            int n2, int kmax, int nrel, const int (&spi)[SPMAX],
+                                            const int (&spc)[SPMAX], const int *__restrict__ slist,
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
                                             int *__restrict__ neigh, const int *__restrict__ all_nspecial,
-                                            const int *__restrict__ all_special, int ms_, int &cnt, float bandf,
-                                            int *__restrict__ stage) {
+                                            const int *__restrict__ all_special, int ms_, int &cnt, float bandf) {
 #pragma clang fp contract(fast)
   const float rix = (float)ri.x, riy = (float)ri.y, riz = (float)ri.z;
   const float px = (float)box.prd[0], py = (float)box.prd[1], pz = (float)box.prd[2];
   const float ipx = (float)box.iprd[0], ipy = (float)box.iprd[1], ipz = (float)box.iprd[2];
-  for (int q = b; q < e; q++) {
-    float4 rf = posf[q];
+  auto test = [&](int q, const float4 &rf) {
     float dxf = rix - rf.x, dyf = riy - rf.y, dzf = riz - rf.z;
     if (MINIMG) {
       dxf -= px * __builtin_rintf(dxf * ipx);
@@ -235,7 +234,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
       double rsq = delx * delx + dely * dely + delz * delz;
       reject = rsq > cutneighsq;
     }
-    if (reject || q == s) continue;
+    if (reject || q == s) return;
     int entry = q;
     bool own_list = true;
     if (!NOSPECIAL && ASYM) {
@@ -251,37 +250,36 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
           if (ql[k] == ts) { which = (k < q1) ? 1 : (k < q2) ? 2 : 3; break; }
         if (which) {
           int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
-          if (sf == 0) continue;
+          if (sf == 0) return;
           if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
         }
       }
     }
-    if (!NOSPECIAL && n3 > 0 && own_list) {
-      int which = 0;
-      if (n3 <= SPMAX) {
+    if (!NOSPECIAL && nrel > 0 && own_list) {
+      int code = 0;   // 0 = not special or weight 1; -1 = weight 0 (excluded); 1..3 = level with a fractional weight
+      if (nrel <= SPMAX) {
 #pragma unroll
-        for (int k = 0; k < SPMAX; k++)
-          if (k < n3 && spi[k] == q && which == 0) which = (k < n1) ? 1 : (k < n2) ? 2 : 3;
+        for (int k = 0; k < SPMAX; k++) code = (spi[k] == q) ? spc[k] : code;
       } else {
         int tq = tag[q];
-        for (int k = 0; k < n3; k++)
-          if (slist[k] == tq) { which = (k < n1) ? 1 : (k < n2) ? 2 : 3; break; }
+        for (int k = 0; k < kmax; k++)
+          if (slist[k] == tq) {
+            int which = (k < n1) ? 1 : (k < n2) ? 2 : 3;
+            int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
+            code = (sf == 0) ? -1 : (sf == 2) ? which : 0;
+            break;
+          }
       }
-      if (which) {
-        int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
-        if (sf == 0) continue;                       // weight 0.0: excluded from the list
-        if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
-      }
+      if (code < 0) return;                        // weight 0.0: excluded from the list
+      if (code > 0) entry = q | (code << NEIGH_SB_SHIFT);
     }
-    if (cnt < maxneigh) {
-      if (STAGE) stage[cnt * BLOCK + threadIdx.x] = entry;
-      else neigh[(size_t)cnt * npad + s] = entry;
-    }
+    if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
     cnt++;
-  }
+  };
+  for (int q = b; q < e; q++) test(q, posf[q]);
 }
 
-template <bool NOSPECIAL, bool ASYM, bool STAGE>
+template <bool NOSPECIAL, bool ASYM>
 __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
                                                        const float4 *__restrict__ posf, float cutf, float bandf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
@@ -293,27 +291,36 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags) {
-  // STAGE: entries are collected in a per-lane LDS column and written out row by row at the end, so that every
-  // store instruction covers one contiguous row segment of the ELL table.  (Writing neigh[cnt][s] directly
-  // scatters each instruction over ~10 rows 4*npad bytes apart: partial cache lines, 5x write amplification.)
-  extern __shared__ int stage[];
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
   double4 ri = pos[active ? s : 0];
   int cself = cell_index(ri, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
   int cx = cself % ncx, cy = (cself / ncx) % ncy, cz = cself / (ncx * ncy);
-  int n1 = 0, n2 = 0, n3 = 0;
+  // special entries whose level carries a weight != 1 (for `special_bonds fene` the 1-2 partners only): translated
+  // to physical indices once, compared as integers in the loop
+  int n1 = 0, n2 = 0, kmax = 0, nrel = 0;
   const int *slist = nullptr;
-  int spi[SPMAX];
+  int spi[SPMAX], spc[SPMAX];
 #pragma unroll
-  for (int k = 0; k < SPMAX; k++) spi[k] = -1;
+  for (int k = 0; k < SPMAX; k++) { spi[k] = -1; spc[k] = 0; }
   if (!NOSPECIAL && active) {
     int t = tag[s];
-    n1 = nspecial[3 * (size_t)t]; n2 = nspecial[3 * (size_t)t + 1]; n3 = nspecial[3 * (size_t)t + 2];
+    n1 = nspecial[3 * (size_t)t]; n2 = nspecial[3 * (size_t)t + 1];
+    int n3 = nspecial[3 * (size_t)t + 2];
     slist = special + (size_t)t * ms;
-    if (n3 <= SPMAX) {
+    kmax = (sf3 != 1) ? n3 : (sf2 != 1) ? n2 : (sf1 != 1) ? n1 : 0;
+    nrel = ((sf1 != 1) ? n1 : 0) + ((sf2 != 1) ? n2 - n1 : 0) + ((sf3 != 1) ? n3 - n2 : 0);
+    if (nrel <= SPMAX) {
+      int m = 0;
+      for (int k = 0; k < kmax; k++) {
+        int which = (k < n1) ? 1 : (k < n2) ? 2 : 3;
+        int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
+        if (sf == 1) continue;
+        int qi = map[slist[k]], code = (sf == 0) ? -1 : which;
 #pragma unroll
-      for (int k = 0; k < SPMAX; k++) if (k < n3) spi[k] = map[slist[k]];
+        for (int j = 0; j < SPMAX; j++) if (j == m) { spi[j] = qi; spc[j] = code; }
+        m++;
+      }
     }
   }
   // positions were wrapped into the box just before this kernel: interior = farther than cutneigh from all faces
@@ -334,10 +341,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
       int lo = max(x0, 0), hi = min(x1, ncx - 1);
 #define RANGE(B, E)                                                                                              \
   do {                                                                                                            \
-    if (all_in) neigh_range<NOSPECIAL, false, ASYM, STAGE>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, \
-                                              sf1, sf2, sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf, stage); \
-    else neigh_range<NOSPECIAL, true, ASYM, STAGE>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, n3, spi, slist, sf1, sf2, \
-                                      sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf, stage);      \
+    if (all_in) neigh_range<NOSPECIAL, false, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, \
+                                              sf1, sf2, sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf);        \
+    else neigh_range<NOSPECIAL, true, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
+                                      sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf);             \
   } while (0)
       if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + 1]);                      // cell 0 (image of ncx)
       RANGE(cell_start[row + lo], cell_start[row + hi + 1]);
@@ -349,10 +356,6 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
       }
 #undef RANGE
     }
-  }
-  if (STAGE) {
-    int m = min(cnt, maxneigh);
-    for (int k = 0; k < m; k++) neigh[(size_t)k * npad + s] = stage[k * BLOCK + threadIdx.x];
   }
   numneigh[s] = min(cnt, maxneigh);
   if (cnt > maxneigh) flags[FLAG_NEIGH_OVERFLOW] = 1;
@@ -405,19 +408,15 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
     float cutf = (float)cutneighsq;
     float bandf = (float)(4.0 * 1.5 * cn * e_d + 3.0 * e_d * e_d + 1e-5 * cutneighsq);
     if (getenv("LAMMPS_LE_BUILD_FP64")) bandf = 1e30f;     // diagnostic: every candidate takes the FP64 test
-#define BUILD1(NOSP, AS, STG, LDS)                                                                                 \
-  hipLaunchKernelGGL((k_build_neigh<NOSP, AS, STG>), dim3(nb), dim3(BLOCK), LDS, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
+#define BUILD(NOSP, AS)                                                                                            \
+  hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
                      sf2, sf3, d.neigh, d.numneigh, d.flags)
-    size_t lds = (size_t)d.maxneigh * BLOCK * sizeof(int);
-    bool stage = lds <= 64 * 1024 && getenv("LAMMPS_LE_BUILD_STAGE");
-#define BUILD(NOSP, AS) do { if (stage) BUILD1(NOSP, AS, true, lds); else BUILD1(NOSP, AS, false, 0); } while (0)
-    if ((sf1 == 1 && sf2 == 1 && sf3 == 1) || getenv("LAMMPS_LE_DIAG_NOSPECIAL")) BUILD(true, false);
+    if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
     else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
     else BUILD(false, false);
 #undef BUILD
-#undef BUILD1
   }
 }
 
