@@ -65,6 +65,14 @@ int  lammps_has_style(void *handle, const char *category, const char *name);
  * over the last run), "pair_kernel_launches", "neigh_pairs" (stored full-list entries), "maxneigh" */
 double lammps_le_stat(void *handle, const char *name);
 
+/* ranks: one process per GPU.  Replaces the MPI_Comm argument of the reference's `lammps_open` entry point
+ * (library.h:91; there is no MPI here, so that entry point itself is not exported): the launcher creates a 128-byte RCCL unique
+ * id on rank 0, distributes it, and every rank joins before its first `run`.  backend = "rccl" (xGMI) or "shm"
+ * (file mailbox; tests).  Afterwards every rank issues the same commands, as MPI ranks of the reference do. */
+int  lammps_le_comm_unique_id(char *out128);
+void lammps_le_comm_init(void *handle, const char *backend, int rank, int world, const char *unique_id,
+                         const char *session);
+
 #ifdef __cplusplus
 }
 #endif

@@ -278,6 +278,10 @@ extern "C" void lammps_le_comm_init(void *handle, const char *backend, int rank,
                                     const char *session) {
   BEGIN_CAPTURE e->comm_init(backend, rank, world, unique_id, session ? session : "default"); END_CAPTURE
 }
+// RCCL binding self-test on one GPU (size-1 communicator): 0 = pass
+extern "C" int lammps_le_rccl_selftest() {
+  try { return lmp_le::comm_rccl_selftest(); } catch (const std::exception &ex) { fprintf(stderr, "%s\n", ex.what()); return 1; }
+}
 // transport self-test without a GPU ("shm" backend): ring exchange + all-gather + max-reduce; returns 0 on success
 extern "C" int lammps_le_comm_selftest(const char *session, int rank, int world) {
   using namespace lmp_le;

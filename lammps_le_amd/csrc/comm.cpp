@@ -63,6 +63,43 @@ void comm_unique_id(char out[128]) {
   memcpy(out, id.internal, 128);
 }
 
+// One-rank RCCL self-test (runs on a one-GPU box): a communicator of size 1 exercises the dlopen'ed entry points
+// with the argument layouts and enum values this file declares by hand — all-reduce(max, int32), all-gather(int8)
+// and a grouped send/recv to self on a non-blocking stream.  Returns 0 on success, a step number otherwise.
+int comm_rccl_selftest() {
+  rccl.load();
+  ncclUniqueId_ id;
+  NCCL_CHECK(rccl.GetUniqueId(&id));
+  ncclComm_t c = nullptr;
+  NCCL_CHECK(rccl.CommInitRank(&c, 1, id, 0));
+  hipStream_t st;
+  HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  int *d = nullptr;
+  const int n = 1024;
+  HIP_CHECK(hipMalloc(&d, 4 * n * sizeof(int)));
+  std::vector<int> h(4 * n, 0);
+  for (int i = 0; i < n; i++) h[i] = 3 * i - 1000;
+  HIP_CHECK(hipMemcpyAsync(d, h.data(), 4 * n * sizeof(int), hipMemcpyHostToDevice, st));
+  int rc = 0;
+  NCCL_CHECK(rccl.AllReduce(d, d + n, n, ncclInt32, ncclMax, c, st));
+  NCCL_CHECK(rccl.AllGather(d, d + 2 * n, n * sizeof(int), ncclInt8, c, st));
+  NCCL_CHECK(rccl.GroupStart());
+  NCCL_CHECK(rccl.Send(d, n * sizeof(int), ncclInt8, 0, c, st));
+  NCCL_CHECK(rccl.Recv(d + 3 * n, n * sizeof(int), ncclInt8, 0, c, st));
+  NCCL_CHECK(rccl.GroupEnd());
+  HIP_CHECK(hipMemcpyAsync(h.data(), d, 4 * n * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (int i = 0; i < n && !rc; i++) {
+    if (h[n + i] != h[i]) rc = 2;
+    else if (h[2 * n + i] != h[i]) rc = 3;
+    else if (h[3 * n + i] != h[i]) rc = 4;
+  }
+  (void)hipFree(d);
+  (void)hipStreamDestroy(st);
+  rccl.CommDestroy(c);
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // file mailbox (test transport)
 // ---------------------------------------------------------------------------------------------

@@ -40,5 +40,6 @@ struct Comm {
 };
 
 void comm_unique_id(char out[128]);
+int comm_rccl_selftest();   // size-1 communicator on the current device (tests)
 
 }  // namespace lmp_le

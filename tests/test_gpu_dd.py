@@ -75,3 +75,12 @@ def test_le_fixes_across_slabs(tmp_path):
     assert r["thermo"][5] == o.nbonds()
     assert np.abs(r["x"] - o.x()).max() < 1e-7
     assert len([b for b in o.bond_set() if b[0] == 2]) > 20
+
+
+def test_rccl_bindings_on_one_rank():
+    """The engine declares RCCL's entry points by hand (dlopen, no header): a size-1 communicator on the test GPU
+    checks argument layouts and enum values through all-reduce(max), all-gather and a grouped send/recv to self."""
+    import ctypes
+    from lammps_le_amd import library_path
+    lib = ctypes.CDLL(library_path())
+    assert lib.lammps_le_rccl_selftest() == 0
