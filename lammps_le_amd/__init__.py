@@ -190,7 +190,8 @@ class lammps(object):
     def comm_init(self, backend, rank, world, unique_id=b"", session="default"):
         """Join a group of `world` engine instances.  backend "rccl": unique_id = the 128-byte ncclUniqueId
         created on rank 0 by `comm_unique_id()` and broadcast by the launcher; backend "shm": file mailbox under
-        /dev/shm (test transport).  Must be called before the first run; every rank then issues the same commands."""
+        /dev/shm (test transport, one process per rank); backend "local": the ranks are instances driven by threads
+        of this process (development transport).  Must be called before the first run; every rank then issues the same commands."""
         self.lib.lammps_le_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         buf = C.create_string_buffer(bytes(unique_id).ljust(128, b"\0"), 128)
         self.lib.lammps_le_comm_init(self.lmp, backend.encode(), rank, world, buf, session.encode())

@@ -6,6 +6,10 @@
 //     flags, ncclAllGather for the rare whole-system gathers.  librccl is dlopen'ed on first use so that
 //     single-GPU runs and CPU-only hosts never touch it.  The ncclUniqueId travels through whatever launched
 //     the ranks (bench.py broadcasts it with torch.distributed).
+//   * backend "local": the ranks are engine instances driven by threads of ONE process and share one GPU; a
+//     message is a stream-ordered device-to-device copy on the receiver's stream behind the sender's event, i.e.
+//     the same asynchronous semantics as RCCL without a second device.  Development transport: it lets the
+//     decomposed step loop be profiled (launch counts, synchronisations, idle gaps) on the one-GPU box.
 //   * backend "shm": a file mailbox under /dev/shm with host staging.  Test transport only — it lets several
 //     ranks share ONE GPU (RCCL refuses duplicate devices) so that the decomposition is verified against the
 //     oracle on the single-GPU box, and it runs without any GPU for the transport self-test.
@@ -15,9 +19,13 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <fstream>
+#include <map>
+#include <mutex>
 
 namespace lmp_le {
 
@@ -133,6 +141,83 @@ void Comm::shm_recv(int src, void *buf, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// in-process transport ("local")
+// ---------------------------------------------------------------------------------------------
+struct LocalMsg {
+  const void *ptr = nullptr;
+  size_t bytes = 0;
+  bool host = false;
+  hipEvent_t ready = nullptr, done = nullptr;
+  bool acked = false;
+};
+struct LocalHub {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<std::pair<int, int>, std::deque<std::shared_ptr<LocalMsg>>> box;   // (src, dst) -> messages in order
+};
+namespace {
+std::mutex hubs_mu;
+std::map<std::string, std::weak_ptr<LocalHub>> hubs;
+std::shared_ptr<LocalHub> hub_for(const std::string &session) {
+  std::lock_guard<std::mutex> g(hubs_mu);
+  auto sp = hubs[session].lock();
+  if (!sp) { sp = std::make_shared<LocalHub>(); hubs[session] = sp; }
+  return sp;
+}
+// one phase: post every send, serve every receive, then wait until the peers have taken the sends
+void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std::vector<Msg> &sends,
+                    const std::vector<Msg> &recvs) {
+  std::vector<std::shared_ptr<LocalMsg>> mine;
+  for (auto &m : sends) {
+    auto msg = std::make_shared<LocalMsg>();
+    msg->ptr = m.dev; msg->bytes = m.bytes; msg->host = host;
+    if (!host && m.bytes) {
+      HIP_CHECK(hipEventCreateWithFlags(&msg->ready, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(msg->ready, st));
+    }
+    { std::lock_guard<std::mutex> g(h.mu); h.box[{rank, m.peer}].push_back(msg); }
+    h.cv.notify_all();
+    mine.push_back(msg);
+  }
+  for (auto &m : recvs) {
+    std::shared_ptr<LocalMsg> msg;
+    {
+      std::unique_lock<std::mutex> lk(h.mu);
+      auto &q = h.box[{m.peer, rank}];
+      if (!h.cv.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty(); }))
+        throw LammpsError("local transport: timeout waiting for rank " + std::to_string(m.peer));
+      msg = q.front(); q.pop_front();
+    }
+    if (msg->bytes != m.bytes || msg->host != host)
+      throw LammpsError("local transport: message mismatch (" + std::to_string(msg->bytes) + " vs " + std::to_string(m.bytes) + " bytes)");
+    if (m.bytes) {
+      if (host) memcpy(m.dev, msg->ptr, m.bytes);
+      else {
+        HIP_CHECK(hipStreamWaitEvent(st, msg->ready, 0));
+        HIP_CHECK(hipMemcpyAsync(m.dev, msg->ptr, m.bytes, hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipEventCreateWithFlags(&msg->done, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(msg->done, st));
+      }
+    }
+    { std::lock_guard<std::mutex> g(h.mu); msg->acked = true; }
+    h.cv.notify_all();
+  }
+  for (auto &msg : mine) {
+    {
+      std::unique_lock<std::mutex> lk(h.mu);
+      if (!h.cv.wait_for(lk, std::chrono::seconds(120), [&] { return msg->acked; }))
+        throw LammpsError("local transport: timeout waiting for an acknowledgement");
+    }
+    if (msg->done) {     // the send buffer may be rewritten only after the receiver's copy has run
+      HIP_CHECK(hipStreamWaitEvent(st, msg->done, 0));
+      (void)hipEventDestroy(msg->done);
+    }
+    if (msg->ready) (void)hipEventDestroy(msg->ready);
+  }
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
 void Comm::init(const std::string &backend_name, int rank_, int world_, const void *id, const std::string &session) {
   rank = rank_; world = world_;
   if (world <= 1) { backend = NONE; return; }
@@ -142,6 +227,9 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
     memcpy(uid.internal, id, 128);
     NCCL_CHECK(rccl.CommInitRank(&g_comm, world, uid, rank));
     backend = RCCL;
+  } else if (backend_name == "local") {
+    hub = hub_for(session);
+    backend = LOCAL;
   } else if (backend_name == "shm") {
     shm_dir = "/dev/shm/le_" + session;
     mkdir(shm_dir.c_str(), 0777);
@@ -157,6 +245,16 @@ void Comm::finalize() {
 // host collectives (small, rebuild-time only)
 void Comm::allgather_host(const void *send, void *recv, size_t bytes) {
   if (backend == NONE) { memcpy(recv, send, bytes); return; }
+  if (backend == LOCAL) {
+    std::vector<Msg> ss, rr;
+    for (int r = 0; r < world; r++) {
+      if (r == rank) { memcpy((char *)recv + (size_t)r * bytes, send, bytes); continue; }
+      ss.push_back({const_cast<void *>(send), bytes, r});
+      rr.push_back({(char *)recv + (size_t)r * bytes, bytes, r});
+    }
+    local_exchange(*hub, rank, nullptr, true, ss, rr);
+    return;
+  }
   if (backend == SHM) {
     for (int r = 0; r < world; r++) if (r != rank) shm_send(r, send, bytes);
     for (int r = 0; r < world; r++) {
@@ -216,6 +314,16 @@ void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
 void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_t bytes) {
   if (backend == NONE) { HIP_CHECK(hipMemcpyAsync(recv_dev, send_dev, bytes, hipMemcpyDeviceToDevice, st)); return; }
   if (backend == RCCL) { NCCL_CHECK(rccl.AllGather(send_dev, recv_dev, bytes, ncclInt8, g_comm, st)); return; }
+  if (backend == LOCAL) {
+    std::vector<Msg> ss, rr;
+    for (int r = 0; r < world; r++) {
+      if (r == rank) { HIP_CHECK(hipMemcpyAsync((char *)recv_dev + (size_t)r * bytes, send_dev, bytes, hipMemcpyDeviceToDevice, st)); continue; }
+      ss.push_back({const_cast<void *>(send_dev), bytes, r});
+      rr.push_back({(char *)recv_dev + (size_t)r * bytes, bytes, r});
+    }
+    local_exchange(*hub, rank, st, false, ss, rr);
+    return;
+  }
   ensure_hbuf(bytes * (world + 1));
   HIP_CHECK(hipMemcpyAsync(hbuf.data(), send_dev, bytes, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
@@ -233,6 +341,7 @@ void Comm::exchange(hipStream_t st, const std::vector<Msg> &sends, const std::ve
     NCCL_CHECK(rccl.GroupEnd());
     return;
   }
+  if (backend == LOCAL) { local_exchange(*hub, rank, st, false, sends, recvs); return; }
   size_t mx = 0;
   for (auto &m : sends) mx = std::max(mx, m.bytes);
   for (auto &m : recvs) mx = std::max(mx, m.bytes);
@@ -249,6 +358,7 @@ void Comm::exchange(hipStream_t st, const std::vector<Msg> &sends, const std::ve
 // host-memory variant of exchange (counts; also the GPU-less transport self-test)
 void Comm::exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &recvs) {
   if (backend == NONE) return;
+  if (backend == LOCAL) { local_exchange(*hub, rank, nullptr, true, sends, recvs); return; }
   if (backend == SHM) {
     for (auto &m : sends) shm_send(m.peer, m.dev, m.bytes);
     for (auto &m : recvs) shm_recv(m.peer, m.dev, m.bytes);

@@ -1,5 +1,6 @@
 // comm.h — inter-rank transport of the decomposed engine (see comm.cpp)
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -10,7 +11,7 @@ namespace lmp_le {
 struct Msg { void *dev; size_t bytes; int peer; };
 
 struct Comm {
-  enum Backend { NONE, RCCL, SHM } backend = NONE;
+  enum Backend { NONE, RCCL, SHM, LOCAL } backend = NONE;
   int rank = 0, world = 1;
   hipStream_t main_stream = nullptr;   // every RCCL call is issued on the engine's stream: one total order per rank
   void init(const std::string &backend_name, int rank, int world, const void *unique_id, const std::string &session);
@@ -28,6 +29,7 @@ struct Comm {
   void barrier();
 
  private:
+  std::shared_ptr<struct LocalHub> hub;   // backend "local": ranks are engine instances (threads) of one process
   std::string shm_dir;
   std::vector<long> shm_sent, shm_rcvd;
   void shm_send(int dst, const void *buf, size_t bytes);

@@ -34,7 +34,9 @@ enum FlagSlot {
   FLAG_NLIST = 8,       // number of extruder listings
   FLAG_MAXNEIGH = 9,    // largest neighbor count seen at the last build
   FLAG_AUX = 10,
-  FLAG_SPECIAL_ASYM = 11,   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
+  FLAG_SPECIAL_ASYM = 11,
+  FLAG_RECV_UP = 12,    // decomposition: counts received from the upper / lower slab neighbour
+  FLAG_RECV_DN = 13,   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
   NFLAGS = 16
 };
 enum DevErr {

@@ -28,56 +28,68 @@ __device__ __forceinline__ double zrel_slab(double z, double slab_lo, const Box 
   return zc;
 }
 
-// ---- migration: wrap owned beads, classify stay / leave down / leave up ----
-__global__ __launch_bounds__(BLOCK) void k_dd_classify(int n, double4 *__restrict__ pos, int *__restrict__ img, int npad,
-                                                       Box box, double slab_lo, double width, int me, int P,
-                                                       int *__restrict__ keep, int *__restrict__ dn,
-                                                       int *__restrict__ up, int *__restrict__ flags) {
-  int p = blockIdx.x * BLOCK + threadIdx.x;
-  if (p >= n) return;
-  double4 r = pos[p];
-  if (!(isfinite(r.x) && isfinite(r.y) && isfinite(r.z))) { flags[FLAG_ERROR] = ERR_NONFINITE; keep[p] = 1; dn[p] = up[p] = 0; return; }
-  double *c = &r.x;
-#pragma unroll
-  for (int d = 0; d < 3; d++) {       // Domain::pbc (src/domain.cpp:528-645)
-    double x = c[d];
-    int im = img[d * npad + p];
-    if (x < box.lo[d]) { x += box.prd[d]; im--; }
-    if (x >= box.hi[d]) { x -= box.prd[d]; x = fmax(x, box.lo[d]); im++; }
-    c[d] = x;
-    img[d * npad + p] = im;
-  }
-  pos[p] = r;
-  // owner = slab index from one expression that every rank evaluates identically
-  int owner = (int)((r.z - box.lo[2]) / width);
-  owner = min(max(owner, 0), P - 1);
-  int k = owner == me ? 1 : 0;
-  double zc = zrel_slab(r.z, slab_lo, box);      // direction of travel for a bead that left
-  keep[p] = k;
-  dn[p] = (!k && zc < 0.0) ? 1 : 0;
-  up[p] = (!k && zc >= 0.0) ? 1 : 0;
+// slot for every lane with `pred` set: one atomic per wavefront (lanes of a wavefront get consecutive slots)
+__device__ __forceinline__ int wave_append(bool pred, int *__restrict__ counter) {
+  unsigned long long m = __ballot(pred);
+  if (m == 0ull) return 0;
+  int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1, base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader, 64);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
 }
-__global__ __launch_bounds__(BLOCK) void k_dd_split(int n, int npad, const int *__restrict__ keep, const int *__restrict__ dn,
-                                                    const int *__restrict__ kidx, const int *__restrict__ didx,
-                                                    const int *__restrict__ uidx, const double4 *__restrict__ pos,
-                                                    const double *__restrict__ vx, const double *__restrict__ vy,
-                                                    const double *__restrict__ vz, const int *__restrict__ tag,
-                                                    const int *__restrict__ img, double4 *__restrict__ pos_o,
-                                                    double *__restrict__ vxo, double *__restrict__ vyo,
-                                                    double *__restrict__ vzo, int *__restrict__ tag_o,
-                                                    int *__restrict__ img_o, double *__restrict__ mig_dn,
-                                                    double *__restrict__ mig_up) {
+
+// ---- migration: wrap owned beads (Domain::pbc, src/domain.cpp:528-645), keep those whose slab is mine, pack the
+// rest for the lower / upper neighbour.  Slots come from wave-aggregated atomics: the order is arbitrary, the cell
+// sort that follows (ties by ID) makes the final layout deterministic.  counters: flags[COUNT_A] = kept,
+// [COUNT_B] = sent down, [NDRAW] = sent up.
+__global__ __launch_bounds__(BLOCK) void k_dd_migrate(int n, int npad, int migcap, Box box, double slab_lo, double width,
+                                                      int me, int P, const double4 *__restrict__ pos,
+                                                      const double *__restrict__ vx, const double *__restrict__ vy,
+                                                      const double *__restrict__ vz, const int *__restrict__ tag,
+                                                      const int *__restrict__ img, double4 *__restrict__ pos_o,
+                                                      double *__restrict__ vxo, double *__restrict__ vyo,
+                                                      double *__restrict__ vzo, int *__restrict__ tag_o,
+                                                      int *__restrict__ img_o, double *__restrict__ mig_dn,
+                                                      double *__restrict__ mig_up, int *__restrict__ flags) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
-  if (p >= n) return;
-  double4 r = pos[p];
-  if (keep[p]) {
-    int s = kidx[p];
-    pos_o[s] = r; vxo[s] = vx[p]; vyo[s] = vy[p]; vzo[s] = vz[p]; tag_o[s] = tag[p];
-    img_o[s] = img[p]; img_o[npad + s] = img[npad + p]; img_o[2 * npad + s] = img[2 * npad + p];
-  } else {
-    double *b = dn[p] ? mig_dn + (size_t)didx[p] * MIG_W : mig_up + (size_t)uidx[p] * MIG_W;
+  bool active = p < n;
+  double4 r = pos[active ? p : 0];
+  int im[3] = {0, 0, 0};
+  bool keep = false, godn = false, goup = false;
+  if (active) {
+    if (!(isfinite(r.x) && isfinite(r.y) && isfinite(r.z))) { flags[FLAG_ERROR] = ERR_NONFINITE; keep = true; }
+    double *c = &r.x;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      double x = c[d];
+      int i = img[d * npad + p];
+      if (x < box.lo[d]) { x += box.prd[d]; i--; }
+      if (x >= box.hi[d]) { x -= box.prd[d]; x = fmax(x, box.lo[d]); i++; }
+      c[d] = x;
+      im[d] = i;
+    }
+    if (!keep) {
+      // owner = slab index from one expression that every rank evaluates identically
+      int owner = (int)((r.z - box.lo[2]) / width);
+      owner = min(max(owner, 0), P - 1);
+      keep = owner == me;
+      double zc = zrel_slab(r.z, slab_lo, box);      // direction of travel for a bead that left
+      godn = !keep && zc < 0.0;
+      goup = !keep && zc >= 0.0;
+    }
+  }
+  int sk = wave_append(keep, &flags[FLAG_COUNT_A]);
+  int sd = wave_append(godn, &flags[FLAG_COUNT_B]);
+  int su = wave_append(goup, &flags[FLAG_NDRAW]);
+  if (keep) {
+    pos_o[sk] = r; vxo[sk] = vx[p]; vyo[sk] = vy[p]; vzo[sk] = vz[p]; tag_o[sk] = tag[p];
+    img_o[sk] = im[0]; img_o[npad + sk] = im[1]; img_o[2 * npad + sk] = im[2];
+  } else if (godn || goup) {
+    int slot = godn ? sd : su;
+    if (slot >= migcap) return;                    // reported by the host from the counters
+    double *b = (godn ? mig_dn : mig_up) + (size_t)slot * MIG_W;
     b[0] = r.x; b[1] = r.y; b[2] = r.z; b[3] = r.w; b[4] = vx[p]; b[5] = vy[p]; b[6] = vz[p];
-    b[7] = (double)tag[p]; b[8] = (double)img[p]; b[9] = (double)img[npad + p]; b[10] = (double)img[2 * npad + p];
+    b[7] = (double)tag[p]; b[8] = (double)im[0]; b[9] = (double)im[1]; b[10] = (double)im[2];
     b[11] = 0.0;
   }
 }
@@ -95,31 +107,32 @@ __global__ __launch_bounds__(BLOCK) void k_dd_arrive(int narr, int base, int npa
   img[s] = (int)b[8]; img[npad + s] = (int)b[9]; img[2 * npad + s] = (int)b[10];
 }
 
-// ---- borders: owned beads within cutghost of my lower / upper z face (after the cell sort) ----
-__global__ __launch_bounds__(BLOCK) void k_dd_border_flags(int n, const double4 *__restrict__ pos, Box box, double slab_lo,
-                                                           double width, double cutghost, int *__restrict__ dn,
-                                                           int *__restrict__ up) {
+// ---- borders: owned beads within cutghost of my lower / upper z face (after the cell sort) are appended to the
+// two send lists (wave-aggregated atomics; the receiver sorts its ghosts by cell and ID, so the list order is free)
+__global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__restrict__ pos, Box box, double slab_lo,
+                                                      double width, double cutghost, int *__restrict__ list_dn,
+                                                      int *__restrict__ list_up, int *__restrict__ flags) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
-  if (p >= n) return;
-  double zc = zrel_slab(pos[p].z, slab_lo, box);
-  dn[p] = zc < cutghost ? 1 : 0;
-  up[p] = zc >= width - cutghost ? 1 : 0;
+  bool active = p < n;
+  double zc = active ? zrel_slab(pos[p].z, slab_lo, box) : 0.0;
+  bool dn = active && zc < cutghost, up = active && zc >= width - cutghost;
+  int sd = wave_append(dn, &flags[FLAG_COUNT_A]);
+  int su = wave_append(up, &flags[FLAG_COUNT_B]);
+  if (dn) list_dn[sd] = p;
+  if (up) list_up[su] = p;
 }
-__global__ __launch_bounds__(BLOCK) void k_dd_compact(int n, const int *__restrict__ flag, const int *__restrict__ idx,
-                                                      int *__restrict__ list) {
-  int p = blockIdx.x * BLOCK + threadIdx.x;
-  if (p < n && flag[p]) list[idx[p]] = p;
-}
-// halo pack (also used for the initial border exchange together with the tags)
-__global__ __launch_bounds__(BLOCK) void k_dd_pack(int m, const int *__restrict__ list, const double4 *__restrict__ pos,
+// halo pack of both send lists in one launch (also used for the initial border exchange together with the tags)
+__global__ __launch_bounds__(BLOCK) void k_dd_pack(int m0, int m1, const int *__restrict__ list0,
+                                                   const int *__restrict__ list1, const double4 *__restrict__ pos,
                                                    double4 *__restrict__ out) {
   int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < m) out[i] = pos[list[i]];
+  if (i < m0 + m1) out[i] = pos[i < m0 ? list0[i] : list1[i - m0]];
 }
-__global__ __launch_bounds__(BLOCK) void k_dd_pack_tags(int m, const int *__restrict__ list, const int *__restrict__ tag,
+__global__ __launch_bounds__(BLOCK) void k_dd_pack_tags(int m0, int m1, const int *__restrict__ list0,
+                                                        const int *__restrict__ list1, const int *__restrict__ tag,
                                                         int *__restrict__ out) {
   int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < m) out[i] = tag[list[i]];
+  if (i < m0 + m1) out[i] = tag[i < m0 ? list0[i] : list1[i - m0]];
 }
 __global__ __launch_bounds__(BLOCK) void k_dd_unpack(int m, int base, const int *__restrict__ gdest,
                                                      const double4 *__restrict__ in, double4 *__restrict__ pos) {
@@ -247,30 +260,32 @@ void dd_alloc(DeviceState &d, int world) {
 void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair) {
   hipStream_t st = d.stream;
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
-  const double width = d.slab_hi - d.slab_lo;
+  const double width = d.box.prd[2] / P;   // the SAME expression on every rank and in Engine::upload (owner of a bead)
   int n = d.n, nb = std::max(1, (n + BLOCK - 1) / BLOCK);
-  int *keep = d.le_i[0], *fdn = d.le_i[1], *fup = d.le_i[2], *kidx = d.le_i[3], *didx = d.le_i[4], *uidx = d.le_i[5];
+  const int migcap = (int)(((size_t)d.npad * MIG_W / 4) / MIG_W);
+  // counts travel rank-to-rank on the device and reach the host together with this rank's own counters: one
+  // host synchronisation per phase (migration, borders) instead of three
+  auto swap_counts = [&](int slot_dn, int slot_up) {
+    comm.exchange(st, {{d.flags + slot_dn, sizeof(int), dn_rank}, {d.flags + slot_up, sizeof(int), up_rank}},
+                  {{d.flags + FLAG_RECV_UP, sizeof(int), up_rank}, {d.flags + FLAG_RECV_DN, sizeof(int), dn_rank}});
+    sync_flags(d);
+  };
   // ---- 1. migration ----
-  hipLaunchKernelGGL(k_dd_classify, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.img, d.npad, d.box, d.slab_lo, width, me, P,
-                     keep, fdn, fup, d.flags);
-  scan_exclusive(d, keep, kidx, n, FLAG_COUNT_A);
-  scan_exclusive(d, fdn, didx, n, FLAG_COUNT_B);
-  scan_exclusive(d, fup, uidx, n, FLAG_NDRAW);
-  sync_flags(d);
-  int nkeep = d.flags_h[FLAG_COUNT_A], ndn = d.flags_h[FLAG_COUNT_B], nup = d.flags_h[FLAG_NDRAW];
-  if ((size_t)(ndn + nup) * MIG_W * sizeof(double) > (size_t)d.npad * MIG_W * sizeof(double) / 4)
-    throw LammpsError("too many beads migrate between slabs in one reneighbor");
-  hipLaunchKernelGGL(k_dd_split, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, keep, fdn, kidx, didx, uidx, d.pos, d.v[0],
-                     d.v[1], d.v[2], d.tag, d.img, d.pos_tmp, d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag_tmp, d.img_tmp,
-                     d.migbuf[0], d.migbuf[1]);
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
+  hipLaunchKernelGGL(k_dd_migrate, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, migcap, d.box, d.slab_lo, width, me, P, d.pos,
+                     d.v[0], d.v[1], d.v[2], d.tag, d.img, d.pos_tmp, d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag_tmp,
+                     d.img_tmp, d.migbuf[0], d.migbuf[1], d.flags);
   std::swap(d.pos, d.pos_tmp);
   for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
   std::swap(d.tag, d.tag_tmp);
   std::swap(d.img, d.img_tmp);
-  // counts: what I send down arrives as the lower rank's "from above", and vice versa
-  int sendc[2] = {ndn, nup}, recvc[2] = {0, 0};   // recvc[0] from below (their up), recvc[1] from above (their dn)
-  comm.exchange_host({{&sendc[0], sizeof(int), dn_rank}, {&sendc[1], sizeof(int), up_rank}},
-                     {{&recvc[1], sizeof(int), up_rank}, {&recvc[0], sizeof(int), dn_rank}});
+  swap_counts(FLAG_COUNT_B, FLAG_NDRAW);      // what I send down arrives as the lower rank's "from above"
+  int nkeep = d.flags_h[FLAG_COUNT_A], ndn = d.flags_h[FLAG_COUNT_B], nup = d.flags_h[FLAG_NDRAW];
+  int recvc[2] = {d.flags_h[FLAG_RECV_DN], d.flags_h[FLAG_RECV_UP]};   // [0] from below (their up), [1] from above
+  if (ndn > migcap || nup > migcap || recvc[0] + recvc[1] > 2 * migcap)
+    throw LammpsError("too many beads migrate between slabs in one reneighbor (down " + std::to_string(ndn) + ", up " +
+                      std::to_string(nup) + ", arriving " + std::to_string(recvc[0] + recvc[1]) + ", capacity " +
+                      std::to_string(migcap) + ")");
   comm.exchange(st, {{d.migbuf[0], (size_t)ndn * MIG_W * sizeof(double), dn_rank},
                      {d.migbuf[1], (size_t)nup * MIG_W * sizeof(double), up_rank}},
                 {{d.migin, (size_t)recvc[1] * MIG_W * sizeof(double), up_rank},
@@ -286,34 +301,33 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   hipLaunchKernelGGL(k_fill_int, dim3((d.maxtag + 2 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.maxtag + 2, d.map, -1);
   launch_sort_owned(d);
   // ---- 3. borders ----
-  hipLaunchKernelGGL(k_dd_border_flags, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width, d.cutghost, fdn,
-                     fup);
-  scan_exclusive(d, fdn, didx, n, FLAG_COUNT_A);
-  scan_exclusive(d, fup, uidx, n, FLAG_COUNT_B);
-  hipLaunchKernelGGL(k_dd_compact, dim3(nb), dim3(BLOCK), 0, st, n, fdn, didx, d.sendlist[0]);
-  hipLaunchKernelGGL(k_dd_compact, dim3(nb), dim3(BLOCK), 0, st, n, fup, uidx, d.sendlist[1]);
-  sync_flags(d);
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 2 * sizeof(int), st));
+  hipLaunchKernelGGL(k_dd_borders, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width, d.cutghost,
+                     d.sendlist[0], d.sendlist[1], d.flags);
+  swap_counts(FLAG_COUNT_A, FLAG_COUNT_B);
   d.nsend[0] = d.flags_h[FLAG_COUNT_A];
   d.nsend[1] = d.flags_h[FLAG_COUNT_B];
-  comm.exchange_host({{&d.nsend[0], sizeof(int), dn_rank}, {&d.nsend[1], sizeof(int), up_rank}},
-                     {{&d.nrecv[1], sizeof(int), up_rank}, {&d.nrecv[0], sizeof(int), dn_rank}});
+  d.nrecv[0] = d.flags_h[FLAG_RECV_DN];
+  d.nrecv[1] = d.flags_h[FLAG_RECV_UP];
   d.nghost = d.nrecv[0] + d.nrecv[1];
   if (n + d.nghost > d.npad - 64) throw LammpsError("ghost overflow on this rank");
   // first exchange: positions and tags (arrival order: from above first, then from below — same as every step)
   int *tagsend = d.le_i[6], *tagrecv = d.gtag_in;
-  for (int k = 0; k < 2; k++)
-    if (d.nsend[k]) {
-      int m = d.nsend[k], g = (m + BLOCK - 1) / BLOCK, off = k ? d.nsend[0] : 0;
-      hipLaunchKernelGGL(k_dd_pack, dim3(g), dim3(BLOCK), 0, st, m, d.sendlist[k], d.pos, d.sendbuf + off);
-      hipLaunchKernelGGL(k_dd_pack_tags, dim3(g), dim3(BLOCK), 0, st, m, d.sendlist[k], d.tag, tagsend + off);
-    }
+  int nsall = d.nsend[0] + d.nsend[1];
+  if (nsall) {
+    int g = (nsall + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(k_dd_pack, dim3(g), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1], d.sendlist[0], d.sendlist[1], d.pos,
+                       d.sendbuf);
+    hipLaunchKernelGGL(k_dd_pack_tags, dim3(g), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1], d.sendlist[0], d.sendlist[1],
+                       d.tag, tagsend);
+  }
   comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
-                     {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank}},
-                {{d.recvbuf, (size_t)d.nrecv[1] * sizeof(double4), up_rank},
-                 {d.recvbuf + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(double4), dn_rank}});
-  comm.exchange(st, {{tagsend, (size_t)d.nsend[0] * sizeof(int), dn_rank},
+                     {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank},
+                     {tagsend, (size_t)d.nsend[0] * sizeof(int), dn_rank},
                      {tagsend + d.nsend[0], (size_t)d.nsend[1] * sizeof(int), up_rank}},
-                {{tagrecv, (size_t)d.nrecv[1] * sizeof(int), up_rank},
+                {{d.recvbuf, (size_t)d.nrecv[1] * sizeof(double4), up_rank},
+                 {d.recvbuf + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(double4), dn_rank},
+                 {tagrecv, (size_t)d.nrecv[1] * sizeof(int), up_rank},
                  {tagrecv + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(int), dn_rank}});
   // ---- 4. ghosts into cell order behind the owned beads ----
   int m = d.nghost, gb = std::max(1, (m + BLOCK - 1) / BLOCK);
@@ -338,12 +352,10 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
 void dd_halo(DeviceState &d, Comm &comm) {
   hipStream_t st = d.stream;
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
-  for (int k = 0; k < 2; k++)
-    if (d.nsend[k]) {
-      int m = d.nsend[k], off = k ? d.nsend[0] : 0;
-      hipLaunchKernelGGL(k_dd_pack, dim3((m + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, m, d.sendlist[k], d.pos,
-                         d.sendbuf + off);
-    }
+  int nsall = d.nsend[0] + d.nsend[1];
+  if (nsall)
+    hipLaunchKernelGGL(k_dd_pack, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
+                       d.sendlist[0], d.sendlist[1], d.pos, d.sendbuf);
   comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
                      {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank}},
                 {{d.recvbuf, (size_t)d.nrecv[1] * sizeof(double4), up_rank},

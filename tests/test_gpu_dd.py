@@ -29,6 +29,50 @@ def run_ranks(world, system, script, tmp_path):
     return np.load(out)
 
 
+def run_ranks_local(world, system, script, tmp_path):
+    """Same as run_ranks, but the ranks are threads of this process talking through the in-process transport
+    (stream-ordered device-to-device copies): no files, no host staging, any number of ranks on the one GPU."""
+    import threading
+    from lammps_le_amd import lammps
+    from systems import write_data
+    session = uuid.uuid4().hex[:12]
+    path = os.path.join(str(tmp_path), "data.local")
+    write_data(path, system)
+    out, errs = [None] * world, []
+
+    def work(rank):
+        try:
+            lmp = lammps(cmdargs=["-screen", "none"])
+            lmp.comm_init("local", rank, world, session=session)
+            for ln in script.split("\n"):
+                w = ln.split("#")[0].split()
+                lmp.command("read_data " + path if w and w[0] == "read_data" else ln)
+            res = dict(x=lmp.gather("x"), v=lmp.gather("v"), image=lmp.gather("image"),
+                       num_bond=lmp.gather("num_bond"), bond_type=lmp.gather("bond_type"), bond_atom=lmp.gather("bond_atom"),
+                       nspecial=lmp.gather("nspecial"), special=lmp.gather("special"),
+                       thermo=np.array([lmp.get_thermo(k) for k in ("temp", "epair", "emol", "etotal", "press", "bonds")]),
+                       neigh_pairs=np.array([lmp.stat("neigh_pairs")]), builds=np.array([lmp.stat("neigh_builds")]))
+            for fid in ("loop", "loading", "unloading"):
+                try:
+                    res["f_" + fid] = np.array([lmp.extract_fix(fid, 0, 1, 0), lmp.extract_fix(fid, 0, 1, 1)])
+                except Exception:
+                    pass
+            out[rank] = res
+            lmp.close()
+        except Exception as e:       # a failing rank leaves the others waiting for the transport's timeout
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for r in range(1, world):        # every rank holds the same gathered state
+        assert np.array_equal(out[r]["x"], out[0]["x"]) and np.array_equal(out[r]["bond_atom"], out[0]["bond_atom"])
+    return out[0]
+
+
 def bond_set(nb, bt, ba):
     out = set()
     for i in np.nonzero(nb)[0]:
@@ -75,6 +119,39 @@ def test_le_fixes_across_slabs(tmp_path):
     assert r["thermo"][5] == o.nbonds()
     assert np.abs(r["x"] - o.x()).max() < 1e-7
     assert len([b for b in o.bond_set() if b[0] == 2]) > 20
+
+
+@pytest.mark.parametrize("world,n", [(2, 6000), (4, 40000), (5, 40000)])
+def test_md_across_slabs_in_process(tmp_path, world, n):
+    """4 and 5 slabs (interior ranks with two different neighbours) over the in-process transport."""
+    s = lattice_chain(n, nchains=2, seed=23)
+    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 30\nrun 60\n"
+    o = run_oracle(script, s)
+    r = run_ranks_local(world, s, script, tmp_path)
+    assert np.abs(r["x"] - o.x()).max() < 1e-9
+    assert np.abs(r["v"] - o.v()).max() < 1e-8
+    assert (r["image"] == o.image()).all()
+    assert np.abs(r["thermo"][:5] - o.thermo()[:5]).max() < 1e-9
+    assert r["neigh_pairs"][0] == 2 * o.neigh_pairs()
+    assert r["builds"][0] == o.neigh_builds()
+
+
+def test_le_fixes_across_three_slabs_in_process(tmp_path):
+    n = 60000      # slab width 13.8 >= two ghost shells of 6.2
+    s = melted(n, nchains=3, seed=9, types=barrier_types(n, 17))
+    base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 6.2") \
+        .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 10.0 6.0 1.0 1.0")
+    script = base + LE.format(n1=20, nl=10, nu=10, neutral=1, left=2, right=3, tp=0.5, lr="4",
+                              lprob="prob 0.5 684474", uprob="prob 0.3 456456", rmax=0.5) + "run 50\n"
+    o = run_oracle(script, s)
+    r = run_ranks_local(3, s, script, tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+    ns_o, sp_o = o.special_table()
+    assert special_sets(r["nspecial"], r["special"]) == special_sets(ns_o, sp_o)
+    for fid in ("loop", "loading", "unloading"):
+        assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1]
+    assert np.abs(r["x"] - o.x()).max() < 1e-7
 
 
 def test_rccl_bindings_on_one_rank():
