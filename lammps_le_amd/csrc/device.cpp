@@ -54,8 +54,8 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
     d.cellinv[k] = d.ncell[k] / extent;
     d.ncells *= d.ncell[k];
   }
-  dalloc(d.cell_of, np); dalloc(d.cell_count, (size_t)d.ncells + 1); dalloc(d.cell_start, (size_t)d.ncells + 1);
-  dalloc(d.cell_fill, (size_t)d.ncells + 1); dalloc(d.scan_tmp, (size_t)d.ncells / 1024 + 2); dalloc(d.perm, np);
+  dalloc(d.cell_of, np); dalloc(d.cell_count, (size_t)d.ncells + 2); dalloc(d.cell_start, (size_t)d.ncells + 2);
+  dalloc(d.cell_fill, (size_t)d.ncells + 2); dalloc(d.scan_tmp, (size_t)d.ncells / 1024 + 2); dalloc(d.perm, np);
   double vol = box.prd[0] * box.prd[1] * box.prd[2];
   double expect = (double)n / vol * 4.18879020478639 * cutneigh * cutneigh * cutneigh;
   int mn = (int)(expect * 1.5) + 24;
@@ -106,7 +106,7 @@ void dev_free(DeviceState &d) {
   dfree(d.rng_pool[0]); dfree(d.rng_pool[1]); dfree(d.rng_wstate); d.rng_W = 0; d.rng_batch_raw[0] = d.rng_batch_raw[1] = 0;
   dfree(d.xt); dfree(d.xht);
   dfree(d.gcell_start); dfree(d.gcell_count); dfree(d.sendlist[0]); dfree(d.sendlist[1]); dfree(d.migbuf[0]);
-  dfree(d.migbuf[1]); dfree(d.migin); dfree(d.sendbuf); dfree(d.recvbuf); dfree(d.gdest); dfree(d.gtag_in);
+  dfree(d.migbuf[1]); dfree(d.migin); dfree(d.sendbuf); dfree(d.recvbuf); dfree(d.gdest); dfree(d.gtag_in); dfree(d.gone);
   dfree(d.gather_send); d.gather_recv = nullptr; d.gather_cap = 0;
   for (int k = 0; k < 16; k++) dfree(d.le_i[k]);
   for (int k = 0; k < 2; k++) dfree(d.le_d[k]);
@@ -117,12 +117,17 @@ void dev_free(DeviceState &d) {
 
 // flags reach the host through a mapped pinned page written by a one-wave kernel (a blit-copy of 64 bytes costs
 // ~18 us on this stack, a kernel + sync ~5 us)
-__global__ void k_publish_flags(const int *__restrict__ flags, int *__restrict__ host) {
-  if (threadIdx.x < NFLAGS) host[threadIdx.x] = flags[threadIdx.x];
+// `reset` = bit mask of flags that are zeroed right after they were published (saves one memset launch per flag
+// and phase: the consumer of a flag is always the host, which reads the published copy)
+__global__ void k_publish_flags(int *__restrict__ flags, int *__restrict__ host, unsigned reset) {
+  if (threadIdx.x < NFLAGS) {
+    host[threadIdx.x] = flags[threadIdx.x];
+    if ((reset >> threadIdx.x) & 1u) flags[threadIdx.x] = 0;
+  }
   __threadfence_system();
 }
-void sync_flags(DeviceState &d) {
-  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, d.stream, d.flags, d.flags_h_dev);
+void sync_flags(DeviceState &d, unsigned reset) {
+  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, d.stream, d.flags, d.flags_h_dev, reset);
   HIP_CHECK(hipStreamSynchronize(d.stream));
 }
 

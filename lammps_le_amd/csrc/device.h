@@ -129,6 +129,7 @@ struct DeviceState {
   int *sendlist[2] = {nullptr, nullptr};                // owned indices sent down / up every step
   int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
   double4 *sendbuf = nullptr, *recvbuf = nullptr;       // halo staging
+  int *gone = nullptr;                                  // [npad] 1 = this bead has just left for another slab
   int *gdest = nullptr;                                 // arrival order -> sorted ghost slot
   int *gtag_in = nullptr;                               // ghost tags in arrival order
   double *migbuf[2] = {nullptr, nullptr}, *migin = nullptr;   // migrating beads (MIG_W doubles each)
@@ -160,7 +161,7 @@ void reduce_partials(DeviceState &d, double *out16);
 
 // neighbor (kernels_neigh.hip)
 void launch_reneighbor(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
-void launch_sort_owned(DeviceState &d);
+void launch_sort_owned(DeviceState &d, int m_in = -1, int n_out = -1, const int *gone = nullptr);
 void launch_lists(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
 
 // rng (kernels_rng.hip)
@@ -188,7 +189,7 @@ void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
 void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
 void launch_ex_unload(DeviceState &d, const ExUnloadParams &p, int rng_slot);
 void launch_extrusion(DeviceState &d, const ExtrusionParams &p, int rng_slot);
-void sync_flags(DeviceState &d);   // copy flags to flags_h and wait
+void sync_flags(DeviceState &d, unsigned reset_mask = 0);   // copy flags to flags_h, zero the masked ones, wait
 void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);
 void dd_alloc(DeviceState &d, int world);
 

@@ -367,13 +367,12 @@ static void check_device_error(Engine *e, DeviceState &d) {
 void Engine::reneighbor() {
   DeviceState &d = *dev;
   double t0 = wall();
-  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MOVED, 0, sizeof(int), d.stream));
+  // FLAG_MOVED / NEIGH_OVERFLOW / MAXNEIGH are zero here: they are reset by the publish kernel that reports them
   for (int attempt = 0; attempt < 6; attempt++) {
-    HIP_CHECK(hipMemsetAsync(d.flags + FLAG_NEIGH_OVERFLOW, 0, sizeof(int), d.stream));
     if (attempt > 0) launch_lists(d, cutneighmax * cutneighmax, special_lj, pair_lj);   // sorted already: lists only
     else if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);
     else launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
-    sync_flags(d);
+    sync_flags(d, (1u << FLAG_MOVED) | (1u << FLAG_NEIGH_OVERFLOW) | (1u << FLAG_MAXNEIGH));
     check_device_error(this, d);
     if (!d.flags_h[FLAG_NEIGH_OVERFLOW]) break;
     // grow the ELL table and rebuild (atoms are already wrapped and sorted: the rebuild is idempotent)

@@ -38,53 +38,50 @@ __device__ __forceinline__ int wave_append(bool pred, int *__restrict__ counter)
   return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
-// ---- migration: wrap owned beads (Domain::pbc, src/domain.cpp:528-645), keep those whose slab is mine, pack the
-// rest for the lower / upper neighbour.  Slots come from wave-aggregated atomics: the order is arbitrary, the cell
-// sort that follows (ties by ID) makes the final layout deterministic.  counters: flags[COUNT_A] = kept,
-// [COUNT_B] = sent down, [NDRAW] = sent up.
-__global__ __launch_bounds__(BLOCK) void k_dd_migrate(int n, int npad, int migcap, Box box, double slab_lo, double width,
-                                                      int me, int P, const double4 *__restrict__ pos,
-                                                      const double *__restrict__ vx, const double *__restrict__ vy,
-                                                      const double *__restrict__ vz, const int *__restrict__ tag,
-                                                      const int *__restrict__ img, double4 *__restrict__ pos_o,
-                                                      double *__restrict__ vxo, double *__restrict__ vyo,
-                                                      double *__restrict__ vzo, int *__restrict__ tag_o,
-                                                      int *__restrict__ img_o, double *__restrict__ mig_dn,
-                                                      double *__restrict__ mig_up, int *__restrict__ flags) {
+// ---- migration: wrap owned beads (Domain::pbc, src/domain.cpp:528-645); a bead whose slab is no longer mine is
+// packed for the lower / upper neighbour (slots from wave-aggregated atomics: leavers are few) and marked `gone`.
+// Kept beads are not moved here: the cell sort that follows bins `gone` beads into a sentinel cell behind all real
+// cells, which compacts the arrays for free.  counters: flags[COUNT_B] = sent down, [NDRAW] = sent up.
+__global__ __launch_bounds__(BLOCK) void k_dd_leave(int n, int npad, int migcap, Box box, double slab_lo, double width,
+                                                    int me, int P, double4 *__restrict__ pos,
+                                                    const double *__restrict__ vx, const double *__restrict__ vy,
+                                                    const double *__restrict__ vz, const int *__restrict__ tag,
+                                                    int *__restrict__ img, double *__restrict__ mig_dn,
+                                                    double *__restrict__ mig_up, int *__restrict__ gone,
+                                                    int *__restrict__ flags) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   bool active = p < n;
   double4 r = pos[active ? p : 0];
   int im[3] = {0, 0, 0};
-  bool keep = false, godn = false, goup = false;
+  bool godn = false, goup = false;
   if (active) {
-    if (!(isfinite(r.x) && isfinite(r.y) && isfinite(r.z))) { flags[FLAG_ERROR] = ERR_NONFINITE; keep = true; }
+    bool bad = !(isfinite(r.x) && isfinite(r.y) && isfinite(r.z));
+    if (bad) flags[FLAG_ERROR] = ERR_NONFINITE;
     double *c = &r.x;
+    bool wrapped = false;
 #pragma unroll
     for (int d = 0; d < 3; d++) {
       double x = c[d];
       int i = img[d * npad + p];
-      if (x < box.lo[d]) { x += box.prd[d]; i--; }
-      if (x >= box.hi[d]) { x -= box.prd[d]; x = fmax(x, box.lo[d]); i++; }
+      if (x < box.lo[d]) { x += box.prd[d]; i--; wrapped = true; }
+      if (x >= box.hi[d]) { x -= box.prd[d]; x = fmax(x, box.lo[d]); i++; wrapped = true; }
       c[d] = x;
       im[d] = i;
     }
-    if (!keep) {
+    if (wrapped) { pos[p] = r; img[p] = im[0]; img[npad + p] = im[1]; img[2 * npad + p] = im[2]; }
+    if (!bad) {
       // owner = slab index from one expression that every rank evaluates identically
       int owner = (int)((r.z - box.lo[2]) / width);
       owner = min(max(owner, 0), P - 1);
-      keep = owner == me;
       double zc = zrel_slab(r.z, slab_lo, box);      // direction of travel for a bead that left
-      godn = !keep && zc < 0.0;
-      goup = !keep && zc >= 0.0;
+      godn = owner != me && zc < 0.0;
+      goup = owner != me && zc >= 0.0;
     }
+    gone[p] = (godn || goup) ? 1 : 0;
   }
-  int sk = wave_append(keep, &flags[FLAG_COUNT_A]);
   int sd = wave_append(godn, &flags[FLAG_COUNT_B]);
   int su = wave_append(goup, &flags[FLAG_NDRAW]);
-  if (keep) {
-    pos_o[sk] = r; vxo[sk] = vx[p]; vyo[sk] = vy[p]; vzo[sk] = vz[p]; tag_o[sk] = tag[p];
-    img_o[sk] = im[0]; img_o[npad + sk] = im[1]; img_o[2 * npad + sk] = im[2];
-  } else if (godn || goup) {
+  if (godn || goup) {
     int slot = godn ? sd : su;
     if (slot >= migcap) return;                    // reported by the host from the counters
     double *b = (godn ? mig_dn : mig_up) + (size_t)slot * MIG_W;
@@ -96,9 +93,11 @@ __global__ __launch_bounds__(BLOCK) void k_dd_migrate(int n, int npad, int migca
 __global__ __launch_bounds__(BLOCK) void k_dd_arrive(int narr, int base, int npad, const double *__restrict__ in,
                                                      double4 *__restrict__ pos, double *__restrict__ vx,
                                                      double *__restrict__ vy, double *__restrict__ vz,
-                                                     int *__restrict__ tag, int *__restrict__ img) {
+                                                     int *__restrict__ tag, int *__restrict__ img,
+                                                     int *__restrict__ gone) {
   int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= narr) return;
+  gone[base + i] = 0;
   const double *b = in + (size_t)i * MIG_W;
   int s = base + i;
   pos[s] = make_double4(b[0], b[1], b[2], b[3]);
@@ -107,15 +106,31 @@ __global__ __launch_bounds__(BLOCK) void k_dd_arrive(int narr, int base, int npa
   img[s] = (int)b[8]; img[npad + s] = (int)b[9]; img[2 * npad + s] = (int)b[10];
 }
 
-// ---- borders: owned beads within cutghost of my lower / upper z face (after the cell sort) are appended to the
-// two send lists (wave-aggregated atomics; the receiver sorts its ghosts by cell and ID, so the list order is free)
+// ---- borders (after the cell sort): the send lists hold (a) every owned bead within the PAIR shell (rc + skin) of
+// my lower / upper z face and (b) beads within the full ghost cutoff (`comm_modify cutoff`, which the reference
+// needs for long extruder bonds) that actually have a bond partner on another rank.  The reference ghosts the
+// whole `comm_modify cutoff` shell (src/comm_brick.cpp:600-720); with cutoff 5.0 and 13-sigma slabs that is 76 %
+// of a slab per step over xGMI, against 23 % here — the forces are the same because only bond partners are ever
+// looked up beyond the pair shell.  Slots: wave-aggregated atomics; the receiver sorts its ghosts by cell and ID,
+// so the list order is free.
 __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__restrict__ pos, Box box, double slab_lo,
-                                                      double width, double cutghost, int *__restrict__ list_dn,
+                                                      double width, double cutpair, double cutghost, int bpa,
+                                                      const int *__restrict__ tag, const int *__restrict__ map,
+                                                      const int *__restrict__ num_bond,
+                                                      const int *__restrict__ bond_atom, int *__restrict__ list_dn,
                                                       int *__restrict__ list_up, int *__restrict__ flags) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   bool active = p < n;
   double zc = active ? zrel_slab(pos[p].z, slab_lo, box) : 0.0;
-  bool dn = active && zc < cutghost, up = active && zc >= width - cutghost;
+  bool dn = active && zc < cutpair, up = active && zc >= width - cutpair;
+  bool far_dn = active && !dn && zc < cutghost, far_up = active && !up && zc >= width - cutghost;
+  if (far_dn || far_up) {
+    int t = tag[p], nb = num_bond[t];
+    bool remote = false;      // map[] holds owned beads only at this point
+    for (int m = 0; m < nb; m++) remote = remote || map[bond_atom[(size_t)t * bpa + m]] < 0;
+    dn = dn || (far_dn && remote);
+    up = up || (far_up && remote);
+  }
   int sd = wave_append(dn, &flags[FLAG_COUNT_A]);
   int su = wave_append(up, &flags[FLAG_COUNT_B]);
   if (dn) list_dn[sd] = p;
@@ -252,6 +267,7 @@ void dd_alloc(DeviceState &d, int world) {
   al(d.sendbuf, np * sizeof(double4));
   al(d.recvbuf, np * sizeof(double4));
   al(d.gdest, np * sizeof(int));
+  al(d.gone, np * sizeof(int));
   al(d.gtag_in, np * sizeof(int));
   (void)world;
 }
@@ -265,22 +281,18 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   const int migcap = (int)(((size_t)d.npad * MIG_W / 4) / MIG_W);
   // counts travel rank-to-rank on the device and reach the host together with this rank's own counters: one
   // host synchronisation per phase (migration, borders) instead of three
+  const unsigned counters = (1u << FLAG_COUNT_A) | (1u << FLAG_COUNT_B) | (1u << FLAG_NDRAW);
   auto swap_counts = [&](int slot_dn, int slot_up) {
     comm.exchange(st, {{d.flags + slot_dn, sizeof(int), dn_rank}, {d.flags + slot_up, sizeof(int), up_rank}},
                   {{d.flags + FLAG_RECV_UP, sizeof(int), up_rank}, {d.flags + FLAG_RECV_DN, sizeof(int), dn_rank}});
-    sync_flags(d);
+    sync_flags(d, counters);     // published, then zeroed for the next phase
   };
   // ---- 1. migration ----
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
-  hipLaunchKernelGGL(k_dd_migrate, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, migcap, d.box, d.slab_lo, width, me, P, d.pos,
-                     d.v[0], d.v[1], d.v[2], d.tag, d.img, d.pos_tmp, d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag_tmp,
-                     d.img_tmp, d.migbuf[0], d.migbuf[1], d.flags);
-  std::swap(d.pos, d.pos_tmp);
-  for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
-  std::swap(d.tag, d.tag_tmp);
-  std::swap(d.img, d.img_tmp);
+  hipLaunchKernelGGL(k_dd_leave, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, migcap, d.box, d.slab_lo, width, me, P, d.pos,
+                     d.v[0], d.v[1], d.v[2], d.tag, d.img, d.migbuf[0], d.migbuf[1], d.gone, d.flags);
   swap_counts(FLAG_COUNT_B, FLAG_NDRAW);      // what I send down arrives as the lower rank's "from above"
-  int nkeep = d.flags_h[FLAG_COUNT_A], ndn = d.flags_h[FLAG_COUNT_B], nup = d.flags_h[FLAG_NDRAW];
+  int ndn = d.flags_h[FLAG_COUNT_B], nup = d.flags_h[FLAG_NDRAW];
   int recvc[2] = {d.flags_h[FLAG_RECV_DN], d.flags_h[FLAG_RECV_UP]};   // [0] from below (their up), [1] from above
   if (ndn > migcap || nup > migcap || recvc[0] + recvc[1] > 2 * migcap)
     throw LammpsError("too many beads migrate between slabs in one reneighbor (down " + std::to_string(ndn) + ", up " +
@@ -291,18 +303,18 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
                 {{d.migin, (size_t)recvc[1] * MIG_W * sizeof(double), up_rank},
                  {d.migin + (size_t)recvc[1] * MIG_W, (size_t)recvc[0] * MIG_W * sizeof(double), dn_rank}});
   int narr = recvc[0] + recvc[1];
-  if (nkeep + narr > d.npad - 64) throw LammpsError("slab overflow: more beads than the allocation of this rank");
+  if (n + narr > d.npad - 64) throw LammpsError("slab overflow: more beads than the allocation of this rank");
   if (narr)
-    hipLaunchKernelGGL(k_dd_arrive, dim3((narr + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, narr, nkeep, d.npad, d.migin,
-                       d.pos, d.v[0], d.v[1], d.v[2], d.tag, d.img);
-  d.n = n = nkeep + narr;
-  nb = std::max(1, (n + BLOCK - 1) / BLOCK);
-  // ---- 2. map reset, cell sort of the owned beads (sets map for them) ----
+    hipLaunchKernelGGL(k_dd_arrive, dim3((narr + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, narr, n, d.npad, d.migin,
+                       d.pos, d.v[0], d.v[1], d.v[2], d.tag, d.img, d.gone);
+  // ---- 2. map reset, cell sort of kept + arrived beads (sets map for them; the gone ones drop off the end) ----
   hipLaunchKernelGGL(k_fill_int, dim3((d.maxtag + 2 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.maxtag + 2, d.map, -1);
-  launch_sort_owned(d);
+  launch_sort_owned(d, n + narr, n + narr - ndn - nup, d.gone);
+  d.n = n = n + narr - ndn - nup;
+  nb = std::max(1, (n + BLOCK - 1) / BLOCK);
   // ---- 3. borders ----
-  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 2 * sizeof(int), st));
-  hipLaunchKernelGGL(k_dd_borders, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width, d.cutghost,
+  hipLaunchKernelGGL(k_dd_borders, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width,
+                     std::min(sqrt(cutneighsq), d.cutghost), d.cutghost, d.bpa, d.tag, d.map, d.num_bond, d.bond_atom,
                      d.sendlist[0], d.sendlist[1], d.flags);
   swap_counts(FLAG_COUNT_A, FLAG_COUNT_B);
   d.nsend[0] = d.flags_h[FLAG_COUNT_A];

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
                                                     Box box, int ncx, int ncy, int ncz, double cix, double ciy,
                                                     double ciz, double zlo_ext, int *__restrict__ cell_of,
                                                     int *__restrict__ cell_count, int *__restrict__ rank,
-                                                    int *__restrict__ flags) {
+                                                    int *__restrict__ flags, const int *__restrict__ gone,
+                                                    int sentinel) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
   double4 r = pos[p];
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
   }
   pos[p] = r;
   int cell = cell_index(r, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
+  // decomposed runs: a bead that has just migrated to another slab is binned into a sentinel cell behind all real
+  // cells, so the sort that follows also compacts the array (no separate keep/scan/scatter pass)
+  if (gone && gone[p]) cell = sentinel;
   cell_of[p] = cell;
   // beads arrive nearly cell-sorted: one returning atomic per run of equal cells inside the wavefront
   const int lane = threadIdx.x & 63;
@@ -362,23 +366,26 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
   atomicMax(&flags[FLAG_MAXNEIGH], cnt);
 }
 
-// phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays
-void launch_sort_owned(DeviceState &d) {
-  int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
-  if (nb == 0) nb = 1;
+// phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
+// Decomposed runs pass m_in = slots to bin (kept + gone + arrived) and `gone`; n_out beads remain afterwards.
+void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
+  if (m_in < 0) m_in = n_out = d.n;
+  int nb = std::max(1, (m_in + BLOCK - 1) / BLOCK);
+  const int nc = d.ncells + (gone ? 1 : 0);     // + sentinel cell
   hipStream_t st = d.stream;
-  HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(d.ncells + 1) * sizeof(int), st));
-  hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.img, d.npad, d.box, d.ncell[0],
+  HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(nc + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, m_in, d.pos, d.img, d.npad, d.box, d.ncell[0],
                      d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of,
-                     d.cell_count, d.tag_tmp, d.flags);
-  int sb = (d.ncells + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, d.ncells, d.cell_count, d.cell_start,
-                     d.scan_tmp);
+                     d.cell_count, d.tag_tmp, d.flags, gone, d.ncells);
+  int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_count, d.cell_start, d.scan_tmp);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sb, d.scan_tmp);
-  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, st, d.ncells, d.cell_start, d.scan_tmp, n);
-  hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, n, d.cell_of, d.cell_start, d.tag_tmp, d.perm);
+  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_start, d.scan_tmp, m_in);
+  hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, m_in, d.cell_of, d.cell_start, d.tag_tmp, d.perm);
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
                      d.cell_start, d.perm, d.tag);
+  const int n = n_out;
+  nb = std::max(1, (n + BLOCK - 1) / BLOCK);
   hipLaunchKernelGGL(k_permute, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.perm, d.pos, d.pos_tmp, d.xhold, d.v[0],
                      d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map, d.posf);
   std::swap(d.pos, d.pos_tmp);
@@ -397,7 +404,6 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   if (has_pair) {
     auto sflag = [](double w) { return w == 0.0 ? 0 : (w == 1.0 ? 1 : 2); };
     int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
-    HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), st));
     double margin = sqrt(cutneighsq) * (1.0 + 1e-12);
     // FP32 test: a float coordinate is off by <= M * 2^-24 (M = largest |coordinate|), a separation component
     // (difference, periodic shift with a float box length) by e_d <= 8 * M * 2^-24, the squared distance of a pair
