@@ -48,7 +48,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   d.ncells = 1;
   for (int k = 0; k < 3; k++) {
     double extent = (k == 2 && d.dd) ? (d.slab_hi - d.slab_lo) + 2.0 * d.cutghost : box.prd[k];
-    d.ncell[k] = cutneigh > 0.0 ? (int)(extent / cutneigh) : 1;
+    d.ncell[k] = cutneigh > 0.0 ? (int)(extent / (k == 0 ? cutneigh / CELL_XSPLIT : cutneigh)) : 1;
     if (d.ncell[k] < 1) d.ncell[k] = 1;
     // keep cells from getting needlessly tiny for bond-only runs
     d.cellinv[k] = d.ncell[k] / extent;

@@ -44,6 +44,11 @@ enum DevErr {
   ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8
 };
 
+// Neighbor cells are cutneigh wide in y and z and cutneigh / CELL_XSPLIT wide in x (the fastest index of the cell
+// order): the 2*CELL_XSPLIT+1 x-cells a bead has to look at are still ONE contiguous index range per (y,z) row, but
+// cover 2.25 instead of 3 cutoffs -> 25 % fewer candidates in the list build.
+constexpr int CELL_XSPLIT = 4;
+
 struct DeviceState {
   hipStream_t stream = nullptr;
   int n = 0;        // owned atoms

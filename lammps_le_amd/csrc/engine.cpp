@@ -159,7 +159,7 @@ void Engine::upload() {
   if (!realloc)
     for (int k = 0; k < 3; k++) {
       double extent = (k == 2 && d.dd) ? (d.slab_hi - d.slab_lo) + 2.0 * d.cutghost : box.prd[k];
-      if ((int)(extent / cellcut) != d.ncell[k]) realloc = true;
+      if ((int)(extent / (k == 0 ? cellcut / CELL_XSPLIT : cellcut)) != d.ncell[k]) realloc = true;
     }
   if (realloc) {
     if (d.pos) dev_free(d);

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
   bool all_in = __all(interior || !active) && !dd;
   if (!active) return;
   int cnt = 0;
-  int x0 = cx - 1, x1 = cx + 1;   // x-cell range, may stick out of [0, ncx)
+  int x0 = cx - CELL_XSPLIT, x1 = cx + CELL_XSPLIT;   // x-cell range (>= cutneigh each way), may stick out of [0, ncx)
   for (int dz = -1; dz <= 1; dz++) {
     int az = cz + dz;
     if (dd) { if (az < 0 || az >= ncz) continue; }            // slab grid: ghosts pad the z direction
@@ -350,13 +350,13 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
     else neigh_range<NOSPECIAL, true, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
                                       sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf);             \
   } while (0)
-      if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + 1]);                      // cell 0 (image of ncx)
+      if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + x1 - ncx + 1]);           // cells 0.. (images of ncx..x1)
       RANGE(cell_start[row + lo], cell_start[row + hi + 1]);
-      if (x0 < 0) RANGE(cell_start[row + ncx - 1], cell_start[row + ncx]);             // cell ncx-1 (image of -1)
+      if (x0 < 0) RANGE(cell_start[row + ncx + x0], cell_start[row + ncx]);            // cells ..ncx-1 (images of x0..-1)
       if (dd) {   // ghost beads of the same cells, stored (cell-sorted) behind the owned beads
-        if (x1 >= ncx) RANGE(n + gcell_start[row], n + gcell_start[row + 1]);
+        if (x1 >= ncx) RANGE(n + gcell_start[row], n + gcell_start[row + x1 - ncx + 1]);
         RANGE(n + gcell_start[row + lo], n + gcell_start[row + hi + 1]);
-        if (x0 < 0) RANGE(n + gcell_start[row + ncx - 1], n + gcell_start[row + ncx]);
+        if (x0 < 0) RANGE(n + gcell_start[row + ncx + x0], n + gcell_start[row + ncx]);
       }
 #undef RANGE
     }
