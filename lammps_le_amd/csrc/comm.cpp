@@ -156,6 +156,18 @@ struct LocalHub {
   std::map<std::pair<int, int>, std::deque<std::shared_ptr<LocalMsg>>> box;   // (src, dst) -> messages in order
 };
 namespace {
+// events are taken from a per-thread ring and never destroyed while the process lives: a waiter captures the record
+// it was enqueued behind, so re-recording an event many exchanges later cannot disturb it, whereas destroying an
+// event another stream may still be waiting on is not something to rely on
+hipEvent_t ring_event() {
+  static thread_local std::vector<hipEvent_t> ring;
+  static thread_local size_t next = 0;
+  if (ring.empty()) {
+    ring.resize(256);
+    for (auto &e : ring) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  return ring[next++ % ring.size()];
+}
 std::mutex hubs_mu;
 std::map<std::string, std::weak_ptr<LocalHub>> hubs;
 std::shared_ptr<LocalHub> hub_for(const std::string &session) {
@@ -172,7 +184,7 @@ void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std:
     auto msg = std::make_shared<LocalMsg>();
     msg->ptr = m.dev; msg->bytes = m.bytes; msg->host = host;
     if (!host && m.bytes) {
-      HIP_CHECK(hipEventCreateWithFlags(&msg->ready, hipEventDisableTiming));
+      msg->ready = ring_event();
       HIP_CHECK(hipEventRecord(msg->ready, st));
     }
     { std::lock_guard<std::mutex> g(h.mu); h.box[{rank, m.peer}].push_back(msg); }
@@ -195,7 +207,7 @@ void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std:
       else {
         HIP_CHECK(hipStreamWaitEvent(st, msg->ready, 0));
         HIP_CHECK(hipMemcpyAsync(m.dev, msg->ptr, m.bytes, hipMemcpyDeviceToDevice, st));
-        HIP_CHECK(hipEventCreateWithFlags(&msg->done, hipEventDisableTiming));
+        msg->done = ring_event();
         HIP_CHECK(hipEventRecord(msg->done, st));
       }
     }
@@ -208,11 +220,8 @@ void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std:
       if (!h.cv.wait_for(lk, std::chrono::seconds(120), [&] { return msg->acked; }))
         throw LammpsError("local transport: timeout waiting for an acknowledgement");
     }
-    if (msg->done) {     // the send buffer may be rewritten only after the receiver's copy has run
-      HIP_CHECK(hipStreamWaitEvent(st, msg->done, 0));
-      (void)hipEventDestroy(msg->done);
-    }
-    if (msg->ready) (void)hipEventDestroy(msg->ready);
+    // the send buffer may be rewritten only after the receiver's copy has run
+    if (msg->done) HIP_CHECK(hipStreamWaitEvent(st, msg->done, 0));
   }
 }
 }  // namespace

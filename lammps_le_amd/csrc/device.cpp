@@ -9,7 +9,10 @@ namespace lmp_le {
 template <class T>
 static void dalloc(T *&p, size_t count) {
   HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+  // null-stream memset + wait: the engine's streams are non-blocking, i.e. NOT ordered behind the null stream, and
+  // a memset that is still pending when the first kernel writes the buffer would wipe that kernel's output
   HIP_CHECK(hipMemset(p, 0, count * sizeof(T)));
+  HIP_CHECK(hipStreamSynchronize(nullptr));
 }
 template <class T>
 static void dfree(T *&p) {

@@ -259,7 +259,12 @@ static void ensure_gather(DeviceState &d, size_t doubles_per_rank, int world) {
 
 void dd_alloc(DeviceState &d, int world) {
   size_t np = d.npad;
-  auto al = [](auto *&p, size_t bytes) { HIP_CHECK(hipMalloc((void **)&p, bytes)); HIP_CHECK(hipMemset(p, 0, bytes)); };
+  auto al = [](auto *&p, size_t bytes) {
+    if (p) (void)hipFree(p);
+    HIP_CHECK(hipMalloc((void **)&p, bytes));
+    HIP_CHECK(hipMemset(p, 0, bytes));
+    HIP_CHECK(hipStreamSynchronize(nullptr));   // see dalloc (device.cpp)
+  };
   al(d.gcell_start, ((size_t)d.ncells + 2) * sizeof(int));
   al(d.gcell_count, ((size_t)d.ncells + 2) * sizeof(int));
   for (int k = 0; k < 2; k++) { al(d.sendlist[k], np * sizeof(int)); al(d.migbuf[k], np * MIG_W * sizeof(double) / 4 + 1024); }

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, 
 // physical indices (the bead's own special list is translated through map[] once), the minimum image is
 // branch-free and skipped by wavefronts that are wholly interior.  Entries come out in (row segment, index)
 // order, which depends only on the sorted positions -> deterministic.
+constexpr int STAGE_CAP = 192;   // float4 slots of one wavefront's staged row interval (2.5 KB)
 constexpr int SPMAX = 4;   // special entries THAT MATTER (weight != 1) translated to indices and kept in registers
 
 // The distance test runs in FP32 on a float4 copy of the positions (half the bytes through the texture-address
@@ -205,7 +206,7 @@ constexpr int SPMAX = 4;   // special entries THAT MATTER (weight != 1) translat
 // band (a fraction ~1e-4 of the candidates) the FP64 test is repeated on the double positions, so the accepted set is
 // exactly the FP64 one.  (A variant that used FP32 only to reject, confirming every survivor in FP64, was slower:
 // some lane of a wavefront survives in almost every iteration, so both paths executed.)
-template <bool NOSPECIAL, bool MINIMG, bool ASYM>
+template <bool NOSPECIAL, bool MINIMG, bool ASYM, bool STAGED>
 __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const float4 *__restrict__ posf,
                                             float cutf, const double4 *__restrict__ pos,
                                             const int *__restrict__ tag, const Box &box, double cutneighsq, int n1,
@@ -213,12 +214,14 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
                                             const int (&spc)[SPMAX], const int *__restrict__ slist,
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
                                             int *__restrict__ neigh, const int *__restrict__ all_nspecial,
-                                            const int *__restrict__ all_special, int ms_, int &cnt, float bandf) {
+                                            const int *__restrict__ all_special, int ms_, int &cnt, float bandf,
+                                            const float4 *stg, int stg_base) {
 #pragma clang fp contract(fast)
   const float rix = (float)ri.x, riy = (float)ri.y, riz = (float)ri.z;
   const float px = (float)box.prd[0], py = (float)box.prd[1], pz = (float)box.prd[2];
   const float ipx = (float)box.iprd[0], ipy = (float)box.iprd[1], ipz = (float)box.iprd[2];
-  auto test = [&](int q, const float4 &rf) {
+  for (int q = b; q < e; q++) {
+    const float4 rf = STAGED ? stg[q - stg_base] : posf[q];
     float dxf = rix - rf.x, dyf = riy - rf.y, dzf = riz - rf.z;
     if (MINIMG) {
       dxf -= px * __builtin_rintf(dxf * ipx);
@@ -238,7 +241,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
       double rsq = delx * delx + dely * dely + delz * delz;
       reject = rsq > cutneighsq;
     }
-    if (reject || q == s) return;
+    if (reject || q == s) continue;
     int entry = q;
     bool own_list = true;
     if (!NOSPECIAL && ASYM) {
@@ -254,7 +257,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
           if (ql[k] == ts) { which = (k < q1) ? 1 : (k < q2) ? 2 : 3; break; }
         if (which) {
           int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
-          if (sf == 0) return;
+          if (sf == 0) continue;
           if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
         }
       }
@@ -274,17 +277,16 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
             break;
           }
       }
-      if (code < 0) return;                        // weight 0.0: excluded from the list
+      if (code < 0) continue;                        // weight 0.0: excluded from the list
       if (code > 0) entry = q | (code << NEIGH_SB_SHIFT);
     }
     if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
     cnt++;
-  };
-  for (int q = b; q < e; q++) test(q, posf[q]);
+  }
 }
 
 template <bool NOSPECIAL, bool ASYM>
-__global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+__device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
                                                        const float4 *__restrict__ posf, float cutf, float bandf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
                                                        const int *__restrict__ cell_start,
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
                                                        const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
-                                                       int *__restrict__ flags) {
+                                                       int *__restrict__ flags, int diag) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
   double4 ri = pos[active ? s : 0];
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
   int spi[SPMAX], spc[SPMAX];
 #pragma unroll
   for (int k = 0; k < SPMAX; k++) { spi[k] = -1; spc[k] = 0; }
-  if (!NOSPECIAL && active) {
+  if (!NOSPECIAL && active && !(diag & 4)) {
     int t = tag[s];
     n1 = nspecial[3 * (size_t)t]; n2 = nspecial[3 * (size_t)t + 1];
     int n3 = nspecial[3 * (size_t)t + 2];
@@ -331,39 +333,144 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
   bool interior = ri.x > box.lo[0] + margin && ri.x < box.hi[0] - margin && ri.y > box.lo[1] + margin &&
                   ri.y < box.hi[1] - margin && ri.z > box.lo[2] + margin && ri.z < box.hi[2] - margin;
   bool all_in = __all(interior || !active) && !dd;
-  if (!active) return;
+  // Row-segment staging.  The 64 beads of a wavefront are consecutive in cell order, so for one (dy,dz) offset
+  // their candidate ranges are overlapping windows of ONE short index interval [B,E) (~64 + one window).  The
+  // wavefront copies that interval's float4 positions into LDS with coalesced loads and every lane then walks its
+  // own window in LDS.  Left to per-lane global loads, the same lines are requested by many lanes and wavefronts
+  // while still in flight: the vector L1 spent 58 % of the kernel in pending-hit stalls (TCP_PENDING_STALL_CYCLES)
+  // and the data-return path was 83 % busy.  Wrapped pieces at the row ends, ghost ranges of decomposed runs and
+  // intervals longer than STAGE_CAP take the direct path.
+  __shared__ float4 s_stage[BLOCK / 64][STAGE_CAP];
+  const int lane = threadIdx.x & 63;
+  float4 *stg = s_stage[threadIdx.x >> 6];
+  const unsigned long long actmask = __ballot(active);
+  if (actmask == 0ull) return;
+  if (diag & 8) { if (active) numneigh[s] = 0; return; }                       // lanes past the end of an otherwise live wavefront stay as helpers
+  const int last = 63 - __clzll((long long)actmask);
   int cnt = 0;
+  const int maxneigh_w = (diag & 1) ? 0 : maxneigh;   // diagnostics: bit 0 = no entry stores, bit 1 = no candidate loops
   int x0 = cx - CELL_XSPLIT, x1 = cx + CELL_XSPLIT;   // x-cell range (>= cutneigh each way), may stick out of [0, ncx)
-  for (int dz = -1; dz <= 1; dz++) {
-    int az = cz + dz;
-    if (dd) { if (az < 0 || az >= ncz) continue; }            // slab grid: ghosts pad the z direction
-    else { if (az < 0) az += ncz; else if (az >= ncz) az -= ncz; }
-    for (int dy = -1; dy <= 1; dy++) {
-      int ay = cy + dy; if (ay < 0) ay += ncy; else if (ay >= ncy) ay -= ncy;
-      int row = (az * ncy + ay) * ncx;
-      // up to three pieces: wrapped low part, main part, wrapped high part (in increasing cell order)
-      int lo = max(x0, 0), hi = min(x1, ncx - 1);
-#define RANGE(B, E)                                                                                              \
+#define RANGE_T(B, E, STG, SB)                                                                                    \
   do {                                                                                                            \
-    if (all_in) neigh_range<NOSPECIAL, false, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, \
-                                              sf1, sf2, sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf);        \
-    else neigh_range<NOSPECIAL, true, ASYM>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
-                                      sf3, npad, maxneigh, neigh, nspecial, special, ms, cnt, bandf);             \
+    if (all_in) neigh_range<NOSPECIAL, false, ASYM, STG>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, \
+                                              sf1, sf2, sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
+    else neigh_range<NOSPECIAL, true, ASYM, STG>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
+                                      sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
   } while (0)
+#define RANGE(B, E) RANGE_T(B, E, false, 0)
+  // Pass A: the main index range of all nine (dz,dy) rows, 18 independent loads issued together (the rolled loop
+  // below would otherwise expose one load round trip per row, and a second one for the staging copy).
+  __shared__ int s_rng[2][9][BLOCK];
+  const int lo = max(x0, 0), hi = min(x1, ncx - 1);
+  auto row_of = [&](int r, bool &zskip) {
+    int az = cz + (r / 3 - 1), ay = cy + (r % 3 - 1);
+    zskip = false;
+    if (dd) zskip = az < 0 || az >= ncz;                      // slab grid: ghosts pad the z direction
+    else { if (az < 0) az += ncz; else if (az >= ncz) az -= ncz; }
+    az = min(max(az, 0), ncz - 1);
+    if (ay < 0) ay += ncy; else if (ay >= ncy) ay -= ncy;
+    return (az * ncy + ay) * ncx;
+  };
+  {
+    int vb[9], ve[9];
+#pragma unroll
+    for (int r = 0; r < 9; r++) {
+      bool zskip;
+      const int row = row_of(r, zskip);
+      const bool live = active && !zskip;
+      vb[r] = live ? cell_start[row + lo] : 0;
+      ve[r] = live ? cell_start[row + hi + 1] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 9; r++) { s_rng[0][r][threadIdx.x] = vb[r]; s_rng[1][r][threadIdx.x] = ve[r]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (diag & 16) { if (active) numneigh[s] = s_rng[0][4][threadIdx.x] & 1; return; }
+  // Pass B: row r is processed from LDS while the staging loads of row r+1 are in flight
+  auto interval = [&](int r, int &mb, int &me, int &B, int &E, bool &fits) {
+    mb = s_rng[0][r][threadIdx.x]; me = s_rng[1][r][threadIdx.x];
+    // interval of the wavefront: ranges grow with the lane index, so [first lane's begin, last lane's end)
+    B = __shfl(mb, 0, 64); E = __shfl(me, last, 64);
+    fits = !dd && E - B <= STAGE_CAP && __all(me <= mb || (mb >= B && me <= E));
+  };
+  int mb, me, B, E;
+  bool fits;
+  interval(0, mb, me, B, E, fits);
+  float4 t0, t1, t2;
+  {
+    const int lm = min(max(E - B - 1, 0), npad - 1 - B);      // (an interval that does not fit is not staged: stay in bounds)
+    t0 = posf[B + min(lane, lm)]; t1 = posf[B + min(lane + 64, lm)]; t2 = posf[B + min(lane + 128, lm)];
+  }
+  for (int r = 0; r < 9; r++) {
+    bool zskip;
+    const int row = row_of(r, zskip);
+    const bool live = active && !zskip && !(diag & 2);   // diag bit 1: ranges and staging stay, candidate loops go
+    if (fits && !(diag & 128)) {
+      const int len = E - B;
+      if (lane < len) stg[lane] = t0;
+      if (lane + 64 < len) stg[lane + 64] = t1;
+      if (lane + 128 < len) stg[lane + 128] = t2;
+    }
+    const int cmb = mb, cme = me, cB = B;
+    const bool cfits = fits;
+    if (r + 1 < 9) {   // next row: its interval is known (pass A), issue its loads now
+      interval(r + 1, mb, me, B, E, fits);
+      const int lm = min(max(E - B - 1, 0), npad - 1 - B);
+      if (!(diag & 64)) { t0 = posf[B + min(lane, lm)]; t1 = posf[B + min(lane + 64, lm)]; t2 = posf[B + min(lane + 128, lm)]; }
+    }
+    __builtin_amdgcn_wave_barrier();                       // LDS ops of one wavefront execute in order
+    if (cfits) { if (live) RANGE_T(cmb, cme, true, cB); }
+    else if (live) RANGE(cmb, cme);
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
       if (x1 >= ncx) RANGE(cell_start[row], cell_start[row + x1 - ncx + 1]);           // cells 0.. (images of ncx..x1)
-      RANGE(cell_start[row + lo], cell_start[row + hi + 1]);
       if (x0 < 0) RANGE(cell_start[row + ncx + x0], cell_start[row + ncx]);            // cells ..ncx-1 (images of x0..-1)
       if (dd) {   // ghost beads of the same cells, stored (cell-sorted) behind the owned beads
         if (x1 >= ncx) RANGE(n + gcell_start[row], n + gcell_start[row + x1 - ncx + 1]);
         RANGE(n + gcell_start[row + lo], n + gcell_start[row + hi + 1]);
         if (x0 < 0) RANGE(n + gcell_start[row + ncx + x0], n + gcell_start[row + ncx]);
       }
-#undef RANGE
     }
   }
+#undef RANGE
+#undef RANGE_T
+  if (!active) return;
   numneigh[s] = min(cnt, maxneigh);
-  if (cnt > maxneigh) flags[FLAG_NEIGH_OVERFLOW] = 1;
-  atomicMax(&flags[FLAG_MAXNEIGH], cnt);
+  // The longest list is only needed when a list did not fit (the host then grows the table to it).  Recording it
+  // unconditionally - one atomicMax per wavefront on ONE address - serialises 15.6k read-modify-writes in a single
+  // L2 channel: 170 us of a 255 us kernel at 1M beads.
+  if (cnt > maxneigh) { flags[FLAG_NEIGH_OVERFLOW] = 1; atomicMax(&flags[FLAG_MAXNEIGH], cnt); }
+}
+
+template <bool NOSPECIAL, bool ASYM>
+__global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+                                                       const float4 *__restrict__ posf, float cutf, float bandf,
+                                                       const int *__restrict__ tag, const int *__restrict__ map,
+                                                       const int *__restrict__ cell_start,
+                                                       const int *__restrict__ gcell_start, int dd, double zlo_ext,
+                                                       int ncx, int ncy, int ncz, double cix, double ciy, double ciz,
+                                                       Box box, double cutneighsq, double margin,
+                                                       const int *__restrict__ nspecial,
+                                                       const int *__restrict__ special, int ms, int sf1, int sf2,
+                                                       int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
+                                                       int *__restrict__ flags, int diag) {
+  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag);
+}
+// same body under a second name: LAMMPS_LE_DIAG_BUILD re-runs the build into scratch outputs with parts switched
+// off, so that a profile of a physically unchanged run shows what each part costs
+template <bool NOSPECIAL, bool ASYM>
+__global__ __launch_bounds__(BLOCK) void k_build_neigh_diag(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+                                                       const float4 *__restrict__ posf, float cutf, float bandf,
+                                                       const int *__restrict__ tag, const int *__restrict__ map,
+                                                       const int *__restrict__ cell_start,
+                                                       const int *__restrict__ gcell_start, int dd, double zlo_ext,
+                                                       int ncx, int ncy, int ncz, double cix, double ciy, double ciz,
+                                                       Box box, double cutneighsq, double margin,
+                                                       const int *__restrict__ nspecial,
+                                                       const int *__restrict__ special, int ms, int sf1, int sf2,
+                                                       int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
+                                                       int *__restrict__ flags, int diag) {
+  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag);
 }
 
 // phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
@@ -418,11 +525,17 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
-                     sf2, sf3, d.neigh, d.numneigh, d.flags)
+                     sf2, sf3, d.neigh, d.numneigh, d.flags, 0)
     if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
     else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
     else BUILD(false, false);
 #undef BUILD
+    if (const char *dg = getenv("LAMMPS_LE_DIAG_BUILD")) {   // diagnostics: extra launch, entry stores off, scratch counters
+      hipLaunchKernelGGL((k_build_neigh_diag<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
+                         d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],
+                         d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,
+                         sf2, sf3, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
+    }
   }
 }
 
