@@ -220,6 +220,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
   const float rix = (float)ri.x, riy = (float)ri.y, riz = (float)ri.z;
   const float px = (float)box.prd[0], py = (float)box.prd[1], pz = (float)box.prd[2];
   const float ipx = (float)box.iprd[0], ipy = (float)box.iprd[1], ipz = (float)box.iprd[2];
+  const float cut_hi = cutf + bandf, cut_lo = cutf - bandf;
   for (int q = b; q < e; q++) {
     const float4 rf = STAGED ? stg[q - stg_base] : posf[q];
     float dxf = rix - rf.x, dyf = riy - rf.y, dzf = riz - rf.z;
@@ -229,8 +230,9 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
       dzf -= pz * __builtin_rintf(dzf * ipz);
     }
     float rsqf = dxf * dxf + dyf * dyf + dzf * dzf;
-    bool reject = rsqf > cutf;
-    if (__builtin_fabsf(rsqf - cutf) <= bandf) {
+    if (rsqf > cut_hi) continue;                // the common case costs one compare
+    bool reject = false;
+    if (rsqf >= cut_lo) {                       // inside the FP32 error band: repeat the test in FP64
       double4 rj = pos[q];
       double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
       if (MINIMG) {
