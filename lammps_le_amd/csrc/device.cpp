@@ -2,7 +2,10 @@
 #include "device.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 namespace lmp_le {
 
@@ -70,8 +73,9 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.partial, (size_t)d.nred_blocks * 16);
   HIP_CHECK(hipHostMalloc((void **)&d.partial_h, (size_t)d.nred_blocks * 16 * sizeof(double)));
   dalloc(d.flags, NFLAGS);
-  HIP_CHECK(hipHostMalloc((void **)&d.flags_h, NFLAGS * sizeof(int), hipHostMallocMapped));
-  for (int k = 0; k < NFLAGS; k++) d.flags_h[k] = 0;
+  HIP_CHECK(hipHostMalloc((void **)&d.flags_h, (NFLAGS + 16) * sizeof(int), hipHostMallocMapped));
+  for (int k = 0; k < NFLAGS + 16; k++) d.flags_h[k] = 0;
+  d.flags_seq = 0;
   HIP_CHECK(hipHostGetDevicePointer((void **)&d.flags_h_dev, d.flags_h, 0));
   // LE fix scratch
   dalloc(d.xt, nt);
@@ -122,15 +126,30 @@ void dev_free(DeviceState &d) {
 // ~18 us on this stack, a kernel + sync ~5 us)
 // `reset` = bit mask of flags that are zeroed right after they were published (saves one memset launch per flag
 // and phase: the consumer of a flag is always the host, which reads the published copy)
-__global__ void k_publish_flags(int *__restrict__ flags, int *__restrict__ host, unsigned reset) {
+// The host does not call hipStreamSynchronize for these hand-overs (its wake-up costs 30-50 us, twice per rebuild):
+// the kernel writes a sequence number behind the flags and the host spins on the mapped page.
+__global__ void k_publish_flags(int *__restrict__ flags, int *__restrict__ host, unsigned reset, int seq) {
   if (threadIdx.x < NFLAGS) {
     host[threadIdx.x] = flags[threadIdx.x];
     if ((reset >> threadIdx.x) & 1u) flags[threadIdx.x] = 0;
   }
   __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) { host[NFLAGS] = seq; __threadfence_system(); }
 }
 void sync_flags(DeviceState &d, unsigned reset) {
-  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, d.stream, d.flags, d.flags_h_dev, reset);
+  const int seq = ++d.flags_seq;
+  hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, d.stream, d.flags, d.flags_h_dev, reset, seq);
+  static const bool spin = !getenv("LAMMPS_LE_NO_SPIN");
+  if (spin) {
+    volatile int *h = d.flags_h;
+    auto t0 = std::chrono::steady_clock::now();
+    long it = 0;
+    while (h[NFLAGS] != seq) {
+      if ((++it & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;   // long-running
+    }                                                                            // work (or a fault): block instead
+    if (h[NFLAGS] == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+  }
   HIP_CHECK(hipStreamSynchronize(d.stream));
 }
 
