@@ -309,9 +309,10 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
                                                  double *__restrict__ fy, double *__restrict__ fz,
                                                  double *__restrict__ partial, int *__restrict__ flags) {
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
-  if (HAS_PAIR)
+  if (HAS_PAIR && !(A.uniform && !A.has_sb)) {   // one coefficient set and no fractional special weights: scalars, no table
     for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
-  __syncthreads();
+    __syncthreads();
+  }
   int lb = logical_block(A.nblocks);
   int p = lb * BLOCK + threadIdx.x;
   double e[14];
@@ -341,9 +342,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
                                                 const double4 *__restrict__ xhold, double dtv, double triggersq,
                                                 int check, int *__restrict__ flags) {
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
-  if (HAS_PAIR)
+  if (HAS_PAIR && !(A.uniform && !A.has_sb)) {   // one coefficient set and no fractional special weights: scalars, no table
     for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
-  __syncthreads();
+    __syncthreads();
+  }
   int lb = logical_block(A.nblocks);
   int p = lb * BLOCK + threadIdx.x;
   if (lb >= A.nblocks || p >= A.n) return;
