@@ -136,6 +136,13 @@ struct DeviceState {
   int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
   double4 *sendbuf = nullptr, *recvbuf = nullptr;       // halo staging
   int *gone = nullptr;                                  // [npad] 1 = this bead has just left for another slab
+  // halo / compute overlap: beads that are sent to a neighbour or read a ghost form phase 1 of a step, the rest
+  // (phase 0) is computed while the ghost positions of the next step travel on comm_stream
+  unsigned char *phase = nullptr;                       // [npad]
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_phase1 = nullptr, ev_halo = nullptr;
+  bool halo_inflight = false;                           // ev_halo guards ghost slots that comm_stream is filling
+  bool halo_ahead = false;                              // ghosts of the coming step were already exchanged
   int *gdest = nullptr;                                 // arrival order -> sorted ghost slot
   int *gtag_in = nullptr;                               // ghost tags in arrival order
   double *migbuf[2] = {nullptr, nullptr}, *migin = nullptr;   // migrating beads (MIG_W doubles each)
@@ -158,7 +165,7 @@ void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, 
 void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4], bool eflag, bool has_pair);
 void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start = nullptr,
-                 hipEvent_t ev_stop = nullptr);
+                 hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true);
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt);
 void launch_ke(DeviceState &d, const TypeTables &tt);

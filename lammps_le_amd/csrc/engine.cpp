@@ -13,6 +13,8 @@ namespace lmp_le {
 
 void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair);
 void dd_halo(DeviceState &d, Comm &comm);
+void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, double4 *dst);
+void dd_halo_wait(DeviceState &d);
 void dd_gather_positions(DeviceState &d, Comm &comm);
 void dd_gather_all(DeviceState &d, Comm &comm, std::vector<double> &rows, int &stride);
 
@@ -58,7 +60,12 @@ void Engine::comm_init(const std::string &backend, int rank_, int world_, const 
   rank = rank_; world = world_;
   if (rank != 0) screen = nullptr;
 }
-void Engine::halo_exchange() { if (world > 1) dd_halo(*dev, *comm); }
+void Engine::halo_exchange() {
+  if (world <= 1) return;
+  dd_halo_wait(*dev);
+  if (dev->halo_ahead) { dev->halo_ahead = false; return; }   // already exchanged behind phase 1 of the previous step
+  dd_halo(*dev, *comm);
+}
 
 void Engine::say(const std::string &s) {
   if (screen) { fputs(s.c_str(), screen); fflush(screen); }
@@ -397,7 +404,7 @@ bool Engine::decide() {
   ago++;
   if (ago >= neigh_delay && ago % neigh_every == 0) {
     if (!neigh_check) return true;
-    if (world > 1) comm->allreduce_int_max(dev->stream, dev->flags, 2);   // FLAG_MOVED, FLAG_ERROR (neighbor.cpp:2011)
+    if (world > 1) { dd_halo_wait(*dev); comm->allreduce_int_max(dev->stream, dev->flags, 2); }   // FLAG_MOVED, FLAG_ERROR (neighbor.cpp:2011)
     sync_flags(*dev);
     check_device_error(this, *dev);
     bool moved = dev->flags_h[FLAG_MOVED] != 0;
@@ -635,6 +642,7 @@ void Engine::iterate(long nsteps) {
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
   bool ident = (sortfreq == 0);
   bool pre_integrated = false;
+  const bool overlap = getenv("LAMMPS_LE_OVERLAP") != nullptr && atoi(getenv("LAMMPS_LE_OVERLAP")) != 0;
   for (long it = 0; it < nsteps; it++) {
     ntimestep++;
     bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
@@ -653,12 +661,32 @@ void Engine::iterate(long nsteps) {
       bool check_next = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
       if (lg) langevin_draws(this, lg);
       bool timed = timed_begin(this);
-      launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
-                  timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr);
+      // opt-in (LAMMPS_LE_OVERLAP=1): parity-tested on one GPU with the in-process and mailbox transports, but the
+      // RCCL path on a second stream has not run on multi-GPU hardware yet, so the default keeps every
+      // collective on the one engine stream
+      if (d.dd) dd_halo_wait(d);               // this step's forces read the ghost slots
+      if (d.dd && next && overlap) {
+        // phase 1 = beads that are sent to a neighbour or read a ghost; their new positions start travelling on
+        // comm_stream (ghost slots of the NEXT step) while phase 0 - the interior - is still being computed
+        launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next, nullptr,
+                    nullptr, 1, false);
+        HIP_CHECK(hipEventRecord(d.ev_phase1, d.stream));
+        launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
+                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, 0, false);
+        HIP_CHECK(hipStreamWaitEvent(d.comm_stream, d.ev_phase1, 0));
+        dd_halo(d, *comm, d.comm_stream, d.pos_tmp, d.pos_tmp);
+        HIP_CHECK(hipEventRecord(d.ev_halo, d.comm_stream));
+        d.halo_inflight = true;
+        d.halo_ahead = true;
+        std::swap(d.pos, d.pos_tmp);
+      } else
+        launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
+                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr);
       if (timed) d.ev_used++;
       if (lg) rng_langevin_consumed(d);
       pre_integrated = next;
     } else {
+      if (d.dd) dd_halo_wait(d);
       compute_forces(eflag);
       if (lg) langevin_post_force(this, lg, nnve == 1);
       if (!(lg && nnve == 1))

@@ -19,6 +19,7 @@ constexpr int MIG_W = 12;    // doubles per migrating bead: x y z type vx vy vz 
 constexpr int GATH_W = 14;   // doubles per bead in whole-system gathers: tag x y z type vx vy vz fx fy fz ix iy iz
 
 void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);   // kernels_le.hip
+void dd_halo_wait(DeviceState &d);
 
 // signed z offset from the bottom of my slab, wrapped to [-Lz/2, Lz/2)
 __device__ __forceinline__ double zrel_slab(double z, double slab_lo, const Box &box) {
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
                                                       const int *__restrict__ tag, const int *__restrict__ map,
                                                       const int *__restrict__ num_bond,
                                                       const int *__restrict__ bond_atom, int *__restrict__ list_dn,
-                                                      int *__restrict__ list_up, int *__restrict__ flags) {
+                                                      int *__restrict__ list_up, int *__restrict__ flags,
+                                                      unsigned char *__restrict__ phase) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   bool active = p < n;
   double zc = active ? zrel_slab(pos[p].z, slab_lo, box) : 0.0;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
   int su = wave_append(up, &flags[FLAG_COUNT_B]);
   if (dn) list_dn[sd] = p;
   if (up) list_up[su] = p;
+  if (active) phase[p] = (dn || up) ? 1 : 0;   // sent beads are phase 1; the list kernels add the beads that read ghosts
 }
 // halo pack of both send lists in one launch (also used for the initial border exchange together with the tags)
 __global__ __launch_bounds__(BLOCK) void k_dd_pack(int m0, int m1, const int *__restrict__ list0,
@@ -273,6 +276,12 @@ void dd_alloc(DeviceState &d, int world) {
   al(d.recvbuf, np * sizeof(double4));
   al(d.gdest, np * sizeof(int));
   al(d.gone, np * sizeof(int));
+  al(d.phase, np);
+  if (!d.comm_stream) {
+    HIP_CHECK(hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&d.ev_phase1, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&d.ev_halo, hipEventDisableTiming));
+  }
   al(d.gtag_in, np * sizeof(int));
   (void)world;
 }
@@ -280,6 +289,8 @@ void dd_alloc(DeviceState &d, int world) {
 // Rebuild ownership and ghosts on this rank, then sort and build lists.  Collective over all ranks.
 void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair) {
   hipStream_t st = d.stream;
+  dd_halo_wait(d);
+  d.halo_ahead = false;
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
   const double width = d.box.prd[2] / P;   // the SAME expression on every rank and in Engine::upload (owner of a bead)
   int n = d.n, nb = std::max(1, (n + BLOCK - 1) / BLOCK);
@@ -320,7 +331,7 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   // ---- 3. borders ----
   hipLaunchKernelGGL(k_dd_borders, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width,
                      std::min(sqrt(cutneighsq), d.cutghost), d.cutghost, d.bpa, d.tag, d.map, d.num_bond, d.bond_atom,
-                     d.sendlist[0], d.sendlist[1], d.flags);
+                     d.sendlist[0], d.sendlist[1], d.flags, d.phase);
   swap_counts(FLAG_COUNT_A, FLAG_COUNT_B);
   d.nsend[0] = d.flags_h[FLAG_COUNT_A];
   d.nsend[1] = d.flags_h[FLAG_COUNT_B];
@@ -365,25 +376,33 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   launch_lists(d, cutneighsq, sl, has_pair);
 }
 
-// per-step forward communication of ghost positions (CommBrick::forward_comm, src/comm_brick.cpp:452-512)
-void dd_halo(DeviceState &d, Comm &comm) {
-  hipStream_t st = d.stream;
+// per-step forward communication of ghost positions (CommBrick::forward_comm, src/comm_brick.cpp:452-512): owned
+// border beads of `src` are packed, exchanged and scattered into the ghost slots of `dst`, all on stream `st`.
+void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, double4 *dst) {
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
   int nsall = d.nsend[0] + d.nsend[1];
   if (nsall)
     hipLaunchKernelGGL(k_dd_pack, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
-                       d.sendlist[0], d.sendlist[1], d.pos, d.sendbuf);
+                       d.sendlist[0], d.sendlist[1], src, d.sendbuf);
   comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
                      {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank}},
                 {{d.recvbuf, (size_t)d.nrecv[1] * sizeof(double4), up_rank},
                  {d.recvbuf + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(double4), dn_rank}});
   if (d.nghost)
     hipLaunchKernelGGL(k_dd_unpack, dim3((d.nghost + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nghost, d.n, d.gdest,
-                       d.recvbuf, d.pos);
+                       d.recvbuf, dst);
+}
+void dd_halo(DeviceState &d, Comm &comm) { dd_halo(d, comm, d.stream, d.pos, d.pos); }
+// the main stream may not touch ghost slots, send/receive buffers or the communicator while comm_stream works
+void dd_halo_wait(DeviceState &d) {
+  if (!d.halo_inflight) return;
+  HIP_CHECK(hipStreamWaitEvent(d.stream, d.ev_halo, 0));
+  d.halo_inflight = false;
 }
 
 // every rank receives (tag, x, xhold) of all beads: xt / xht by tag for the replicated LE kernels
 void dd_gather_positions(DeviceState &d, Comm &comm) {
+  dd_halo_wait(d);
   long maxn = comm.allreduce_host_max(d.n);
   int stride = (int)maxn;
   ensure_gather(d, (size_t)stride * GATH_W, comm.world);
@@ -397,6 +416,7 @@ void dd_gather_positions(DeviceState &d, Comm &comm) {
 
 // host download of the whole system: rows of GATH_W doubles for every bead of every rank
 void dd_gather_all(DeviceState &d, Comm &comm, std::vector<double> &rows, int &stride_out) {
+  dd_halo_wait(d);
   long maxn = comm.allreduce_host_max(d.n);
   int stride = (int)maxn;
   ensure_gather(d, (size_t)stride * GATH_W, comm.world);

@@ -340,7 +340,8 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
                                                 double *__restrict__ fx, double *__restrict__ fy,
                                                 double *__restrict__ fz, double4 *__restrict__ pos_next,
                                                 const double4 *__restrict__ xhold, double dtv, double triggersq,
-                                                int check, int *__restrict__ flags) {
+                                                int check, int *__restrict__ flags,
+                                                const unsigned char *__restrict__ phase, int which) {
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
   if (HAS_PAIR && !(A.uniform && !A.has_sb)) {   // one coefficient set and no fractional special weights: scalars, no table
     for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
   int lb = logical_block(A.nblocks);
   int p = lb * BLOCK + threadIdx.x;
   if (lb >= A.nblocks || p >= A.n) return;
+  if (which >= 0 && phase[p] != which) return;     // decomposed runs: this launch handles one phase of the step
   double4 ri = A.pos[p];
   // streaming operands first: their latency overlaps the neighbor loop
   double a = vx[p], b = vy[p], c = vz[p];
@@ -442,7 +444,7 @@ void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool 
 // fused force + Langevin + final_integrate [+ next initial_integrate]; swaps the position buffers when `next`
 void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
-                 hipEvent_t ev_stop) {
+                 hipEvent_t ev_stop, int which, bool swap_buffers) {
   ForceArgs A = force_args(d, sl);
   int grid = xcd_grid(A.nblocks);
   // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
@@ -450,7 +452,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 #define STP(L, N, I, P)                                                                                      \
   hipExtLaunchKernelGGL((k_step<L, N, I, P>), dim3(grid), dim3(BLOCK), 0, d.stream, ev_start, ev_stop, 0, A, bt, \
                         d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],    \
-                        d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags)
+                        d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which)
   int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
   switch (key) {
     case 0: STP(false, false, false, false); break;  case 1: STP(false, false, false, true); break;
@@ -463,7 +465,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
     case 14: STP(true, true, true, false); break;    case 15: STP(true, true, true, true); break;
   }
 #undef STP
-  if (next) std::swap(d.pos, d.pos_tmp);
+  if (next && swap_buffers) std::swap(d.pos, d.pos_tmp);
 }
 
 // sum the per-block partials on the host in block order (deterministic)

@@ -121,9 +121,12 @@ def test_le_fixes_across_slabs(tmp_path):
     assert len([b for b in o.bond_set() if b[0] == 2]) > 20
 
 
-@pytest.mark.parametrize("world,n", [(2, 6000), (4, 40000), (5, 40000)])
-def test_md_across_slabs_in_process(tmp_path, world, n):
-    """4 and 5 slabs (interior ranks with two different neighbours) over the in-process transport."""
+@pytest.mark.parametrize("world,n,overlap", [(2, 6000, 0), (4, 40000, 0), (5, 40000, 1), (2, 6000, 1), (3, 40000, 1)])
+def test_md_across_slabs_in_process(tmp_path, world, n, overlap, monkeypatch):
+    """4 and 5 slabs (interior ranks with two different neighbours) over the in-process transport; overlap=1 also
+    splits every step into the beads that touch ghosts and the interior, with the halo exchange of the next step
+    travelling on a second stream behind the first part (LAMMPS_LE_OVERLAP)."""
+    monkeypatch.setenv("LAMMPS_LE_OVERLAP", str(overlap))
     s = lattice_chain(n, nchains=2, seed=23)
     script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
         "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 30\nrun 60\n"
@@ -137,7 +140,9 @@ def test_md_across_slabs_in_process(tmp_path, world, n):
     assert r["builds"][0] == o.neigh_builds()
 
 
-def test_le_fixes_across_three_slabs_in_process(tmp_path):
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_le_fixes_across_three_slabs_in_process(tmp_path, overlap, monkeypatch):
+    monkeypatch.setenv("LAMMPS_LE_OVERLAP", str(overlap))
     n = 60000      # slab width 13.8 >= two ghost shells of 6.2
     s = melted(n, nchains=3, seed=9, types=barrier_types(n, 17))
     base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 6.2") \
