@@ -137,7 +137,9 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
   int su = wave_append(up, &flags[FLAG_COUNT_B]);
   if (dn) list_dn[sd] = p;
   if (up) list_up[su] = p;
-  if (active) phase[p] = (dn || up) ? 1 : 0;   // sent beads are phase 1; the list kernels add the beads that read ghosts
+  // sent beads are phase 1: a bead with a ghost NEIGHBOR lies within the pair shell of a face and is therefore sent;
+  // the bond-table kernel adds the few beads whose bond partner is a ghost
+  if (active) phase[p] = (dn || up) ? 1 : 0;
 }
 // halo pack of both send lists in one launch (also used for the initial border exchange together with the tags)
 __global__ __launch_bounds__(BLOCK) void k_dd_pack(int m0, int m1, const int *__restrict__ list0,

@@ -152,6 +152,7 @@ struct ForceArgs {
   int has_sb;            // some special weight is neither 0 nor 1 -> list entries carry special bits
   double margin;         // beads farther than this from every box face need no minimum image
   int nn_limit;          // diagnostics only (LAMMPS_LE_NN_LIMIT): cap on neighbors visited per bead
+  int diag;              // diagnostics only (LAMMPS_LE_DIAG_STEP): extra launch with parts off, see launch_step
 };
 
 // one pair term.  The hot loop is written for issue-bound FP64 on CDNA4: branch-free minimum image
@@ -205,7 +206,7 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
                                           const double4 &ri, double &fxi, double &fyi, double &fzi,
                                           double (&e)[14]) {
   const int itype = (int)ri.w, npad = A.npad;
-  const int nn = min(A.numneigh[p], A.nn_limit);
+  const int nn = (A.diag & 2) ? 0 : min(A.numneigh[p], A.nn_limit);
   const int *col = A.neigh + p;
   // software pipeline, 4 neighbors per stage: while the four position gathers of the current stage are in
   // flight the (coalesced) index loads of the next stage are issued, so a stage costs one exposed round trip.
@@ -253,7 +254,7 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
       pair_loop<EFLAG, true, false, true>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
     }
   }
-  for (int m = 0; m < A.bpa; m++) {
+  for (int m = 0; m < ((A.diag & 1) ? 0 : A.bpa); m++) {
     int eb = A.bpart[(size_t)m * npad + p];
     if (eb < 0) continue;
     int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
   // streaming operands first: their latency overlaps the neighbor loop
   double a = vx[p], b = vy[p], c = vz[p];
   uint32_t d0 = 0, d1 = 0, d2 = 0;
-  if (LANGEVIN) {
+  if (LANGEVIN && !(A.diag & 4)) {
     int t = tag[p];
     int rank = IDENT ? (t - 1) : crank[t];
     d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
@@ -385,11 +386,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
     if (check) {
       double4 h = xhold[p];
       double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
-      if (dx * dx + dy * dy + dz * dz > triggersq) flags[FLAG_MOVED] = 1;
+      if (dx * dx + dy * dy + dz * dz > triggersq && !A.diag) flags[FLAG_MOVED] = 1;
     }
   } else {
     fx[p] = f0; fy[p] = f1; fz[p] = f2;
   }
+  if (A.diag & 64) { if (a == 1.2345e300) vx[p] = a; return; }   // diagnostic launch: v is left alone (the value is still computed)
   vx[p] = a; vy[p] = b; vz[p] = c;
 }
 
@@ -429,6 +431,7 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.margin = d.cutneigh;
   static int lim = getenv("LAMMPS_LE_NN_LIMIT") ? atoi(getenv("LAMMPS_LE_NN_LIMIT")) : (1 << 30);
   A.nn_limit = lim;
+  A.diag = 0;
   return A;
 }
 void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool eflag, bool has_pair) {
@@ -454,6 +457,18 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
                         d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],    \
                         d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which)
   int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
+  // LAMMPS_LE_DIAG_STEP=bits: the same kernel is launched once more BEFORE the real launch with parts switched off
+  // (1 bonds, 2 pair loop, 4 draws, 128 nothing); it writes only the second position buffer, which the real launch
+  // overwrites, so the run is physically unchanged and a kernel trace shows what each part costs
+  static const int diag_step = getenv("LAMMPS_LE_DIAG_STEP") ? atoi(getenv("LAMMPS_LE_DIAG_STEP")) : 0;
+  if (diag_step && key == 15 && which < 0) {
+    ForceArgs R = A;
+    A.diag = diag_step | 64;
+    hipEvent_t e0 = ev_start, e1 = ev_stop;
+    ev_start = ev_stop = nullptr;
+    STP(true, true, true, true);
+    A = R; ev_start = e0; ev_stop = e1;
+  }
   switch (key) {
     case 0: STP(false, false, false, false); break;  case 1: STP(false, false, false, true); break;
     case 2: STP(false, false, true, false); break;   case 3: STP(false, false, true, true); break;

@@ -218,7 +218,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
                                             int *__restrict__ neigh, const int *__restrict__ all_nspecial,
                                             const int *__restrict__ all_special, int ms_, int &cnt, float bandf,
-                                            const float4 *stg, int stg_base, int n_owned, bool &ghostref) {
+                                            const float4 *stg, int stg_base) {
 #pragma clang fp contract(fast)
   const float rix = (float)ri.x, riy = (float)ri.y, riz = (float)ri.z;
   const float px = (float)box.prd[0], py = (float)box.prd[1], pz = (float)box.prd[2];
@@ -287,7 +287,6 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
     }
     if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
     cnt++;
-    ghostref = ghostref || q >= n_owned;
   }
 }
 
@@ -302,8 +301,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
                                                        const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
-                                                       int *__restrict__ flags, int diag,
-                                                       unsigned char *__restrict__ phase) {
+                                                       int *__restrict__ flags, int diag) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
   double4 ri = pos[active ? s : 0];
@@ -355,15 +353,14 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   if (diag & 8) { if (active) numneigh[s] = 0; return; }                       // lanes past the end of an otherwise live wavefront stay as helpers
   const int last = 63 - __clzll((long long)actmask);
   int cnt = 0;
-  bool ghostref = false;
   const int maxneigh_w = (diag & 1) ? 0 : maxneigh;   // diagnostics: bit 0 = no entry stores, bit 1 = no candidate loops
   int x0 = cx - CELL_XSPLIT, x1 = cx + CELL_XSPLIT;   // x-cell range (>= cutneigh each way), may stick out of [0, ncx)
 #define RANGE_T(B, E, STG, SB)                                                                                    \
   do {                                                                                                            \
     if (all_in) neigh_range<NOSPECIAL, false, ASYM, STG>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, \
-                                              sf1, sf2, sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB, n, ghostref);  \
+                                              sf1, sf2, sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
     else neigh_range<NOSPECIAL, true, ASYM, STG>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
-                                      sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB, n, ghostref);  \
+                                      sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
   } while (0)
 #define RANGE(B, E) RANGE_T(B, E, false, 0)
   // Pass A: the main index range of all nine (dz,dy) rows, 18 independent loads issued together (the rolled loop
@@ -444,7 +441,6 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
 #undef RANGE_T
   if (!active) return;
   numneigh[s] = min(cnt, maxneigh);
-  if (phase && ghostref) phase[s] = 1;   // a neighbor is a ghost: phase 1 of a decomposed step
   // The longest list is only needed when a list did not fit (the host then grows the table to it).  Recording it
   // unconditionally - one atomicMax per wavefront on ONE address - serialises 15.6k read-modify-writes in a single
   // L2 channel: 170 us of a 255 us kernel at 1M beads.
@@ -462,9 +458,8 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
                                                        const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
-                                                       int *__restrict__ flags, int diag,
-                                                       unsigned char *__restrict__ phase) {
-  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag, phase);
+                                                       int *__restrict__ flags, int diag) {
+  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag);
 }
 // same body under a second name: LAMMPS_LE_DIAG_BUILD re-runs the build into scratch outputs with parts switched
 // off, so that a profile of a physically unchanged run shows what each part costs
@@ -479,9 +474,8 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh_diag(int n, int npad, int
                                                        const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
                                                        int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
-                                                       int *__restrict__ flags, int diag,
-                                                       unsigned char *__restrict__ phase) {
-  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag, phase);
+                                                       int *__restrict__ flags, int diag) {
+  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag);
 }
 
 // phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
@@ -536,7 +530,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
-                     sf2, sf3, d.neigh, d.numneigh, d.flags, 0, d.dd ? d.phase : nullptr)
+                     sf2, sf3, d.neigh, d.numneigh, d.flags, 0)
     if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
     else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
     else BUILD(false, false);
@@ -545,7 +539,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
       hipLaunchKernelGGL((k_build_neigh_diag<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
                          d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],
                          d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,
-                         sf2, sf3, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1, nullptr);
+                         sf2, sf3, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
     }
   }
 }
