@@ -82,9 +82,10 @@ def bond_set(nb, bt, ba):
     return out
 
 
-@pytest.mark.parametrize("world,n", [(2, 6000), (3, 20000)])
-def test_md_across_slabs(tmp_path, world, n):
-    """NVE + Langevin for 60 steps incl. reneighbors with migration across slab faces."""
+@pytest.mark.parametrize("world,n,overlap", [(2, 6000, 0), (3, 20000, 0), (2, 6000, 1)])
+def test_md_across_slabs(tmp_path, world, n, overlap, monkeypatch):
+    """NVE + Langevin for 60 steps incl. reneighbors with migration across slab faces (one process per rank)."""
+    monkeypatch.setenv("LAMMPS_LE_OVERLAP", str(overlap))
     s = lattice_chain(n, nchains=2, seed=21)
     script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
         "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 30\nrun 60\n"
