@@ -50,6 +50,7 @@ Engine::~Engine() {
   }
   if (comm) { try { comm->finalize(); } catch (...) {} delete comm; }
   if (logfile) fclose(logfile);
+  for (auto &dp : dumps) if (dp.fp) fclose(dp.fp);
 }
 
 void Engine::comm_init(const std::string &backend, int rank_, int world_, const void *unique_id, const std::string &session) {
@@ -628,6 +629,7 @@ void Engine::setup() {
   thermo_log.push_back(last_thermo);
   print_thermo_header();
   print_thermo(last_thermo);
+  write_dumps(ntimestep);            // Output::setup (src/output.cpp:150-200): snapshot of the initial state
 }
 
 // Verlet::run (src/verlet.cpp:223-354).  With the standard fix set (one fix nve, at most one fix langevin) a
@@ -646,6 +648,7 @@ void Engine::iterate(long nsteps) {
   for (long it = 0; it < nsteps; it++) {
     ntimestep++;
     bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
+    const bool dump_now = !dumps.empty() && dump_due(ntimestep);   // needs x, v AND f of this step: unfused path
     TypeTables tt = make_tables(this, lg);
     if (!pre_integrated) {
       bool will_check = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
@@ -656,7 +659,7 @@ void Engine::iterate(long nsteps) {
       reneighbor();
       if (sortfreq > 0 && ntimestep >= nextsort) emulate_atom_sort();
     } else halo_exchange();     // ghosts follow their owners (CommBrick::forward_comm)
-    if (fusable && !eflag) {
+    if (fusable && !eflag && !dump_now) {
       bool next = (it + 1 < nsteps);
       bool check_next = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
       if (lg) langevin_draws(this, lg);
@@ -697,6 +700,7 @@ void Engine::iterate(long nsteps) {
         thermo_log.push_back(last_thermo);
         print_thermo(last_thermo);
       }
+      if (dump_now) write_dumps(ntimestep);
     }
   }
   HIP_CHECK(hipStreamSynchronize(d.stream));

@@ -235,6 +235,17 @@ class Engine {
   // ---- topology on the host (read_data path) ----
   void read_data(const std::string &path);
   void write_data(const std::string &path);
+  // ---- dumps (src/dump_custom.cpp, dump_atom.cpp, dump_local.cpp; compute_property_local.cpp) ----
+  struct Dump {
+    std::string id, style, path, label = "ENTRIES";
+    long every = 0, last = -1;
+    std::vector<std::string> cols;
+    FILE *fp = nullptr;
+  };
+  std::vector<Dump> dumps;
+  std::map<std::string, std::vector<std::string>> computes_local;   // compute ID -> property/local attributes
+  bool dump_due(long step) const;
+  void write_dumps(long step);       // downloads, then writes every dump that is due
   void build_special();               // src/special.cpp:55-
   void create_box_atoms_check();
 

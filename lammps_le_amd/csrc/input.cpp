@@ -10,6 +10,8 @@
 
 #include "engine.h"
 
+#include <array>
+
 namespace lmp_le {
 
 double numeric(const std::string &s) {
@@ -362,6 +364,75 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
   } else if (cmd == "write_data") {
     need(1);
     write_data(arg[0]);
+  } else if (cmd == "compute") {
+    // compute ID group property/local attr...   (src/compute_property_local.cpp:30-180; bond attributes only)
+    need(4);
+    if (arg[1] != "all") throw LammpsError("MI355X engine: only group all is supported");
+    if (arg[2] != "property/local") throw LammpsError("Unknown compute style " + arg[2]);
+    std::vector<std::string> attrs(arg.begin() + 3, arg.end());
+    for (auto &a : attrs)
+      if (a != "btype" && a != "batom1" && a != "batom2")
+        throw LammpsError("MI355X engine: compute property/local supports btype batom1 batom2 (got " + a + ")");
+    computes_local[arg[0]] = attrs;
+  } else if (cmd == "uncompute") {
+    need(1);
+    if (!computes_local.erase(arg[0])) throw LammpsError("Could not find uncompute ID");
+  } else if (cmd == "dump") {
+    // dump ID group style N file args   (src/dump.cpp:60-170, dump_custom.cpp:60-250, dump_local.cpp:40-130)
+    need(5);
+    if (arg[1] != "all") throw LammpsError("MI355X engine: only group all is supported");
+    for (auto &dp : dumps) if (dp.id == arg[0]) throw LammpsError("Reuse of dump ID");
+    Dump dp;
+    dp.id = arg[0]; dp.style = arg[2]; dp.every = atol(arg[3].c_str()); dp.path = arg[4];
+    if (dp.every <= 0) throw LammpsError("Invalid dump frequency");
+    static const char *atom_cols[] = {"id", "mol", "type", "mass", "x", "y", "z", "xs", "ys", "zs", "xu", "yu", "zu", "ix", "iy",
+                                      "iz", "vx", "vy", "vz", "fx", "fy", "fz"};
+    if (dp.style == "atom") {
+      if (arg.size() != 5) throw LammpsError("Illegal dump atom command");
+      dp.cols = {"id", "type", "xs", "ys", "zs"};
+    } else if (dp.style == "custom") {
+      if (arg.size() < 6) throw LammpsError("Illegal dump custom command");
+      for (size_t k = 5; k < arg.size(); k++) {
+        bool ok = false;
+        for (auto c : atom_cols) ok = ok || arg[k] == c;
+        if (!ok) throw LammpsError("MI355X engine: dump custom attribute " + arg[k] + " is not supported");
+        dp.cols.push_back(arg[k]);
+      }
+    } else if (dp.style == "local") {
+      if (arg.size() < 6) throw LammpsError("Illegal dump local command");
+      for (size_t k = 5; k < arg.size(); k++) {
+        const std::string &a = arg[k];
+        if (a != "index") {
+          size_t lb = a.find('['), rb = a.find(']');
+          if (a.compare(0, 2, "c_") != 0 || lb == std::string::npos || rb == std::string::npos)
+            throw LammpsError("Invalid attribute in dump local command");
+          std::string cid = a.substr(2, lb - 2);
+          if (!computes_local.count(cid)) throw LammpsError("Could not find dump local compute ID");
+          int col = atoi(a.substr(lb + 1, rb - lb - 1).c_str());
+          if (col < 1 || col > (int)computes_local[cid].size()) throw LammpsError("Dump local compute vector is accessed out-of-range");
+        }
+        dp.cols.push_back(a);
+      }
+    } else throw LammpsError("Unknown dump style " + dp.style);
+    dumps.push_back(dp);
+  } else if (cmd == "dump_modify") {
+    need(1);
+    Dump *dp = nullptr;
+    for (auto &q : dumps) if (q.id == arg[0]) dp = &q;
+    if (!dp) throw LammpsError("Cound not find dump_modify ID");      // (sic) src/output.cpp:708
+    for (size_t k = 1; k < arg.size(); k += 2) {
+      if (k + 1 >= arg.size()) throw LammpsError("Illegal dump_modify command");
+      if (arg[k] == "every") { dp->every = atol(arg[k + 1].c_str()); if (dp->every <= 0) throw LammpsError("Illegal dump_modify command"); }
+      else if (arg[k] == "sort") { if (arg[k + 1] != "id" && arg[k + 1] != "off") throw LammpsError("MI355X engine: dump_modify sort id|off only (rows are always written in ID order)"); }
+      else if (arg[k] == "label") dp->label = arg[k + 1];
+      else throw LammpsError("MI355X engine: dump_modify " + arg[k] + " is not supported");
+    }
+  } else if (cmd == "undump") {
+    need(1);
+    bool found = false;
+    for (size_t k = 0; k < dumps.size(); k++)
+      if (dumps[k].id == arg[0]) { if (dumps[k].fp) fclose(dumps[k].fp); dumps.erase(dumps.begin() + k); found = true; break; }
+    if (!found) throw LammpsError("Could not find undump ID");
   } else if (cmd == "variable") {
     need(3);
     if (arg[1] == "index" || arg[1] == "string" || arg[1] == "equal") {
@@ -618,6 +689,92 @@ void Engine::write_data(const std::string &path) {
       }
   }
   fclose(fp);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// dumps: text snapshots in the reference's formats (header_item: src/dump_custom.cpp:510-527, dump_local.cpp:255-279;
+// values "%d" / "%g" separated by one blank, no trailing blank: dump_custom.cpp:160-170, 280-304).  Rows are in
+// atom-ID order, which is the reference's order at 1 rank with `atom_modify sort 0 0` (or `dump_modify sort id`).
+// ---------------------------------------------------------------------------------------------
+bool Engine::dump_due(long step) const {
+  for (auto &dp : dumps) if (step % dp.every == 0 && dp.last != step) return true;
+  return false;
+}
+void Engine::write_dumps(long step) {
+  if (!dump_due(step)) return;
+  host_current = false;       // mid-run: the device holds the state of this step
+  download();                 // collective when decomposed; every rank then holds the whole system
+  host_current = false;
+  for (auto &dp : dumps) {
+    if (step % dp.every != 0 || dp.last == step) continue;
+    dp.last = step;
+    if (rank != 0) continue;
+    FILE *fp = dp.fp;
+    size_t star = dp.path.find('*');
+    if (star != std::string::npos) {      // one file per snapshot (src/dump.cpp:590-610)
+      std::string name = dp.path.substr(0, star) + std::to_string(step) + dp.path.substr(star + 1);
+      fp = fopen(name.c_str(), "w");
+    } else if (!fp) fp = dp.fp = fopen(dp.path.c_str(), "w");
+    if (!fp) throw LammpsError("Cannot open dump file " + dp.path);
+    long nrows = natoms;
+    std::vector<std::array<int, 3>> bonds;     // (type, atom1, atom2) as compute property/local lists them
+    if (dp.style == "local") {
+      // newton_bond off storage: every bond sits with both atoms, listed once from the lower ID
+      // (src/compute_property_local.cpp:420-470)
+      for (int i = 0; i < natoms; i++)
+        for (int m = 0; m < num_bond[i]; m++) {
+          int bt = bond_type[(size_t)i * bpa + m], j = bond_atom[(size_t)i * bpa + m];
+          if (bt == 0 || i + 1 > j) continue;
+          bonds.push_back({bt, i + 1, j});
+        }
+      nrows = (long)bonds.size();
+    }
+    fprintf(fp, "ITEM: TIMESTEP\n%ld\n", step);
+    fprintf(fp, "ITEM: NUMBER OF %s\n%ld\n", dp.style == "local" ? dp.label.c_str() : "ATOMS", nrows);
+    fprintf(fp, "ITEM: BOX BOUNDS pp pp pp\n");
+    for (int k = 0; k < 3; k++) fprintf(fp, "%-1.16e %-1.16e\n", box.lo[k], box.hi[k]);
+    std::string columns;
+    for (size_t k = 0; k < dp.cols.size(); k++) columns += (k ? " " : "") + dp.cols[k];
+    fprintf(fp, "ITEM: %s %s\n", dp.style == "local" ? dp.label.c_str() : "ATOMS", columns.c_str());
+    const size_t nc = dp.cols.size();
+    if (dp.style == "local") {
+      struct Col { int kind; int attr; };   // kind 0 = index, 1 = compute column
+      std::vector<Col> cc;
+      for (auto &a : dp.cols) {
+        if (a == "index") { cc.push_back({0, 0}); continue; }
+        size_t lb = a.find('['), rb = a.find(']');
+        auto &attrs = computes_local.at(a.substr(2, lb - 2));
+        const std::string &at = attrs[atoi(a.substr(lb + 1, rb - lb - 1).c_str()) - 1];
+        cc.push_back({1, at == "btype" ? 0 : at == "batom1" ? 1 : 2});
+      }
+      for (long r = 0; r < nrows; r++)
+        for (size_t k = 0; k < nc; k++) {
+          if (cc[k].kind == 0) fprintf(fp, "%ld", r + 1);
+          else fprintf(fp, "%g", (double)bonds[r][cc[k].attr]);     // compute values are doubles
+          fputc(k + 1 < nc ? ' ' : '\n', fp);
+        }
+    } else {
+      for (int i = 0; i < natoms; i++)
+        for (size_t k = 0; k < nc; k++) {
+          const std::string &c = dp.cols[k];
+          const double *xi = &x[3 * (size_t)i];
+          const int *im = &image[3 * (size_t)i];
+          if (c == "id") fprintf(fp, "%d", i + 1);
+          else if (c == "mol") fprintf(fp, "%d", molecule[i]);
+          else if (c == "type") fprintf(fp, "%d", type[i]);
+          else if (c == "mass") fprintf(fp, "%g", mass[type[i]]);
+          else if (c == "ix" || c == "iy" || c == "iz") fprintf(fp, "%d", im[c[1] - 'x']);
+          else if (c.size() == 1) fprintf(fp, "%g", xi[c[0] - 'x']);
+          else if (c[1] == 's') fprintf(fp, "%g", (xi[c[0] - 'x'] - box.lo[c[0] - 'x']) / box.prd[c[0] - 'x']);
+          else if (c[1] == 'u') fprintf(fp, "%g", xi[c[0] - 'x'] + im[c[0] - 'x'] * box.prd[c[0] - 'x']);
+          else if (c[0] == 'v') fprintf(fp, "%g", v[3 * (size_t)i + (c[1] - 'x')]);
+          else fprintf(fp, "%g", f[3 * (size_t)i + (c[1] - 'x')]);
+          fputc(k + 1 < nc ? ' ' : '\n', fp);
+        }
+    }
+    if (star != std::string::npos) fclose(fp); else fflush(fp);
+  }
 }
 
 }  // namespace lmp_le

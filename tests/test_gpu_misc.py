@@ -125,3 +125,66 @@ def test_langevin_generators_agree(tmp_path, env, monkeypatch):
     p = run_product(script + "run 37\nrun 5\nrun 1\n", s, tmp_path)
     assert relerr(p.gather("x"), o.x()) < 1e-9
     assert relerr(p.gather("v"), o.v()) < 1e-8
+
+
+def _read_dump(path):
+    """-> list of (timestep, columns, rows) for a text dump with one or several snapshots"""
+    out, lines, k = [], open(path).read().split("\n"), 0
+    while k < len(lines) and lines[k].startswith("ITEM: TIMESTEP"):
+        step = int(lines[k + 1])
+        assert lines[k + 2].startswith("ITEM: NUMBER OF")
+        n = int(lines[k + 3])
+        assert lines[k + 4] == "ITEM: BOX BOUNDS pp pp pp"
+        head = lines[k + 8].split()
+        cols = head[2:]
+        rows = [ln.split() for ln in lines[k + 9:k + 9 + n]]
+        assert all(len(r) == len(cols) for r in rows) and not any(ln.endswith(" ") for ln in lines[k + 9:k + 9 + n])
+        out.append((step, cols, rows))
+        k += 9 + n
+    return out
+
+
+def test_dump_custom_atom_and_local(tmp_path):
+    """dump custom / atom / local (+ compute property/local) in the reference's text formats (dump_custom.cpp:510-527,
+    dump_local.cpp:255-279): snapshots at step 0 and every N steps, values of THAT step (x, v and f), bonds listed once
+    from the lower ID - the contact-map input of a loop-extrusion run."""
+    n = 3000
+    s = melted(n, seed=5)
+    s["ntypes"], s["mass"] = 4, [1.0] * 4
+    base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0")
+    le = LE.format(n1=7, nl=5, nu=5, neutral=1, left=2, right=3, tp=0.5, lr="4", lprob="prob 0.6 101", uprob="prob 0.3 202",
+                   rmax=1.3)
+    d1, d2, d3 = (str(tmp_path / f) for f in ("atoms.dump", "bonds.*.dump", "scaled.dump"))
+    dumps = ("compute pl all property/local btype batom1 batom2\n"
+             "dump 1 all custom 10 %s id type x y z ix iy iz vx vy vz fx fy fz xu\n"
+             "dump 2 all local 10 %s index c_pl[1] c_pl[2] c_pl[3]\n"
+             "dump 3 all atom 20 %s\ndump_modify 1 sort id\n" % (d1, d2, d3))
+    o = run_oracle(base + le + "run 20\n", s)
+    p = run_product(base + le + dumps + "run 20\n", s, tmp_path)
+    snaps = _read_dump(d1)
+    assert [st for st, _, _ in snaps] == [0, 10, 20]
+    step, cols, rows = snaps[-1]
+    assert cols == "id type x y z ix iy iz vx vy vz fx fy fz xu".split()
+    a = np.array(rows, dtype=float)
+    assert (a[:, 0] == np.arange(1, n + 1)).all()
+    L = s["box"][0][1] - s["box"][0][0]
+    g6 = 6e-6      # %g = 6 significant digits
+    assert relerr(a[:, 2:5], o.x()) < g6 and relerr(a[:, 8:11], o.v()) < g6 and relerr(a[:, 11:14], o.f()) < g6
+    assert (a[:, 5:8] == o.image()).all() and relerr(a[:, 14], o.x()[:, 0] + o.image()[:, 0] * L) < g6
+    # step-0 snapshot = the input state
+    a0 = np.array(snaps[0][2], dtype=float)
+    d0 = a0[:, 2:5] - s["x"]                     # the input may lie outside the box; the snapshot is wrapped (setup)
+    assert np.abs((d0 + L / 2) % L - L / 2).max() < 1e-4
+    # bonds: one file per snapshot, every bond once from its lower ID, in atom order
+    bsn = _read_dump(d2.replace("*", "20"))
+    assert len(bsn) == 1 and bsn[0][1] == ["index", "c_pl[1]", "c_pl[2]", "c_pl[3]"]
+    b = np.array(bsn[0][2], dtype=float).astype(int)
+    assert (b[:, 0] == np.arange(1, len(b) + 1)).all() and (b[:, 2] < b[:, 3]).all() and (np.diff(b[:, 2]) >= 0).all()
+    assert {(t, i, j) for _, t, i, j in b} == o.bond_set() and len(b) == o.nbonds()
+    assert os.path.exists(d2.replace("*", "0")) and os.path.exists(d2.replace("*", "10"))
+    sc = _read_dump(d3)
+    assert [st for st, _, _ in sc] == [0, 20] and sc[0][1] == ["id", "type", "xs", "ys", "zs"]
+    xs = np.array(sc[-1][2], dtype=float)[:, 2:5]
+    assert relerr(xs, (o.x() - s["box"][0][0]) / L, floor=0.1) < 1e-5
+    # dumping does not perturb the trajectory
+    assert np.abs(p.gather("x") - o.x()).max() < 1e-9 and p.bond_set() == o.bond_set()

@@ -67,6 +67,33 @@ def test_errors_match_reference_messages(tmp_path):
         lmp.command("fix bad4 all langevin 1.0 1.0 0.0 1234")
 
 
+def test_dump_and_compute_commands_are_parsed(tmp_path):
+    """Argument grammar and error strings of dump / dump_modify / undump / compute property/local (host side only)."""
+    from lammps_le_amd import LammpsError
+    lmp, _ = _open(tmp_path)
+    lmp.command("compute pl all property/local btype batom1 batom2")
+    lmp.command("dump 1 all custom 100 %s id type x y z" % (tmp_path / "a.dump"))
+    lmp.command("dump 2 all local 100 %s index c_pl[1] c_pl[3]" % (tmp_path / "b.dump"))
+    lmp.command("dump_modify 1 sort id")
+    assert lmp.has_style("dump", "custom") and lmp.has_style("dump", "local") and lmp.has_style("compute", "property/local")
+    with pytest.raises(LammpsError, match="Reuse of dump ID"):                 # src/output.cpp:560
+        lmp.command("dump 1 all atom 10 x.dump")
+    with pytest.raises(LammpsError, match="Invalid dump frequency"):           # src/output.cpp:575
+        lmp.command("dump 3 all atom 0 x.dump")
+    with pytest.raises(LammpsError, match="Unknown dump style"):
+        lmp.command("dump 3 all xyzzy 10 x.dump")
+    with pytest.raises(LammpsError, match="out-of-range"):                      # src/dump_local.cpp:443-446
+        lmp.command("dump 3 all local 10 x.dump c_pl[4]")
+    with pytest.raises(LammpsError, match="Could not find dump local compute ID"):
+        lmp.command("dump 3 all local 10 x.dump c_nope[1]")
+    with pytest.raises(LammpsError, match="not supported"):
+        lmp.command("dump 3 all custom 10 x.dump id q")
+    with pytest.raises(LammpsError, match="Could not find undump ID"):        # src/output.cpp:690
+        lmp.command("undump 7")
+    lmp.command("undump 2")
+    lmp.command("uncompute pl")
+
+
 def test_run_fails_loudly_without_gpu(tmp_path):
     import torch
     if torch.cuda.is_available():
