@@ -244,6 +244,11 @@ class Engine {
   };
   std::vector<Dump> dumps;
   std::map<std::string, std::vector<std::string>> computes_local;   // compute ID -> property/local attributes
+  // ---- restart: own binary format, bit-continuous incl. the RNG streams of the fixes ----
+  void write_restart(const std::string &path);
+  void read_restart(const std::string &path);
+  std::map<std::string, std::vector<unsigned char>> restart_fix_state;   // fix ID -> saved state, applied by `fix`
+  void apply_restart_state(Fix *f);
   bool dump_due(long step) const;
   void write_dumps(long step);       // downloads, then writes every dump that is due
   void build_special();               // src/special.cpp:55-

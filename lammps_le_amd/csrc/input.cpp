@@ -328,6 +328,7 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
     else if (st == "ex_load") f.reset(new FixExLoad(this, arg));
     else if (st == "ex_unload") f.reset(new FixExUnload(this, arg));
     else throw LammpsError("Unknown fix style " + st);
+    apply_restart_state(f.get());     // a fix re-specified after read_restart continues its RNG stream (Fix::restart)
     fixes.push_back(std::move(f));
   } else if (cmd == "unfix") {
     need(1);
@@ -364,6 +365,13 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
   } else if (cmd == "write_data") {
     need(1);
     write_data(arg[0]);
+  } else if (cmd == "write_restart") {
+    need(1);
+    write_restart(arg[0]);
+  } else if (cmd == "read_restart") {
+    need(1);
+    if (box_exist) throw LammpsError("Cannot read_restart after simulation box is defined");   // src/read_restart.cpp:60
+    read_restart(arg[0]);
   } else if (cmd == "compute") {
     // compute ID group property/local attr...   (src/compute_property_local.cpp:30-180; bond attributes only)
     need(4);
@@ -775,6 +783,142 @@ void Engine::write_dumps(long step) {
     }
     if (star != std::string::npos) fclose(fp); else fflush(fp);
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// restart files.  The reference's write_restart / read_restart (src/write_restart.cpp, read_restart.cpp) keep the
+// system, the force-field coefficients and per-fix state, but neither fix langevin nor the USER-LE fixes save
+// their RanMars streams, so a restarted reference run is a different trajectory.  This format (engine-specific,
+// binary, host byte order) also keeps the stream positions: `run A; write_restart; [new process] read_restart;
+// fix ...; run B` is bit-identical to `run A; run B` in one process.  As in the reference, fixes, thermo and dump
+// settings are not stored and have to be re-specified; a fix with a saved ID and the same style picks its state up.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Wr {
+  FILE *fp;
+  template <class T> void pod(const T &v) { fwrite(&v, sizeof(T), 1, fp); }
+  void str(const std::string &s) { uint64_t n = s.size(); pod(n); fwrite(s.data(), 1, n, fp); }
+  template <class T> void vec(const std::vector<T> &v) { uint64_t n = v.size(); pod(n); if (n) fwrite(v.data(), sizeof(T), n, fp); }
+};
+struct Rd {
+  FILE *fp;
+  template <class T> void pod(T &v) { if (fread(&v, sizeof(T), 1, fp) != 1) throw LammpsError("Restart file is truncated"); }
+  void str(std::string &s) { uint64_t n; pod(n); s.resize(n); if (n && fread(&s[0], 1, n, fp) != n) throw LammpsError("Restart file is truncated"); }
+  template <class T> void vec(std::vector<T> &v) { uint64_t n; pod(n); v.resize(n); if (n && fread(v.data(), sizeof(T), n, fp) != n) throw LammpsError("Restart file is truncated"); }
+};
+const char RESTART_MAGIC[] = "LAMMPS_LE_AMD restart 1";
+template <class T> void blob_put(std::vector<unsigned char> &b, const T &v) { const unsigned char *p = (const unsigned char *)&v; b.insert(b.end(), p, p + sizeof(T)); }
+template <class T> void blob_get(const std::vector<unsigned char> &b, size_t &off, T &v) { if (off + sizeof(T) > b.size()) throw LammpsError("Restart file: bad fix state"); memcpy(&v, &b[off], sizeof(T)); off += sizeof(T); }
+}  // namespace
+
+void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
+
+void Engine::write_restart(const std::string &path) {
+  if (!box_exist) throw LammpsError("Write_restart command before simulation box is defined");   // src/write_restart.cpp:62
+  download();
+  // the LE fixes' generators live on the device while a run has used them
+  int slot = 0;
+  for (auto &f : fixes) {
+    if (!f->force_reneighbor) continue;
+    if (auto *a = dynamic_cast<FixExtrusion *>(f.get())) { if (a->rng_on_device) le_rng_download(*dev, slot, a->rng); }
+    else if (auto *b = dynamic_cast<FixExLoad *>(f.get())) { if (b->rng_on_device) le_rng_download(*dev, slot, b->rng); }
+    else if (auto *c = dynamic_cast<FixExUnload *>(f.get())) { if (c->rng_on_device) le_rng_download(*dev, slot, c->rng); }
+    slot++;
+  }
+  if (rank != 0) return;
+  FILE *fp = fopen(path.c_str(), "wb");
+  if (!fp) throw LammpsError("Cannot open restart file " + path);
+  Wr w{fp};
+  w.str(RESTART_MAGIC);
+  w.str(units); w.str(atom_style);
+  w.pod(dt); w.pod(skin); w.pod(neigh_every); w.pod(neigh_delay); w.pod(neigh_check); w.pod(newton_pair); w.pod(newton_bond);
+  w.pod(sortfreq); w.pod(nextsort); w.pod(special_lj); w.pod(comm_cutoff); w.pod(ntimestep); w.pod(box);
+  w.pod(natoms); w.pod(ntypes); w.pod(nbondtypes); w.pod(extra_bond); w.pod(extra_special); w.pod(bpa); w.pod(maxspecial);
+  w.pod(nbonds); w.pod(special_built);
+  w.vec(mass); w.vec(mass_set); w.vec(x); w.vec(v); w.vec(type); w.vec(image); w.vec(molecule); w.vec(num_bond);
+  w.vec(bond_type); w.vec(bond_atom); w.vec(nspecial); w.vec(special); w.vec(crank);
+  w.pod(pair_lj); w.pod(pair_zero); w.pod(pair_cut_global); w.pod(pair_shift); w.pod(pair_mix);
+  w.vec(pc_eps); w.vec(pc_sig); w.vec(pc_cut); w.vec(pc_set);
+  w.str(bond_style_name);
+  uint64_t nh = bond_hybrid_styles.size(); w.pod(nh);
+  for (auto &h : bond_hybrid_styles) w.str(h);
+  w.pod(bondtab);
+  uint64_t nf = 0;
+  for (auto &f : fixes) if (f->style == "langevin" || f->force_reneighbor) nf++;
+  w.pod(nf);
+  for (auto &f : fixes) {
+    std::vector<unsigned char> b;
+    if (auto *l = dynamic_cast<FixLangevin *>(f.get())) { blob_put(b, l->seed); blob_put(b, l->draws); }
+    else if (auto *a = dynamic_cast<FixExtrusion *>(f.get())) { blob_put(b, a->rng); blob_put(b, a->last_break); }
+    else if (auto *c = dynamic_cast<FixExLoad *>(f.get())) { blob_put(b, c->rng); blob_put(b, c->last_create); blob_put(b, c->total_create); }
+    else if (auto *u = dynamic_cast<FixExUnload *>(f.get())) { blob_put(b, u->rng); blob_put(b, u->last_break); blob_put(b, u->total_break); }
+    else continue;
+    w.str(f->id); w.str(f->style); w.vec(b);
+  }
+  fclose(fp);
+}
+
+void Engine::read_restart(const std::string &path) {
+  FILE *fp = fopen(path.c_str(), "rb");
+  if (!fp) throw LammpsError("Cannot open restart file " + path);
+  Rd r{fp};
+  try {
+    std::string magic;
+    r.str(magic);
+    if (magic != RESTART_MAGIC) throw LammpsError("Restart file is not a lammps_le_amd restart file");
+    r.str(units); r.str(atom_style);
+    r.pod(dt); r.pod(skin); r.pod(neigh_every); r.pod(neigh_delay); r.pod(neigh_check); r.pod(newton_pair); r.pod(newton_bond);
+    r.pod(sortfreq); r.pod(nextsort); r.pod(special_lj); r.pod(comm_cutoff); r.pod(ntimestep); r.pod(box);
+    r.pod(natoms); r.pod(ntypes); r.pod(nbondtypes); r.pod(extra_bond); r.pod(extra_special); r.pod(bpa); r.pod(maxspecial);
+    r.pod(nbonds); r.pod(special_built);
+    r.vec(mass); r.vec(mass_set); r.vec(x); r.vec(v); r.vec(type); r.vec(image); r.vec(molecule); r.vec(num_bond);
+    r.vec(bond_type); r.vec(bond_atom); r.vec(nspecial); r.vec(special); r.vec(crank);
+    r.pod(pair_lj); r.pod(pair_zero); r.pod(pair_cut_global); r.pod(pair_shift); r.pod(pair_mix);
+    r.vec(pc_eps); r.vec(pc_sig); r.vec(pc_cut); r.vec(pc_set);
+    r.str(bond_style_name);
+    uint64_t nh; r.pod(nh);
+    bond_hybrid_styles.resize(nh);
+    for (auto &h : bond_hybrid_styles) r.str(h);
+    r.pod(bondtab);
+    uint64_t nf; r.pod(nf);
+    restart_fix_state.clear();
+    for (uint64_t k = 0; k < nf; k++) {
+      std::string id, style;
+      std::vector<unsigned char> b;
+      r.str(id); r.str(style); r.vec(b);
+      b.insert(b.begin(), style.begin(), style.end());
+      b.insert(b.begin() + style.size(), (unsigned char)0);
+      restart_fix_state[id] = b;
+    }
+  } catch (...) { fclose(fp); throw; }
+  fclose(fp);
+  if (x.size() != 3 * (size_t)natoms || num_bond.size() != (size_t)natoms) throw LammpsError("Restart file is inconsistent");
+  f.assign(3 * (size_t)natoms, 0.0);
+  box_exist = true;
+  host_current = true;
+  dev_current = false;
+  char buf[160];
+  snprintf(buf, sizeof buf, "Reading restart file ...\n  %d atoms\n  %ld bonds\n", natoms, nbonds);
+  say(buf);
+}
+
+void Engine::apply_restart_state(Fix *f) {
+  auto it = restart_fix_state.find(f->id);
+  if (it == restart_fix_state.end()) return;
+  const std::vector<unsigned char> &b = it->second;
+  std::string style((const char *)b.data());
+  size_t off = style.size() + 1;
+  if (style == f->style) {
+    if (auto *l = dynamic_cast<FixLangevin *>(f)) {
+      int seed; uint64_t draws;
+      blob_get(b, off, seed); blob_get(b, off, draws);
+      if (seed == l->seed) { l->draws = draws; l->dev_ready = false; }   // another seed = a new stream, as in the reference
+    } else if (auto *a = dynamic_cast<FixExtrusion *>(f)) { blob_get(b, off, a->rng); blob_get(b, off, a->last_break); }
+    else if (auto *c = dynamic_cast<FixExLoad *>(f)) { blob_get(b, off, c->rng); blob_get(b, off, c->last_create); blob_get(b, off, c->total_create); }
+    else if (auto *u = dynamic_cast<FixExUnload *>(f)) { blob_get(b, off, u->rng); blob_get(b, off, u->last_break); blob_get(b, off, u->total_break); }
+  }
+  restart_fix_state.erase(it);
 }
 
 }  // namespace lmp_le

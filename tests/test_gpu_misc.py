@@ -188,3 +188,34 @@ def test_dump_custom_atom_and_local(tmp_path):
     assert relerr(xs, (o.x() - s["box"][0][0]) / L, floor=0.1) < 1e-5
     # dumping does not perturb the trajectory
     assert np.abs(p.gather("x") - o.x()).max() < 1e-9 and p.bond_set() == o.bond_set()
+
+
+def test_restart_is_bit_continuous(tmp_path):
+    """write_restart / read_restart keep the RanMars streams of fix langevin and of the three LE fixes (the reference
+    does not): `run 25; write_restart` + a NEW instance `read_restart; fix ...; run 25` is bit-identical to
+    `run 25; run 25` in one instance - positions, velocities, images, types, bonds, special lists, fix counters."""
+    from lammps_le_amd import lammps
+    n = 3000
+    s = melted(n, seed=5, types=barrier_types(n, 7))
+    base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0")
+    le = LE.format(n1=6, nl=5, nu=7, neutral=1, left=2, right=3, tp=0.5, lr="4", lprob="prob 0.6 101", uprob="prob 0.3 202",
+                   rmax=1.3)
+    a = run_product(base + le + "run 25\nrun 25\n", s, tmp_path)
+    o = run_oracle(base + le + "run 25\nrun 25\n", s)
+    rfile = str(tmp_path / "state.restart")
+    b1 = run_product(base + le + "run 25\nwrite_restart %s\n" % rfile, s, tmp_path)
+    b1.close()
+    b = lammps(cmdargs=["-screen", "none"])
+    b.command("read_restart " + rfile)
+    for ln in (le + "run 25\n").split("\n"):
+        b.command(ln)
+    for name in ("x", "v", "image", "type", "num_bond", "bond_type", "bond_atom", "nspecial", "special"):
+        assert np.array_equal(a.gather(name), b.gather(name)), name
+    for fid in ("loop", "loading", "unloading"):
+        assert a.extract_fix(fid, 0, 1, 0) == b.extract_fix(fid, 0, 1, 0) and a.extract_fix(fid, 0, 1, 1) == b.extract_fix(fid, 0, 1, 1)
+    assert b.bond_set() == o.bond_set() and np.abs(b.gather("x") - o.x()).max() < 1e-9
+    assert len([t for t in o.bond_set() if t[0] == 2]) > 5
+    # a restart file cannot be read into a system that already has a box
+    from lammps_le_amd import LammpsError
+    with pytest.raises(LammpsError, match="Cannot read_restart after simulation box is defined"):
+        b.command("read_restart " + rfile)

@@ -94,6 +94,28 @@ def test_dump_and_compute_commands_are_parsed(tmp_path):
     lmp.command("uncompute pl")
 
 
+def test_restart_round_trip_on_the_host(tmp_path):
+    """write_restart / read_restart of a system that has not run yet: everything the script defined comes back."""
+    from lammps_le_amd import LammpsError, lammps
+    lmp, s = _open(tmp_path)
+    lmp.command("fix 2 all langevin 1.0 1.0 1.0 904297")
+    rf = str(tmp_path / "r.bin")
+    lmp.command("write_restart " + rf)
+    new = lammps(cmdargs=["-screen", "none"])
+    with pytest.raises(LammpsError, match="Cannot open restart file"):
+        new.command("read_restart " + rf + ".missing")
+    new.command("read_restart " + rf)
+    assert new.get_natoms() == 500 and np.array_equal(new.gather("x"), lmp.gather("x"))
+    assert new.bond_set() == lmp.bond_set() and np.array_equal(new.gather("special"), lmp.gather("special"))
+    assert new.extract_setting("bond_per_atom") == 3
+    open(rf + ".bad", "wb").write(b"not a restart file at all")
+    other = lammps(cmdargs=["-screen", "none"])
+    with pytest.raises(LammpsError, match="truncated|not a lammps_le_amd restart"):
+        other.command("read_restart " + rf + ".bad")
+    with pytest.raises(LammpsError, match="before simulation box is defined"):
+        other.command("write_restart x")
+
+
 def test_run_fails_loudly_without_gpu(tmp_path):
     import torch
     if torch.cuda.is_available():
