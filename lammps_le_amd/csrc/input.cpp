@@ -804,8 +804,8 @@ struct Wr {
 struct Rd {
   FILE *fp;
   template <class T> void pod(T &v) { if (fread(&v, sizeof(T), 1, fp) != 1) throw LammpsError("Restart file is truncated"); }
-  void str(std::string &s) { uint64_t n; pod(n); s.resize(n); if (n && fread(&s[0], 1, n, fp) != n) throw LammpsError("Restart file is truncated"); }
-  template <class T> void vec(std::vector<T> &v) { uint64_t n; pod(n); v.resize(n); if (n && fread(v.data(), sizeof(T), n, fp) != n) throw LammpsError("Restart file is truncated"); }
+  void str(std::string &s) { uint64_t n; pod(n); if (n > (1u << 20)) throw LammpsError("Restart file is not a lammps_le_amd restart file"); s.resize(n); if (n && fread(&s[0], 1, n, fp) != n) throw LammpsError("Restart file is truncated"); }
+  template <class T> void vec(std::vector<T> &v) { uint64_t n; pod(n); if (n > (1ull << 36)) throw LammpsError("Restart file is truncated"); v.resize(n); if (n && fread(v.data(), sizeof(T), n, fp) != n) throw LammpsError("Restart file is truncated"); }
 };
 const char RESTART_MAGIC[] = "LAMMPS_LE_AMD restart 1";
 template <class T> void blob_put(std::vector<unsigned char> &b, const T &v) { const unsigned char *p = (const unsigned char *)&v; b.insert(b.end(), p, p + sizeof(T)); }
