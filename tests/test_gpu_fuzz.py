@@ -55,3 +55,42 @@ def test_random_le_scenarios(tmp_path, seed):
     for t in np.nonzero(nso[:, 2])[0]:
         assert list(spp[t, :nsp[t, 2]]) == list(spo[t, :nso[t, 2]]), t + 1
     assert np.abs(p.gather("x") - o.x()).max() < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_le_scenarios_decomposed(tmp_path, seed):
+    """The same randomised LE scenarios (incl. the ones where several fixes fire in one step) on two z-slabs: the
+    replicated extruder table must give the 1-rank topology bit for bit."""
+    from test_gpu_dd import bond_set, run_ranks_local
+    rng = np.random.RandomState(1000 + seed)
+    n = int(rng.choice([8000, 10000, 12000]))    # slabs of a 2-rank run must be two 5.0 ghost shells thick
+    rng.choice([1200, 2000, 3500])               # (keeps the parameter stream of the 1-rank sweep)
+    nchains = int(rng.choice([1, 2, 5]))
+    frac = float(rng.choice([0.0, 0.1, 0.4]))
+    types = barrier_types(n, 50 + seed, frac=frac) if frac > 0 else np.ones(n, dtype=np.int32)
+    s = melted(n, nchains=nchains, seed=20 + seed % 3, steps=800, types=types)
+    s["ntypes"], s["mass"] = 4, [1.0] * 4
+    n1, nl, nu = int(rng.randint(3, 9)), int(rng.randint(4, 11)), int(rng.randint(4, 11))
+    tp = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+    lp, up = float(rng.choice([0.2, 0.6, 1.0])), float(rng.choice([0.1, 0.5, 1.0]))
+    lprob = "" if lp >= 1.0 else "prob %g %d" % (lp, 100 + seed)
+    uprob = "" if up >= 1.0 else "prob %g %d" % (up, 200 + seed)
+    rmax = float(rng.choice([0.5, 1.3, 2.0]))
+    lr = "4" if rng.rand() < 0.7 else ""
+    base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 8.0 5.0 1.0 1.0")
+    script = base + LE.format(n1=n1, nl=nl, nu=nu, neutral=1, left=2, right=3, tp=tp, lr=lr, lprob=lprob, uprob=uprob,
+                              rmax=rmax) + "run 32\n"
+    try:
+        o = run_oracle(script, s)
+    except RuntimeError:
+        pytest.skip("the reference itself aborts on this parameter set")
+    # FENE R0 = 5.0 keeps every extruder bond shorter than the 5.0 ghost shell, so bond partners are always reachable
+    r = run_ranks_local(2, s, script, tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+    nso, spo = o.special_table()
+    assert (r["nspecial"] == nso).all()
+    for t in np.nonzero(nso[:, 2])[0]:
+        assert list(r["special"][t, :nso[t, 2]]) == list(spo[t, :nso[t, 2]]), t + 1
+    for fid in ("loop", "loading", "unloading"):
+        assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1]
+    assert np.abs(r["x"] - o.x()).max() < 1e-6
