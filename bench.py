@@ -171,6 +171,8 @@ def main():
                        "%d z-slabs, one rank per GPU, halo + migration over %s, replicated extruder table"
                        % (world, "a file mailbox on ONE shared GPU (rehearsal, not a result)" if shm_rehearsal else "RCCL")},
             "roofline": roofline, "cpu_baseline": cpu,
+            # LJ units: the reference prints tau/day instead of ns/day (src/finish.cpp:124-145); timestep 0.005 tau
+            "tau_per_day": round(args.steps / elapsed * 0.005 * 86400.0, 1),
             "engine_loop_time_s": round(lmp.stat("loop_time"), 5), "neigh_builds": int(lmp.stat("neigh_builds")),
             "extruders": int(nbonds - (nbeads - nchains)), "fene_warnings": int(lmp.stat("fene_warnings")),
         }

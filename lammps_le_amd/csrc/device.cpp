@@ -73,7 +73,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.partial, (size_t)d.nred_blocks * 16);
   HIP_CHECK(hipHostMalloc((void **)&d.partial_h, (size_t)d.nred_blocks * 16 * sizeof(double)));
   dalloc(d.flags, NFLAGS);
-  HIP_CHECK(hipHostMalloc((void **)&d.flags_h, (NFLAGS + 16) * sizeof(int), hipHostMallocMapped));
+  HIP_CHECK(hipHostMalloc((void **)&d.flags_h, (NFLAGS + 16) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
   for (int k = 0; k < NFLAGS + 16; k++) d.flags_h[k] = 0;
   d.flags_seq = 0;
   HIP_CHECK(hipHostGetDevicePointer((void **)&d.flags_h_dev, d.flags_h, 0));
@@ -129,17 +129,28 @@ void dev_free(DeviceState &d) {
 // The host does not call hipStreamSynchronize for these hand-overs (its wake-up costs 30-50 us, twice per rebuild):
 // the kernel writes a sequence number behind the flags and the host spins on the mapped page.
 __global__ void k_publish_flags(int *__restrict__ flags, int *__restrict__ host, unsigned reset, int seq) {
-  if (threadIdx.x < NFLAGS) {
-    host[threadIdx.x] = flags[threadIdx.x];
-    if ((reset >> threadIdx.x) & 1u) flags[threadIdx.x] = 0;
+  // ONE thread writes the flags and then, behind a system-scope release, the sequence number the host spins on: the
+  // host must never see the new number next to old flags (flags and number sit in different 64-byte sectors of the
+  // mapped page, and stores of different lanes have no order among themselves)
+  if (threadIdx.x != 0) return;
+  for (int k = 0; k < NFLAGS; k++) {
+    int v = flags[k];
+    __hip_atomic_store(&host[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((reset >> k) & 1u) flags[k] = 0;
   }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) { host[NFLAGS] = seq; __threadfence_system(); }
+  __hip_atomic_store(&host[NFLAGS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-void sync_flags(DeviceState &d, unsigned reset) {
+void publish_flags(DeviceState &d, unsigned reset) {
   const int seq = ++d.flags_seq;
   hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, d.stream, d.flags, d.flags_h_dev, reset, seq);
+}
+void sync_flags(DeviceState &d, unsigned reset) {
+  publish_flags(d, reset);
+  wait_flags(d);
+}
+// waits for the LAST publish_flags (work enqueued behind it keeps running)
+void wait_flags(DeviceState &d) {
+  const int seq = d.flags_seq;
   static const bool spin = !getenv("LAMMPS_LE_NO_SPIN");
   if (spin) {
     volatile int *h = d.flags_h;
@@ -148,7 +159,7 @@ void sync_flags(DeviceState &d, unsigned reset) {
     while (h[NFLAGS] != seq) {
       if ((++it & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;   // long-running
     }                                                                            // work (or a fault): block instead
-    if (h[NFLAGS] == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+    if (h[NFLAGS] == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }   // pairs with the release store
   }
   HIP_CHECK(hipStreamSynchronize(d.stream));
 }

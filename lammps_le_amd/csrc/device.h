@@ -203,6 +203,8 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
 void launch_ex_unload(DeviceState &d, const ExUnloadParams &p, int rng_slot);
 void launch_extrusion(DeviceState &d, const ExtrusionParams &p, int rng_slot);
 void sync_flags(DeviceState &d, unsigned reset_mask = 0);   // copy flags to flags_h, zero the masked ones, wait
+void publish_flags(DeviceState &d, unsigned reset_mask = 0);   // the same without waiting ...
+void wait_flags(DeviceState &d);                               // ... and the wait for the last publish
 void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);
 void dd_alloc(DeviceState &d, int world);
 

@@ -372,19 +372,24 @@ static void check_device_error(Engine *e, DeviceState &d) {
   throw LammpsError(msg);
 }
 
-void Engine::reneighbor() {
+// defer_check: the flags of the build are published but not waited for - the caller enqueues the step kernel first
+// (it leaves the state untouched if a list overflowed) and then calls finish_reneighbor(); the host round trip of
+// the check (~25 us) is hidden behind that kernel instead of idling the GPU once per rebuild.
+void Engine::reneighbor(bool defer_check) {
   DeviceState &d = *dev;
   double t0 = wall();
+  static const long test_overflow_at = getenv("LAMMPS_LE_TEST_OVERFLOW_AT") ? atol(getenv("LAMMPS_LE_TEST_OVERFLOW_AT")) : -1;
+  if (test_overflow_at >= 0 && neigh_builds == test_overflow_at) dev_alloc_neigh(d, 4);   // test hook: force an overflow
   // FLAG_MOVED / NEIGH_OVERFLOW / MAXNEIGH are zero here: they are reset by the publish kernel that reports them
-  for (int attempt = 0; attempt < 6; attempt++) {
-    if (attempt > 0) launch_lists(d, cutneighmax * cutneighmax, special_lj, pair_lj);   // sorted already: lists only
-    else if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);
-    else launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
-    sync_flags(d, (1u << FLAG_MOVED) | (1u << FLAG_NEIGH_OVERFLOW) | (1u << FLAG_MAXNEIGH));
+  if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);
+  else launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
+  if (defer_check && !d.dd) {
+    publish_flags(d, 1u << FLAG_MOVED);          // NEIGH_OVERFLOW stays set on the device: the step kernel reads it
+    reneigh_pending = true;
+  } else {
+    sync_flags(d, 1u << FLAG_MOVED);
     check_device_error(this, d);
-    if (!d.flags_h[FLAG_NEIGH_OVERFLOW]) break;
-    // grow the ELL table and rebuild (atoms are already wrapped and sorted: the rebuild is idempotent)
-    dev_alloc_neigh(d, d.flags_h[FLAG_MAXNEIGH] + 16);
+    if (d.flags_h[FLAG_NEIGH_OVERFLOW]) regrow_lists();
   }
   if (d.le_snapshot && d.topo_dirty) {   // NTopoBond::build: the bond list the LE fixes will see until the next reneighbor
     d.topo_dirty = false;
@@ -396,6 +401,28 @@ void Engine::reneighbor() {
   ago = 0;
   neigh_builds++;
   timers[2] += wall() - t0;
+}
+
+bool Engine::finish_reneighbor() {
+  if (!reneigh_pending) return true;
+  reneigh_pending = false;
+  wait_flags(*dev);
+  check_device_error(this, *dev);
+  return !dev->flags_h[FLAG_NEIGH_OVERFLOW];
+}
+// grow the ELL table and rebuild (atoms are already wrapped and sorted: the rebuild is idempotent)
+void Engine::regrow_lists() {
+  DeviceState &d = *dev;
+  for (int attempt = 0; attempt < 6 && d.flags_h[FLAG_NEIGH_OVERFLOW]; attempt++) {
+    dev_alloc_neigh(d, d.flags_h[FLAG_MAXNEIGH] + 16);
+    HIP_CHECK(hipMemsetAsync(d.flags + FLAG_NEIGH_OVERFLOW, 0, sizeof(int), d.stream));
+    HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), d.stream));
+    launch_lists(d, cutneighmax * cutneighmax, special_lj, pair_lj);
+    sync_flags(d);
+    check_device_error(this, d);
+  }
+  if (d.flags_h[FLAG_NEIGH_OVERFLOW]) throw LammpsError("Neighbor list overflow, boost neigh_modify one");   // src/npair_*.cpp
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_MAXNEIGH, 0, sizeof(int), d.stream));
 }
 
 // Neighbor::decide (src/neighbor.cpp:1933-1948); `moved` was produced by the initial_integrate kernel
@@ -656,8 +683,9 @@ void Engine::iterate(long nsteps) {
     }
     for (auto &f : fixes) if (f->has_post_integrate) f->post_integrate();
     if (decide()) {
-      reneighbor();
-      if (sortfreq > 0 && ntimestep >= nextsort) emulate_atom_sort();
+      const bool sort_due = sortfreq > 0 && ntimestep >= nextsort;
+      reneighbor(fusable && !eflag && !dump_now && !sort_due);
+      if (sort_due) emulate_atom_sort();
     } else halo_exchange();     // ghosts follow their owners (CommBrick::forward_comm)
     if (fusable && !eflag && !dump_now) {
       bool next = (it + 1 < nsteps);
@@ -682,13 +710,23 @@ void Engine::iterate(long nsteps) {
         d.halo_inflight = true;
         d.halo_ahead = true;
         std::swap(d.pos, d.pos_tmp);
-      } else
+      } else {
         launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
                     timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr);
+        if (!finish_reneighbor()) {
+          // a list of the build that preceded this launch overflowed: the kernel saw the flag and stored nothing.
+          // Undo the launch on the host side, grow the table, rebuild, launch again.
+          if (next) std::swap(d.pos, d.pos_tmp);
+          regrow_lists();
+          launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
+                      timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr);
+        }
+      }
       if (timed) d.ev_used++;
       if (lg) rng_langevin_consumed(d);
       pre_integrated = next;
     } else {
+      if (!finish_reneighbor()) regrow_lists();
       if (d.dd) dd_halo_wait(d);
       compute_forces(eflag);
       if (lg) langevin_post_force(this, lg, nnve == 1);

@@ -265,7 +265,10 @@ class Engine {
   void device_init();                 // throws LammpsError if no HIP device
   void upload();                      // host -> device (after read_data / scatter)
   void download();                    // device -> host (x, v, f, type, image, topology)
-  void reneighbor();                  // pbc + spatial sort + cell lists + neighbor list + bond table
+  void reneighbor(bool defer_check = false);   // pbc + spatial sort + cell lists + neighbor list + bond table
+  bool reneigh_pending = false;       // the build's overflow / error flags are published but not yet looked at
+  bool finish_reneighbor();           // waits for them; false = a list overflowed (nothing may depend on the lists yet)
+  void regrow_lists();                // grow the table and rebuild until every list fits
   bool decide();                      // Neighbor::decide (src/neighbor.cpp:1933-1948)
   void emulate_atom_sort();           // keep `crank` equal to the reference's local order (Atom::sort)
   std::vector<long> le_reneigh_step;  // next_reneighbor per fix

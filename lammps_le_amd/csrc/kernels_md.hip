@@ -352,6 +352,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
   int p = lb * BLOCK + threadIdx.x;
   if (lb >= A.nblocks || p >= A.n) return;
   if (which >= 0 && phase[p] != which) return;     // decomposed runs: this launch handles one phase of the step
+  // a list of the build this launch follows did not fit: the host has not looked yet (Engine::reneighbor defers the
+  // check behind this kernel); store nothing, it will rebuild and launch again
+  const int poisoned = flags[FLAG_NEIGH_OVERFLOW];
   double4 ri = A.pos[p];
   // streaming operands first: their latency overlaps the neighbor loop
   double a = vx[p], b = vy[p], c = vz[p];
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
     f1 += fdrag1 + fran1;
     f2 += fdrag2 + fran2;
   }
+  if (poisoned) return;
   const double dtfm = tt.dtfm[type];
   a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;          // final_integrate of this step
   if (NEXT) {

@@ -219,3 +219,16 @@ def test_restart_is_bit_continuous(tmp_path):
     from lammps_le_amd import LammpsError
     with pytest.raises(LammpsError, match="Cannot read_restart after simulation box is defined"):
         b.command("read_restart " + rfile)
+
+
+def test_neighbor_table_overflow_is_recovered(tmp_path, monkeypatch):
+    """A list that does not fit the ELL table: at setup the build is repeated at once; inside the loop the step kernel
+    has already been enqueued behind the build (deferred check) - it must leave the state untouched, and the host must
+    grow the table, rebuild and launch the step again.  Test hook: the table is shrunk to 4 entries before build 0."""
+    monkeypatch.setenv("LAMMPS_LE_TEST_OVERFLOW_AT", "0")
+    s = lattice_chain(4000, seed=11, jitter=0.08)
+    script = CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nrun 40\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert relerr(p.gather("x"), o.x()) < 1e-9 and relerr(p.gather("v"), o.v()) < 1e-8
+    assert p.stat("neigh_builds") == o.neigh_builds() and p.stat("neigh_pairs") == 2 * o.neigh_pairs()
