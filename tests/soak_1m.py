@@ -1,0 +1,27 @@
+"""Soak run: the default bench system (1M-bead lattice-start chain, dense LE parameters) for 100 000 steps.
+The lattice start relaxes slowly at the 100-bead scale; once extruded loops outgrow the straight runs (after ~60 000
+steps) extruder bonds get over-stretched: FENE warnings accumulate and the run ends with the reference's own
+`Bad FENE bond` abort (src/MOLECULE/bond_fene.cpp:84-86).  A 20k-bead system (short runs, fast relaxation) shows none
+of this in either engine: tests/soak_compare.py."""
+import os, sys, tempfile, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from lammps_le_amd import lammps
+from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
+n = 1000000
+sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
+data = os.path.join(tempfile.mkdtemp(), "data")
+write_data(data, sysd)
+script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01)
+lmp = lammps(cmdargs=["-screen", "none"])
+for ln in script.split("\n"):
+    lmp.command(ln)
+lmp.command("thermo 20000")
+t0 = time.time()
+for k in range(5):
+    try:
+        lmp.command("run 20000")
+    except Exception as e:
+        print("aborted in block %d: %s" % (k + 1, e)); break
+    print("step %d T %.4f epair %.4f emol %.4f press %.4f bonds %d fene_warn %d builds %d  (%.1f s)" % (
+        (k + 1) * 20000, lmp.get_thermo("temp"), lmp.get_thermo("epair"), lmp.get_thermo("emol"), lmp.get_thermo("press"),
+        lmp.get_thermo("bonds"), lmp.stat("fene_warnings"), lmp.stat("neigh_builds"), time.time() - t0), flush=True)
