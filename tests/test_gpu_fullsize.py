@@ -1,0 +1,78 @@
+"""BASELINE.json's full size (1M-bead chain, the default bench system) through properties that do not need the oracle
+(which takes two minutes per thousand steps there; tests/parity_1m.py does that comparison by hand): conservation
+laws of the NVE path, bit-reproducibility of a whole run, and the structural invariants of the bond topology after
+the three LE fixes have fired twice."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = 1000000
+
+
+@pytest.fixture(scope="module")
+def system(tmp_path_factory):
+    from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
+    sysd = lattice_chains(N, nchains=1, seed=1, barrier_every=200)
+    data = str(tmp_path_factory.mktemp("full") / "data.chain1m")
+    write_data(data, sysd)
+    script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01)
+    return sysd, script
+
+
+def _open(script, drop=()):
+    from lammps_le_amd import lammps
+    lmp = lammps(cmdargs=["-screen", "none"])
+    for ln in script.split("\n"):
+        if not any(ln.startswith(d) for d in drop):
+            lmp.command(ln)
+    return lmp
+
+
+def test_nve_conserves_momentum_and_energy(system):
+    """pair lj/cut + bond fene + fix nve only (no thermostat, no LE fixes): sum of m*v is conserved to rounding and the
+    total energy to the integrator's accuracy over 300 steps incl. ~30 rebuilds."""
+    sysd, script = system
+    lmp = _open(script, drop=("fix 2 ", "fix loop", "fix loading", "fix unloading", "thermo_style"))
+    lmp.command("run 200")                       # let the lattice start relax a little
+    p0 = lmp.gather("v").sum(axis=0)
+    e0 = lmp.get_thermo("etotal")
+    lmp.command("run 300")
+    p1 = lmp.gather("v").sum(axis=0)
+    e1 = lmp.get_thermo("etotal")
+    assert np.abs(p1 - p0).max() < 1e-7, (p0, p1)          # sums over 1e6 beads of O(1) velocities
+    assert abs(e1 - e0) < 2e-4 * abs(e0), (e0, e1)         # per-bead total energy, dt = 0.005
+    assert lmp.stat("neigh_builds") >= 10
+
+
+def test_run_is_bit_reproducible_and_topology_is_consistent(system):
+    """Two instances, same script, 2004 steps (both firings of every LE fix): identical to the last bit (no atomics in any
+    floating-point sum, deterministic list order).  Then the invariants of the bond topology."""
+    sysd, script = system
+    a, b = _open(script), _open(script)
+    a.command("run 2004")
+    b.command("run 2004")
+    for name in ("x", "v", "image", "num_bond", "bond_type", "bond_atom", "nspecial"):
+        assert np.array_equal(a.gather(name), b.gather(name)), name
+    nb, bt, ba = a.gather("num_bond"), a.gather("bond_type"), a.gather("bond_atom")
+    ns, sp = a.gather("nspecial"), a.gather("special")
+    n = len(nb)
+    # every stored bond is stored by both ends with the same type (newton_bond off storage)
+    half = set()
+    for i in np.nonzero(nb)[0]:
+        for m in range(nb[i]):
+            half.add((int(bt[i, m]), int(i) + 1, int(ba[i, m])))
+    assert all((t, j, i) in half for (t, i, j) in half)
+    ext = {(i, j) for (t, i, j) in half if t == 2 and i < j}
+    assert len(ext) > 20 and int(a.get_thermo("bonds")) == (n - 1) + len(ext) == len(half) // 2
+    # backbone intact, at most one extruder anchor per bead, anchors are backbone-interior beads
+    assert all((1, i, i + 1) in half for i in range(1, n))
+    ends = [i for e in ext for i in e]
+    assert len(ends) == len(set(ends)) and min(ends) > 1 and max(ends) < n
+    # the 1-2 special block of a bead = its bond partners
+    for i in list(range(0, n, 997)) + [e - 1 for e in ends]:
+        assert sorted(sp[i, :ns[i, 0]]) == sorted(int(ba[i, m]) for m in range(nb[i])), i + 1
+    # fix counters: extrusion moves preserve the bond count; loads minus unloads = extruders present
+    assert a.extract_fix("loading", 0, 1, 1) - a.extract_fix("unloading", 0, 1, 1) == len(ext)
