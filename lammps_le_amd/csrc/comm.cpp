@@ -60,7 +60,6 @@ struct Rccl {
 #undef SYM
   }
 } rccl;
-ncclComm_t g_comm = nullptr;
 #define NCCL_CHECK(x) do { int r_ = (x); if (r_ != 0) throw LammpsError(std::string("RCCL error: ") + rccl.GetErrorString(r_)); } while (0)
 }  // namespace
 
@@ -234,7 +233,9 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
     rccl.load();
     ncclUniqueId_ uid;
     memcpy(uid.internal, id, 128);
-    NCCL_CHECK(rccl.CommInitRank(&g_comm, world, uid, rank));
+    ncclComm_t c = nullptr;
+    NCCL_CHECK(rccl.CommInitRank(&c, world, uid, rank));
+    rccl_comm = c;
     backend = RCCL;
   } else if (backend_name == "local") {
     hub = hub_for(session);
@@ -247,7 +248,7 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
   } else throw LammpsError("unknown comm backend " + backend_name);
 }
 void Comm::finalize() {
-  if (backend == RCCL && g_comm) { rccl.CommDestroy(g_comm); g_comm = nullptr; }
+  if (backend == RCCL && rccl_comm) { rccl.CommDestroy((ncclComm_t)rccl_comm); rccl_comm = nullptr; }
   backend = NONE;
 }
 
@@ -275,7 +276,7 @@ void Comm::allgather_host(const void *send, void *recv, size_t bytes) {
   // RCCL: through a small device bounce buffer
   ensure_bounce(bytes * world + bytes);
   HIP_CHECK(hipMemcpyAsync(bounce, send, bytes, hipMemcpyHostToDevice, main_stream));
-  NCCL_CHECK(rccl.AllGather(bounce, (char *)bounce + bytes, bytes, ncclInt8, g_comm, main_stream));
+  NCCL_CHECK(rccl.AllGather(bounce, (char *)bounce + bytes, bytes, ncclInt8, (ncclComm_t)rccl_comm, main_stream));
   HIP_CHECK(hipMemcpyAsync(recv, (char *)bounce + bytes, bytes * world, hipMemcpyDeviceToHost, main_stream));
   HIP_CHECK(hipStreamSynchronize(main_stream));
 }
@@ -311,7 +312,7 @@ long Comm::allreduce_host_max(long v) {
 // device collectives
 void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
   if (backend == NONE) return;
-  if (backend == RCCL) { NCCL_CHECK(rccl.AllReduce(dev, dev, n, ncclInt32, ncclMax, g_comm, st)); return; }
+  if (backend == RCCL) { NCCL_CHECK(rccl.AllReduce(dev, dev, n, ncclInt32, ncclMax, (ncclComm_t)rccl_comm, st)); return; }
   std::vector<int> h(n), all((size_t)world * n);
   HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
@@ -322,7 +323,7 @@ void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
 }
 void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_t bytes) {
   if (backend == NONE) { HIP_CHECK(hipMemcpyAsync(recv_dev, send_dev, bytes, hipMemcpyDeviceToDevice, st)); return; }
-  if (backend == RCCL) { NCCL_CHECK(rccl.AllGather(send_dev, recv_dev, bytes, ncclInt8, g_comm, st)); return; }
+  if (backend == RCCL) { NCCL_CHECK(rccl.AllGather(send_dev, recv_dev, bytes, ncclInt8, (ncclComm_t)rccl_comm, st)); return; }
   if (backend == LOCAL) {
     std::vector<Msg> ss, rr;
     for (int r = 0; r < world; r++) {
@@ -345,8 +346,8 @@ void Comm::exchange(hipStream_t st, const std::vector<Msg> &sends, const std::ve
   if (backend == NONE) return;
   if (backend == RCCL) {
     NCCL_CHECK(rccl.GroupStart());
-    for (auto &m : sends) if (m.bytes) NCCL_CHECK(rccl.Send(m.dev, m.bytes, ncclInt8, m.peer, g_comm, st));
-    for (auto &m : recvs) if (m.bytes) NCCL_CHECK(rccl.Recv(m.dev, m.bytes, ncclInt8, m.peer, g_comm, st));
+    for (auto &m : sends) if (m.bytes) NCCL_CHECK(rccl.Send(m.dev, m.bytes, ncclInt8, m.peer, (ncclComm_t)rccl_comm, st));
+    for (auto &m : recvs) if (m.bytes) NCCL_CHECK(rccl.Recv(m.dev, m.bytes, ncclInt8, m.peer, (ncclComm_t)rccl_comm, st));
     NCCL_CHECK(rccl.GroupEnd());
     return;
   }

@@ -29,6 +29,7 @@ struct Comm {
   void barrier();
 
  private:
+  void *rccl_comm = nullptr;             // ncclComm_t of THIS engine instance
   std::shared_ptr<struct LocalHub> hub;   // backend "local": ranks are engine instances (threads) of one process
   std::string shm_dir;
   std::vector<long> shm_sent, shm_rcvd;
