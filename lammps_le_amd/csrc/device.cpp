@@ -113,7 +113,7 @@ void dev_free(DeviceState &d) {
   dfree(d.rng_pool[0]); dfree(d.rng_pool[1]); dfree(d.rng_wstate); d.rng_W = 0; d.rng_batch_raw[0] = d.rng_batch_raw[1] = 0;
   dfree(d.xt); dfree(d.xht);
   dfree(d.gcell_start); dfree(d.gcell_count); dfree(d.sendlist[0]); dfree(d.sendlist[1]); dfree(d.migbuf[0]);
-  dfree(d.migbuf[1]); dfree(d.migin); dfree(d.sendbuf); dfree(d.recvbuf); dfree(d.gdest); dfree(d.gtag_in); dfree(d.gone); dfree(d.phase);
+  dfree(d.migbuf[1]); dfree(d.migin); dfree(d.sendbuf); dfree(d.recvbuf); dfree(d.gdest); dfree(d.gtag_in); dfree(d.gone); dfree(d.phase); dfree(d.sendslot);
   dfree(d.gather_send); d.gather_recv = nullptr; d.gather_cap = 0;
   for (int k = 0; k < 16; k++) dfree(d.le_i[k]);
   for (int k = 0; k < 2; k++) dfree(d.le_d[k]);

@@ -36,7 +36,8 @@ enum FlagSlot {
   FLAG_AUX = 10,
   FLAG_SPECIAL_ASYM = 11,
   FLAG_RECV_UP = 12,    // decomposition: counts received from the upper / lower slab neighbour
-  FLAG_RECV_DN = 13,   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
+  FLAG_RECV_DN = 13,
+  FLAG_SEND_BOTH = 14,  // decomposition: some bead is in both send lists (slab barely two shells thick)   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
   NFLAGS = 16
 };
 enum DevErr {
@@ -139,6 +140,9 @@ struct DeviceState {
   // halo / compute overlap: beads that are sent to a neighbour or read a ghost form phase 1 of a step, the rest
   // (phase 0) is computed while the ghost positions of the next step travel on comm_stream
   unsigned char *phase = nullptr;                       // [npad]
+  int *sendslot = nullptr;                              // [npad] slot of a border bead in its send list (bit 30 = upper list), -1 = none
+  bool sendslot_fallback = false;                       // some bead sits in both send lists: pack with the kernel instead
+  bool packed_ahead = false;                            // the step kernel already wrote the border beads' new positions into sendbuf
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_phase1 = nullptr, ev_halo = nullptr;
   bool halo_inflight = false;                           // ev_halo guards ghost slots that comm_stream is filling

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
                                                       const int *__restrict__ num_bond,
                                                       const int *__restrict__ bond_atom, int *__restrict__ list_dn,
                                                       int *__restrict__ list_up, int *__restrict__ flags,
-                                                      unsigned char *__restrict__ phase) {
+                                                      unsigned char *__restrict__ phase, int *__restrict__ sendslot) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   bool active = p < n;
   double zc = active ? zrel_slab(pos[p].z, slab_lo, box) : 0.0;
@@ -137,6 +137,10 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
   int su = wave_append(up, &flags[FLAG_COUNT_B]);
   if (dn) list_dn[sd] = p;
   if (up) list_up[su] = p;
+  // the fused step kernel packs a border bead's new position itself (no pack launch per step); a slab is at least two
+  // ghost shells thick, so a bead is in at most one list - if it ever is in both, -2 makes the halo fall back to packing
+  if (active) sendslot[p] = (dn && up) ? -2 : dn ? sd : up ? (su | (1 << 30)) : -1;
+  if (dn && up) flags[FLAG_SEND_BOTH] = 1;
   // sent beads are phase 1: a bead with a ghost NEIGHBOR lies within the pair shell of a face and is therefore sent;
   // the bond-table kernel adds the few beads whose bond partner is a ghost
   if (active) phase[p] = (dn || up) ? 1 : 0;
@@ -279,6 +283,7 @@ void dd_alloc(DeviceState &d, int world) {
   al(d.gdest, np * sizeof(int));
   al(d.gone, np * sizeof(int));
   al(d.phase, np);
+  al(d.sendslot, np * sizeof(int));
   if (!d.comm_stream) {
     HIP_CHECK(hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking));
     HIP_CHECK(hipEventCreateWithFlags(&d.ev_phase1, hipEventDisableTiming));
@@ -293,13 +298,14 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   hipStream_t st = d.stream;
   dd_halo_wait(d);
   d.halo_ahead = false;
+  d.packed_ahead = false;
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
   const double width = d.box.prd[2] / P;   // the SAME expression on every rank and in Engine::upload (owner of a bead)
   int n = d.n, nb = std::max(1, (n + BLOCK - 1) / BLOCK);
   const int migcap = (int)(((size_t)d.npad * MIG_W / 4) / MIG_W);
   // counts travel rank-to-rank on the device and reach the host together with this rank's own counters: one
   // host synchronisation per phase (migration, borders) instead of three
-  const unsigned counters = (1u << FLAG_COUNT_A) | (1u << FLAG_COUNT_B) | (1u << FLAG_NDRAW);
+  const unsigned counters = (1u << FLAG_COUNT_A) | (1u << FLAG_COUNT_B) | (1u << FLAG_NDRAW) | (1u << FLAG_SEND_BOTH);
   auto swap_counts = [&](int slot_dn, int slot_up) {
     comm.exchange(st, {{d.flags + slot_dn, sizeof(int), dn_rank}, {d.flags + slot_up, sizeof(int), up_rank}},
                   {{d.flags + FLAG_RECV_UP, sizeof(int), up_rank}, {d.flags + FLAG_RECV_DN, sizeof(int), dn_rank}});
@@ -333,10 +339,11 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   // ---- 3. borders ----
   hipLaunchKernelGGL(k_dd_borders, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width,
                      std::min(sqrt(cutneighsq), d.cutghost), d.cutghost, d.bpa, d.tag, d.map, d.num_bond, d.bond_atom,
-                     d.sendlist[0], d.sendlist[1], d.flags, d.phase);
+                     d.sendlist[0], d.sendlist[1], d.flags, d.phase, d.sendslot);
   swap_counts(FLAG_COUNT_A, FLAG_COUNT_B);
   d.nsend[0] = d.flags_h[FLAG_COUNT_A];
   d.nsend[1] = d.flags_h[FLAG_COUNT_B];
+  d.sendslot_fallback = d.flags_h[FLAG_SEND_BOTH] != 0;
   d.nrecv[0] = d.flags_h[FLAG_RECV_DN];
   d.nrecv[1] = d.flags_h[FLAG_RECV_UP];
   d.nghost = d.nrecv[0] + d.nrecv[1];
@@ -383,9 +390,10 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
 void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, double4 *dst) {
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
   int nsall = d.nsend[0] + d.nsend[1];
-  if (nsall)
+  if (nsall && !d.packed_ahead)
     hipLaunchKernelGGL(k_dd_pack, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
                        d.sendlist[0], d.sendlist[1], src, d.sendbuf);
+  d.packed_ahead = false;
   comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
                      {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank}},
                 {{d.recvbuf, (size_t)d.nrecv[1] * sizeof(double4), up_rank},

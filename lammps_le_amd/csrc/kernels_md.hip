@@ -153,6 +153,10 @@ struct ForceArgs {
   double margin;         // beads farther than this from every box face need no minimum image
   int nn_limit;          // diagnostics only (LAMMPS_LE_NN_LIMIT): cap on neighbors visited per bead
   int diag;              // diagnostics only (LAMMPS_LE_DIAG_STEP): extra launch with parts off, see launch_step
+  // decomposed runs: border beads also write their new position into the halo send buffer (no pack launch per step)
+  const int *sendslot;
+  double4 *sendbuf;
+  int nsend0;
 };
 
 // one pair term.  The hot loop is written for issue-bound FP64 on CDNA4: branch-free minimum image
@@ -387,6 +391,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
     a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;        // initial_integrate of the next step
     ri.x += dtv * a; ri.y += dtv * b; ri.z += dtv * c;
     pos_next[p] = ri;
+    if (A.sendslot) {
+      const int sl = A.sendslot[p];
+      if (sl >= 0) A.sendbuf[(sl & ((1 << 30) - 1)) + ((sl >> 30) ? A.nsend0 : 0)] = ri;
+    }
     if (check) {
       double4 h = xhold[p];
       double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
@@ -436,6 +444,7 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   static int lim = getenv("LAMMPS_LE_NN_LIMIT") ? atoi(getenv("LAMMPS_LE_NN_LIMIT")) : (1 << 30);
   A.nn_limit = lim;
   A.diag = 0;
+  A.sendslot = nullptr; A.sendbuf = nullptr; A.nsend0 = 0;
   return A;
 }
 void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool eflag, bool has_pair) {
@@ -453,6 +462,10 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
                  hipEvent_t ev_stop, int which, bool swap_buffers) {
   ForceArgs A = force_args(d, sl);
+  if (d.dd && next && d.sendslot && !d.sendslot_fallback) {
+    A.sendslot = d.sendslot; A.sendbuf = d.sendbuf; A.nsend0 = d.nsend[0];
+    d.packed_ahead = true;
+  }
   int grid = xcd_grid(A.nblocks);
   // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
   // the same clock rocprofv3 --kernel-trace reports
