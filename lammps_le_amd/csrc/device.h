@@ -37,12 +37,13 @@ enum FlagSlot {
   FLAG_SPECIAL_ASYM = 11,
   FLAG_RECV_UP = 12,    // decomposition: counts received from the upper / lower slab neighbour
   FLAG_RECV_DN = 13,
-  FLAG_SEND_BOTH = 14,  // decomposition: some bead is in both send lists (slab barely two shells thick)   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
+  FLAG_SEND_BOTH = 14,
+  FLAG_GHOST_MIXED = 15, // decomposition: ghosts from below and above are not two separate blocks of the cell order  // decomposition: some bead is in both send lists (slab barely two shells thick)   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
   NFLAGS = 16
 };
 enum DevErr {
   ERR_NONE = 0, ERR_BAD_FENE = 1, ERR_BOND_MISSING = 2, ERR_EXT_MULTI = 3, ERR_BPA = 4,
-  ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8
+  ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8, ERR_GHOST_ORDER = 9
 };
 
 // Neighbor cells are cutneigh wide in y and z and cutneigh / CELL_XSPLIT wide in x (the fastest index of the cell
@@ -142,6 +143,7 @@ struct DeviceState {
   unsigned char *phase = nullptr;                       // [npad]
   int *sendslot = nullptr;                              // [npad] slot of a border bead in its send list (bit 30 = upper list), -1 = none
   bool sendslot_fallback = false;                       // some bead sits in both send lists: pack with the kernel instead
+  bool direct_recv = false;                             // send lists are in the receiver's sorted ghost order: a halo lands in place
   bool packed_ahead = false;                            // the step kernel already wrote the border beads' new positions into sendbuf
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_phase1 = nullptr, ev_halo = nullptr;

@@ -367,6 +367,7 @@ static void check_device_error(Engine *e, DeviceState &d) {
     case ERR_COUNT_MISMATCH: msg = "Numbers of created and broken bonds are not equal"; break;
     case ERR_NONFINITE: msg = "Non-numeric atom coords - simulation unstable"; break;
     case ERR_SPECIAL_SCRATCH: msg = "Special list size exceeded in fix bond/create"; break;
+    case ERR_GHOST_ORDER: msg = "internal: ghost blocks of a slab interleave (slab thinner than two ghost shells?)"; break;
   }
   (void)e;
   throw LammpsError(msg);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
   // the fused step kernel packs a border bead's new position itself (no pack launch per step); a slab is at least two
   // ghost shells thick, so a bead is in at most one list - if it ever is in both, -2 makes the halo fall back to packing
   if (active) sendslot[p] = (dn && up) ? -2 : dn ? sd : up ? (su | (1 << 30)) : -1;
-  if (dn && up) flags[FLAG_SEND_BOTH] = 1;
+  if (dn && up) flags[FLAG_ERROR] = ERR_GHOST_ORDER;
   // sent beads are phase 1: a bead with a ghost NEIGHBOR lies within the pair shell of a face and is therefore sent;
   // the bond-table kernel adds the few beads whose bond partner is a ghost
   if (active) phase[p] = (dn || up) ? 1 : 0;
@@ -214,6 +214,31 @@ __global__ __launch_bounds__(BLOCK) void k_dd_ghost_place(int m, int base, const
   tag[base + s] = t;
   gdest[i] = s;
   map[t] = base + s;
+}
+// The ghosts that came from below fill the low z layers of the local grid and those from above the high ones, so
+// the cell-sorted ghost array is [from below | from above].  Each sender is told where its k-th border bead ended up
+// inside its block (`rel`); it then reorders its send list accordingly, and from then on a halo message is received
+// STRAIGHT into the ghost slots: no unpack kernel per step.  arrival layout of the first exchange: [above | below].
+__global__ __launch_bounds__(BLOCK) void k_dd_ghost_rel(int m, int nabove, int nbelow, const int *__restrict__ gdest,
+                                                        int *__restrict__ rel, int *__restrict__ flags) {
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  int s = gdest[i];
+  bool above = i < nabove;                     // arrival block
+  int r = above ? s - nbelow : s;               // slot inside its sorted block
+  if (r < 0 || r >= (above ? nabove : nbelow)) { flags[FLAG_ERROR] = ERR_GHOST_ORDER; r = 0; }
+  rel[i] = r;
+}
+__global__ __launch_bounds__(BLOCK) void k_dd_reorder_sends(int m0, int m1, const int *__restrict__ rel,
+                                                            const int *__restrict__ list0, const int *__restrict__ list1,
+                                                            int *__restrict__ new0, int *__restrict__ new1,
+                                                            int *__restrict__ sendslot) {
+  int k = blockIdx.x * BLOCK + threadIdx.x;
+  if (k >= m0 + m1) return;
+  bool up = k >= m0;
+  int p = up ? list1[k - m0] : list0[k], r = rel[k];
+  (up ? new1 : new0)[r] = p;
+  if (sendslot[p] >= 0) sendslot[p] = up ? (r | (1 << 30)) : r;
 }
 __global__ __launch_bounds__(BLOCK) void k_fill_int(int n, int *a, int v) {
   int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -343,7 +368,7 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   swap_counts(FLAG_COUNT_A, FLAG_COUNT_B);
   d.nsend[0] = d.flags_h[FLAG_COUNT_A];
   d.nsend[1] = d.flags_h[FLAG_COUNT_B];
-  d.sendslot_fallback = d.flags_h[FLAG_SEND_BOTH] != 0;
+  d.sendslot_fallback = false;
   d.nrecv[0] = d.flags_h[FLAG_RECV_DN];
   d.nrecv[1] = d.flags_h[FLAG_RECV_UP];
   d.nghost = d.nrecv[0] + d.nrecv[1];
@@ -381,6 +406,30 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
     hipLaunchKernelGGL(k_dd_ghost_place, dim3(gb), dim3(BLOCK), 0, st, m, n, gperm, d.recvbuf, tagrecv, d.pos, d.tag,
                        d.gdest, d.map, d.posf);
   }
+  // ---- 4b. tell the senders the sorted order of what they sent; they reorder their lists (direct receive from now on)
+  d.direct_recv = false;
+  static const bool no_direct = getenv("LAMMPS_LE_NO_DIRECT_RECV") != nullptr;
+  if (!no_direct) {
+    int *rel_out = d.le_i[10], *rel_in = d.le_i[11];
+    if (m) hipLaunchKernelGGL(k_dd_ghost_rel, dim3(gb), dim3(BLOCK), 0, st, m, d.nrecv[1], d.nrecv[0], d.gdest, rel_out, d.flags);
+    // my "from above" block came from up_rank's lower list, my "from below" block from dn_rank's upper list
+    comm.exchange(st, {{rel_out, (size_t)d.nrecv[1] * sizeof(int), up_rank},
+                       {rel_out + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(int), dn_rank}},
+                  {{rel_in, (size_t)d.nsend[0] * sizeof(int), dn_rank},
+                   {rel_in + d.nsend[0], (size_t)d.nsend[1] * sizeof(int), up_rank}});
+    // (slabs are at least two ghost shells thick, so the two blocks cannot interleave and no bead is in both send
+    // lists; FLAG_GHOST_MIXED / FLAG_SEND_BOTH would be an internal error and are reported with the build's flags)
+    {
+      int *new0 = d.le_i[12], *new1 = d.le_i[13];
+      if (nsall) {
+        hipLaunchKernelGGL(k_dd_reorder_sends, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
+                           rel_in, d.sendlist[0], d.sendlist[1], new0, new1, d.sendslot);
+        HIP_CHECK(hipMemcpyAsync(d.sendlist[0], new0, (size_t)d.nsend[0] * sizeof(int), hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d.sendlist[1], new1, (size_t)d.nsend[1] * sizeof(int), hipMemcpyDeviceToDevice, st));
+      }
+      d.direct_recv = true;
+    }
+  }
   // ---- 5. lists ----
   launch_lists(d, cutneighsq, sl, has_pair);
 }
@@ -394,6 +443,13 @@ void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, dou
     hipLaunchKernelGGL(k_dd_pack, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
                        d.sendlist[0], d.sendlist[1], src, d.sendbuf);
   d.packed_ahead = false;
+  if (d.direct_recv) {   // the senders pack in my sorted ghost order [from below | from above]: receive in place
+    comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
+                       {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank}},
+                  {{dst + d.n + d.nrecv[0], (size_t)d.nrecv[1] * sizeof(double4), up_rank},
+                   {dst + d.n, (size_t)d.nrecv[0] * sizeof(double4), dn_rank}});
+    return;
+  }
   comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
                      {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank}},
                 {{d.recvbuf, (size_t)d.nrecv[1] * sizeof(double4), up_rank},
