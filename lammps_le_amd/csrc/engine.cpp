@@ -646,14 +646,20 @@ void Engine::print_thermo(const ThermoRow &r) {
 // Verlet::setup (src/verlet.cpp:87-156)
 // ---------------------------------------------------------------------------------------------
 void Engine::setup() {
+  const bool trace = getenv("LAMMPS_LE_TRACE_RUN") != nullptr;
+  double s0 = wall();
   reneighbor();                       // pbc + (spatial sort) + lists; ncalls reset below
+  double s1 = wall();
   neigh_builds = 0;
   if (sortfreq > 0) emulate_atom_sort();
   compute_forces(true);
   FixLangevin *lg = the_langevin(this);
   for (auto &f : fixes) f->setup();
   if (lg) langevin_post_force(this, lg, false);   // FixLangevin::setup -> post_force (:372-373)
+  double s2 = wall();
   last_thermo = eval_thermo();
+  double s3 = wall();
+  if (trace) fprintf(stderr, "[setup] reneighbor %.2f ms, forces+fixes (enqueue) %.2f ms, thermo %.2f ms\n", 1e3 * (s1 - s0), 1e3 * (s2 - s1), 1e3 * (s3 - s2));
   thermo_log.push_back(last_thermo);
   print_thermo_header();
   print_thermo(last_thermo);
@@ -747,8 +753,12 @@ void Engine::iterate(long nsteps) {
 
 void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
+  const bool trace = getenv("LAMMPS_LE_TRACE_RUN") != nullptr;
+  double tr0 = wall();
   init();
+  double tr1 = wall();
   if (!dev_current || !dev || !dev->pos) upload();
+  double tr2 = wall();
   le_reneigh_step.assign(fixes.size(), -1);
   dev->le_snapshot = 0;
   for (auto &f : fixes) if (f->force_reneighbor) dev->le_snapshot = 1;
@@ -762,6 +772,7 @@ void Engine::run(long nsteps) {
   double t0 = wall();
   iterate(nsteps);
   loop_time = wall() - t0;
+  if (trace) fprintf(stderr, "[run %ld] init %.2f ms, upload %.2f ms, setup %.2f ms, loop %.2f ms\n", nsteps, 1e3 * (tr1 - tr0), 1e3 * (tr2 - tr1), 1e3 * (t0 - tr2), 1e3 * loop_time);
   kstat_ms = 0.0; kstat_n = 0;
   for (size_t k = 0; k < dev->ev_used; k++) {
     float ms = 0.f;
