@@ -167,3 +167,25 @@ def test_rccl_bindings_on_one_rank():
     from lammps_le_amd import library_path
     lib = ctypes.CDLL(library_path())
     assert lib.lammps_le_rccl_selftest() == 0
+
+
+def test_eight_slabs_with_the_bench_script(tmp_path):
+    """The shape of the 8-GPU scaling run: eight z-slabs, `comm_modify cutoff 5.0`, the bench input with the three LE
+    fixes firing - here on 500k beads (slabs 10.5 thick, just above two ghost shells) with all ranks on the test GPU."""
+    from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains
+    from systems import OracleScript
+    n = 500000
+    sysd = lattice_chains(n, nchains=1, seed=3, barrier_every=200)
+    script = CHAIN_INPUT.format(data="data.chain", n1=10, left=2, right=3, tp=0.5, lr="4", nload=10, pload=0.2) + "run 34\n"
+    osc = OracleScript(dict(sysd))
+    for ln in script.split("\n"):
+        if not ln.startswith("thermo_style"):
+            osc.line(ln)
+    o = osc.o
+    r = run_ranks_local(8, sysd, script.replace("thermo_style", "#thermo_style"), tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+    assert len([b for b in o.bond_set() if b[0] == 2]) > 10
+    for fid in ("loop", "loading", "unloading"):
+        assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1]
+    assert np.abs(r["x"] - o.x()).max() < 1e-7 and (r["image"] == o.image()).all()
+    assert r["builds"][0] == o.neigh_builds() and r["neigh_pairs"][0] == 2 * o.neigh_pairs()
