@@ -122,7 +122,8 @@ def test_le_fixes_across_slabs(tmp_path):
     assert len([b for b in o.bond_set() if b[0] == 2]) > 20
 
 
-@pytest.mark.parametrize("world,n,overlap", [(2, 6000, 0), (4, 40000, 0), (5, 40000, 1), (2, 6000, 1), (3, 40000, 1)])
+@pytest.mark.parametrize("world,n,overlap", [(2, 6000, 0), (4, 40000, 0), (5, 40000, 1), (2, 6000, 1), (3, 40000, 1),
+                                              (6, 70000, 0), (7, 100000, 1)])
 def test_md_across_slabs_in_process(tmp_path, world, n, overlap, monkeypatch):
     """4 and 5 slabs (interior ranks with two different neighbours) over the in-process transport; overlap=1 also
     splits every step into the beads that touch ghosts and the interior, with the halo exchange of the next step
