@@ -102,10 +102,19 @@ thermo 100
 timestep 0.012
 run 100
 """
-    p = run_product(script, s, tmp_path)
+    log = os.path.join(str(tmp_path), "log.chain")
+    p = run_product(script, s, tmp_path, cmdargs=("-screen", "none", "-log", log))
     gold = t["thermo"][1]
     for key, g in zip(("temp", "epair", "emol", "etotal", "press"), gold[1:]):
-        assert abs(p.get_thermo(key) - g) <= 1e-6 * abs(g) + 5e-8, (key, p.get_thermo(key), g)
+        assert float("%.8g" % p.get_thermo(key)) == g, (key, p.get_thermo(key), g)        # every printed digit
+    # the printed thermo block, byte for byte as in bench/log.6Oct16.chain.fixed.icc.1:47-49 (src/thermo.cpp formats)
+    p.close()
+    text = open(log).read()
+    assert "Step Temp E_pair E_mol TotEng Press \n" in text
+    assert "       0   0.97029772   0.44484087    20.494523    22.394765    4.6721833 \n" in text
+    assert "     100    0.9729966    0.4361122    20.507698     22.40326    4.6548819 \n" in text
+    assert "Loop time of " in text and " on 1 procs for 100 steps with 32000 atoms" in text
+    p = run_product(script, s, tmp_path)
     assert p.stat("neigh_builds") == t["builds"]
     assert p.stat("neigh_pairs") == 2 * t["neighbors"]
     assert n == 32000
