@@ -365,6 +365,8 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
   } else if (cmd == "write_data") {
     need(1);
     write_data(arg[0]);
+  } else if (cmd == "velocity") {
+    velocity(arg);
   } else if (cmd == "write_restart") {
     need(1);
     write_restart(arg[0]);
@@ -662,6 +664,220 @@ void Engine::build_special() {
   snprintf(buf, sizeof buf, "Finding 1-2 1-3 1-4 neighbors ...\n  special bond factors lj:    %-8g %-8g %-8g\n  %d = max # of special neighbors\n",
            special_lj[1], special_lj[2], special_lj[3], (int)maxall);
   say(buf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// velocity group-ID create|set|scale|zero   (src/velocity.cpp:52-139 command, :162-405 create, :409-580 set,
+// :586-625 scale, :704-728 zero, :733-830 rescale / zero_momentum / zero_rotation, :836-905 options)
+// Host-side, once per script: the master copies are in tag order, the sums run in the reference's local order
+// (`crank`) so that the result agrees with a 1-rank reference run to the last bits that order can influence.
+// RanPark = src/random_park.cpp:41-127 (Park-Miller minimal standard, polar gaussian, coordinate hash for loop geom).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RanPark {
+  int seed, save = 0;
+  double second = 0.0;
+  explicit RanPark(int s) : seed(s) {}
+  double uniform() {
+    int k = seed / 127773;
+    seed = 16807 * (seed - k * 127773) - 2836 * k;
+    if (seed < 0) seed += 2147483647;
+    return (1.0 / 2147483647) * seed;
+  }
+  double gaussian() {
+    if (save) { save = 0; return second; }
+    double v1, v2, rsq;
+    do {
+      v1 = 2.0 * uniform() - 1.0;
+      v2 = 2.0 * uniform() - 1.0;
+      rsq = v1 * v1 + v2 * v2;
+    } while (rsq >= 1.0 || rsq == 0.0);
+    double fac = sqrt(-2.0 * log(rsq) / rsq);
+    second = v1 * fac;
+    save = 1;
+    return v2 * fac;
+  }
+  void reset(int ibase, const double *coord) {   // Jenkins one-at-a-time over the seed and the 24 coordinate bytes
+    unsigned int hash = 0;
+    auto eat = [&](const void *p, int n) {
+      const char *s = (const char *)p;
+      for (int i = 0; i < n; i++) { hash += s[i]; hash += (hash << 10); hash ^= (hash >> 6); }
+    };
+    eat(&ibase, sizeof(int));
+    eat(coord, 3 * sizeof(double));
+    hash += (hash << 3); hash ^= (hash >> 11); hash += (hash << 15);
+    seed = hash & 0x7ffffff;
+    if (!seed) seed = 1;
+    for (int i = 0; i < 5; i++) uniform();
+    save = 0;
+  }
+};
+}  // namespace
+
+void Engine::velocity(std::vector<std::string> &arg) {
+  if (arg.size() < 2) throw LammpsError("Illegal velocity command");
+  if (!box_exist) throw LammpsError("Velocity command before simulation box is defined");
+  if (natoms == 0) throw LammpsError("Velocity command with no atoms existing");
+  if (arg[0] != "all") throw LammpsError("MI355X engine: only group all is supported");
+  const std::string style = arg[1];
+  size_t nfix;
+  if (style == "create") nfix = 4;
+  else if (style == "set") nfix = 5;
+  else if (style == "scale") nfix = 3;
+  else if (style == "zero") nfix = 3;
+  else if (style == "ramp") throw LammpsError("MI355X engine: velocity ramp is not supported");
+  else throw LammpsError("Illegal velocity command");
+  if (arg.size() < nfix) throw LammpsError("Illegal velocity command");
+  int dist = 0, sum = 0, mom = 1, rot = 0, loop = 0;   // defaults: src/velocity.cpp:69-76
+  for (size_t k = nfix; k < arg.size(); k += 2) {
+    if (k + 1 >= arg.size()) throw LammpsError("Illegal velocity command");
+    const std::string &key = arg[k], &val = arg[k + 1];
+    auto yesno = [&]() { if (val == "yes") return 1; if (val == "no") return 0; throw LammpsError("Illegal velocity command"); };
+    if (key == "dist") { if (val == "uniform") dist = 0; else if (val == "gaussian") dist = 1; else throw LammpsError("Illegal velocity command"); }
+    else if (key == "sum") sum = yesno();
+    else if (key == "mom") mom = yesno();
+    else if (key == "rot") rot = yesno();
+    else if (key == "loop") { if (val == "all") loop = 0; else if (val == "local") loop = 1; else if (val == "geom") loop = 2; else throw LammpsError("Illegal velocity command"); }
+    else if (key == "units") { if (val != "box" && val != "lattice") throw LammpsError("Illegal velocity command"); }
+    else if (key == "temp" || key == "bias" || key == "rigid") throw LammpsError("MI355X engine: velocity " + key + " is not supported");
+    else throw LammpsError("Illegal velocity command");
+  }
+  for (int t = 1; t <= ntypes; t++)
+    if (!mass_set[t]) throw LammpsError("Not all per-type masses are set");   // src/atom.cpp check_mass
+  download();   // the run before this command may have left the newest state on the device
+
+  // the reference's local order (1 rank): order[r] = tag-1 of the bead at local index r
+  std::vector<int> order(natoms);
+  for (int i = 0; i < natoms; i++) order[crank[i]] = i;
+  auto m_of = [&](int i) { return mass[type[i]]; };
+  auto temperature = [&]() {   // compute temp, group all: src/compute_temp.cpp:60-101, extra_dof = 3 (src/compute.cpp:91)
+    double t = 0.0;
+    for (int r = 0; r < natoms; r++) {
+      int i = order[r];
+      t += (v[3 * i] * v[3 * i] + v[3 * i + 1] * v[3 * i + 1] + v[3 * i + 2] * v[3 * i + 2]) * m_of(i);
+    }
+    double dof = 3.0 * natoms - 3.0;
+    double tfactor = dof > 0.0 ? mvv2e / (dof * boltz) : 0.0;
+    return t * tfactor;
+  };
+  auto masstotal = [&]() { double m = 0.0; for (int r = 0; r < natoms; r++) m += m_of(order[r]); return m; };
+  auto zero_momentum = [&]() {   // src/velocity.cpp:756-780, src/group.cpp:1125-1163
+    double mt = masstotal(), p[3] = {0, 0, 0};
+    for (int r = 0; r < natoms; r++) { int i = order[r]; double mo = m_of(i); for (int k = 0; k < 3; k++) p[k] += v[3 * i + k] * mo; }
+    if (mt > 0.0) for (int k = 0; k < 3; k++) p[k] /= mt;
+    for (int i = 0; i < natoms; i++) for (int k = 0; k < 3; k++) v[3 * i + k] -= p[k];
+  };
+  auto zero_rotation = [&]() {   // src/velocity.cpp:786-830, src/group.cpp:1018-1062, :1426-1459, :1583-1625, :1682-1728
+    double mt = masstotal(), xcm[3] = {0, 0, 0}, L[3] = {0, 0, 0}, I[3][3] = {{0}};
+    auto unwrap = [&](int i, double *u) { for (int k = 0; k < 3; k++) u[k] = x[3 * i + k] + image[3 * i + k] * box.prd[k]; };
+    double u[3];
+    for (int r = 0; r < natoms; r++) { int i = order[r]; unwrap(i, u); for (int k = 0; k < 3; k++) xcm[k] += u[k] * m_of(i); }
+    if (mt > 0.0) for (int k = 0; k < 3; k++) xcm[k] /= mt;
+    for (int r = 0; r < natoms; r++) {
+      int i = order[r];
+      unwrap(i, u);
+      double dx = u[0] - xcm[0], dy = u[1] - xcm[1], dz = u[2] - xcm[2], mo = m_of(i);
+      L[0] += mo * (dy * v[3 * i + 2] - dz * v[3 * i + 1]);
+      L[1] += mo * (dz * v[3 * i] - dx * v[3 * i + 2]);
+      L[2] += mo * (dx * v[3 * i + 1] - dy * v[3 * i]);
+      I[0][0] += mo * (dy * dy + dz * dz); I[1][1] += mo * (dx * dx + dz * dz); I[2][2] += mo * (dx * dx + dy * dy);
+      I[0][1] -= mo * dx * dy; I[1][2] -= mo * dy * dz; I[0][2] -= mo * dx * dz;
+    }
+    I[1][0] = I[0][1]; I[2][1] = I[1][2]; I[2][0] = I[0][2];
+    double det = I[0][0] * I[1][1] * I[2][2] + I[0][1] * I[1][2] * I[2][0] + I[0][2] * I[1][0] * I[2][1] -
+                 I[0][0] * I[1][2] * I[2][1] - I[0][1] * I[1][0] * I[2][2] - I[2][0] * I[1][1] * I[0][2];
+    if (!(det > 1.0e-6)) throw LammpsError("MI355X engine: velocity rot/zero angular needs a non-singular inertia tensor");
+    double inv[3][3];
+    inv[0][0] = I[1][1] * I[2][2] - I[1][2] * I[2][1];
+    inv[0][1] = -(I[0][1] * I[2][2] - I[0][2] * I[2][1]);
+    inv[0][2] = I[0][1] * I[1][2] - I[0][2] * I[1][1];
+    inv[1][0] = -(I[1][0] * I[2][2] - I[1][2] * I[2][0]);
+    inv[1][1] = I[0][0] * I[2][2] - I[0][2] * I[2][0];
+    inv[1][2] = -(I[0][0] * I[1][2] - I[0][2] * I[1][0]);
+    inv[2][0] = I[1][0] * I[2][1] - I[1][1] * I[2][0];
+    inv[2][1] = -(I[0][0] * I[2][1] - I[0][1] * I[2][0]);
+    inv[2][2] = I[0][0] * I[1][1] - I[0][1] * I[1][0];
+    double w[3];
+    for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) inv[a][b] /= det; }
+    for (int a = 0; a < 3; a++) w[a] = inv[a][0] * L[0] + inv[a][1] * L[1] + inv[a][2] * L[2];
+    for (int i = 0; i < natoms; i++) {
+      unwrap(i, u);
+      double dx = u[0] - xcm[0], dy = u[1] - xcm[1], dz = u[2] - xcm[2];
+      v[3 * i] -= w[1] * dz - w[2] * dy;
+      v[3 * i + 1] -= w[2] * dx - w[0] * dz;
+      v[3 * i + 2] -= w[0] * dy - w[1] * dx;
+    }
+  };
+  auto rescale = [&](double t_old, double t_new) {
+    if (t_old == 0.0) throw LammpsError("Attempting to rescale a 0.0 temperature");
+    double factor = sqrt(t_new / t_old);
+    for (auto &c : v) c *= factor;
+  };
+  auto num = [&](const std::string &s) {
+    char *end = nullptr;
+    double val = strtod(s.c_str(), &end);
+    if (end == s.c_str() || *end) throw LammpsError("Expected floating point parameter instead of '" + s + "' in input script or data file");
+    return val;
+  };
+
+  if (style == "create") {
+    double t_desired = num(arg[2]);
+    int seed = atoi(arg[3].c_str());
+    if (seed <= 0) throw LammpsError("Illegal velocity create command");
+    std::vector<double> vhold;
+    if (sum) vhold = v;
+    auto draw3 = [&](RanPark &rn, double *o) {
+      if (dist == 0) for (int k = 0; k < 3; k++) o[k] = rn.uniform() - 0.5;
+      else for (int k = 0; k < 3; k++) o[k] = rn.gaussian();
+    };
+    double o[3];
+    if (loop == 0) {          // loop all: one stream walked in ID order
+      RanPark rn(seed);
+      for (int i = 0; i < natoms; i++) {
+        draw3(rn, o);
+        double factor = 1.0 / sqrt(m_of(i));
+        for (int k = 0; k < 3; k++) v[3 * i + k] = o[k] * factor;
+      }
+    } else if (loop == 1) {   // loop local, as on rank 0 of a 1-rank run: seed + me, 100 warm-up draws, local order
+      RanPark rn(seed);
+      for (int k = 0; k < 100; k++) rn.uniform();
+      for (int r = 0; r < natoms; r++) {
+        int i = order[r];
+        draw3(rn, o);
+        double factor = 1.0 / sqrt(m_of(i));
+        for (int k = 0; k < 3; k++) v[3 * i + k] = o[k] * factor;
+      }
+    } else {                  // loop geom: stream re-seeded from each bead's coordinates
+      RanPark rn(1);
+      for (int i = 0; i < natoms; i++) {
+        rn.reset(seed, &x[3 * i]);
+        draw3(rn, o);
+        double factor = 1.0 / sqrt(m_of(i));
+        for (int k = 0; k < 3; k++) v[3 * i + k] = o[k] * factor;
+      }
+    }
+    if (mom) zero_momentum();
+    if (rot) zero_rotation();
+    rescale(temperature(), t_desired);
+    if (sum) for (size_t k = 0; k < v.size(); k++) v[k] += vhold[k];
+  } else if (style == "set") {
+    for (int k = 0; k < 3; k++) {
+      const std::string &s = arg[2 + k];
+      if (s.rfind("v_", 0) == 0) throw LammpsError("MI355X engine: velocity set with variables is not supported");
+      if (s == "NULL") continue;
+      double val = num(s);
+      for (int i = 0; i < natoms; i++) { if (sum) v[3 * i + k] += val; else v[3 * i + k] = val; }
+    }
+  } else if (style == "scale") {
+    double t_desired = num(arg[2]);
+    rescale(temperature(), t_desired);
+  } else {   // zero
+    if (arg[2] == "linear") zero_momentum();
+    else if (arg[2] == "angular") zero_rotation();
+    else throw LammpsError("Illegal velocity command");
+  }
+  host_current = true;
+  dev_current = false;   // the next run uploads the new velocities
 }
 
 // write_data (src/write_data.cpp): header, Masses, Atoms (with image flags), Velocities, Bonds (each once)

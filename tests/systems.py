@@ -217,6 +217,8 @@ class OracleScript:
                 o.fix_ex_unload(int(p[0]), int(p[1]), float(p[2]), fid=fid, **kw)
             else:
                 raise ValueError("oracle script: unknown fix " + style)
+        elif c == "velocity":
+            self._velocity(a)
         elif c == "timestep":
             o.timestep(float(a[0]))
         elif c == "thermo":
@@ -225,6 +227,22 @@ class OracleScript:
             o.run(int(a[0]))
         else:
             raise ValueError("oracle script: unknown command " + c)
+
+    def _velocity(self, a):
+        """velocity all create T seed [dist ..] [mom ..] [rot ..] [loop ..] [sum ..]  (oracle/velocity_oracle.py)"""
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        from velocity_oracle import velocity_create
+        assert a[0] == "all" and a[1] == "create", "oracle script: velocity create only"
+        kw = dict(zip(a[4::2], a[5::2]))
+        o = self.o
+        box = np.asarray(self.sys["box"])
+        m = np.asarray(self.sys["mass"])[o.types() - 1]
+        v = velocity_create(o.x(), o.image(), box[:, 1] - box[:, 0], m, float(a[2]), int(a[3]),
+                            dist=kw.get("dist", "uniform"), mom=kw.get("mom", "yes") == "yes",
+                            rot=kw.get("rot", "no") == "yes", loop=kw.get("loop", "all"),
+                            vold=o.v() if kw.get("sum", "no") == "yes" else None, order=o.local_order() - 1)
+        o.set_v(v)
 
     def run(self, script):
         for ln in script.split("\n"):

@@ -77,6 +77,21 @@ def test_langevin_stream_parity(tmp_path):
     assert p.stat("neigh_builds") == o.neigh_builds()
 
 
+def test_velocity_create_between_runs(tmp_path):
+    """`velocity all create` before the first run and again between two runs (the second call has to fetch the
+    newest state from the device, replace v and upload it again); oracle driven from the same script."""
+    s = lattice_chain(3000, seed=13)
+    s["v"] = np.zeros_like(s["v"])
+    script = CHAIN_SCRIPT + ("velocity all create 1.0 4928459 dist gaussian\nfix 1 all nve\nthermo 20\nrun 40\n"
+                             "velocity all create 0.6 8723 loop local\nrun 30\n")
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert relerr(p.gather("x"), o.x()) < 1e-9
+    assert relerr(p.gather("v"), o.v()) < 1e-8
+    assert abs(p.get_thermo("temp") - o.thermo()[0]) < 1e-9
+    assert p.stat("neigh_builds") == o.neigh_builds()
+
+
 def test_chain_benchmark_golden(tmp_path):
     """BASELINE configs[0]: bench/in.chain settings on bench/data.chain; the published 1-rank log's
     step-0 / step-100 thermo (reference default atom_modify sort 1000 -> Atom::sort order emulated)."""

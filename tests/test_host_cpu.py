@@ -142,3 +142,90 @@ def test_ranmars_host_matches_oracle_and_jump():
         for skip in (5, 4096, 12345, 28999):
             fn(seed, skip, 1000, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
             assert np.array_equal(out, ref[skip:skip + 1000]), (seed, skip)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# velocity command (SURVEY 8f widening: the reference's scripts create their start velocities this way)
+def _velocity_case(tmp_path, n, cmd, shuffle=False, v0=False):
+    from lammps_le_amd import lammps
+    types = 1 + (np.arange(n) % 3 == 0).astype(np.int32)
+    s = lattice_chain(n, types=types)
+    s["mass"] = [1.0, 2.5]
+    s["image"] = np.random.RandomState(5).randint(-1, 2, size=(n, 3)).astype(np.int32)
+    if not v0:
+        s["v"] = np.zeros_like(s["v"])
+    path = os.path.join(str(tmp_path), "data.chain")
+    write_data(path, s)
+    lmp = lammps(cmdargs=["-screen", "none"])
+    for ln in CHAIN_SCRIPT.split("\n"):
+        lmp.command(ln.replace("data.chain", path))
+    lmp.command(cmd)
+    return lmp, s, np.asarray(s["mass"])[types - 1]
+
+
+def test_ranpark_published_check_value():
+    """Park & Miller 1988: the minimal standard generator started at 1 holds 1043618065 after 10000 draws."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from velocity_oracle import RanPark
+    r = RanPark(1)
+    for _ in range(10000):
+        r.uniform()
+    assert r.seed == 1043618065
+
+
+@pytest.mark.parametrize("opts", ["", "dist gaussian", "loop local", "loop geom dist gaussian", "mom no rot yes",
+                                  "rot yes dist gaussian loop local"])
+def test_velocity_create_matches_the_restatement(tmp_path, opts):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from velocity_oracle import velocity_create
+    n = 700
+    lmp, s, m = _velocity_case(tmp_path, n, "velocity all create 1.3 4928459 " + opts)
+    v = lmp.gather("v").reshape(n, 3)
+    kw = dict(dist="gaussian" if "gaussian" in opts else "uniform", mom="mom no" not in opts, rot="rot yes" in opts,
+              loop="local" if "local" in opts else "geom" if "geom" in opts else "all")
+    prd = s["box"][:, 1] - s["box"][:, 0]
+    # the engine holds the coordinates it parsed from the data file: hash those, not the pre-print values
+    x = lmp.gather("x").reshape(n, 3)
+    ref = velocity_create(x, s["image"], prd, m, 1.3, 4928459, **kw)
+    assert np.abs(v - ref).max() < 1e-13
+    # the properties the command promises
+    T = (m[:, None] * v * v).sum() / (3 * n - 3)
+    assert abs(T - 1.3) < 1e-12
+    if kw["mom"]:
+        assert np.abs((m[:, None] * v).sum(axis=0)).max() < 1e-10
+    if kw["rot"]:
+        xu = x + s["image"] * prd
+        xcm = (m[:, None] * xu).sum(axis=0) / m.sum()
+        assert np.abs((m[:, None] * np.cross(xu - xcm, v)).sum(axis=0)).max() < 1e-8
+
+
+def test_velocity_set_scale_zero_sum(tmp_path):
+    from lammps_le_amd import LammpsError
+    n = 300
+    lmp, s, m = _velocity_case(tmp_path, n, "velocity all set 0.5 NULL -0.25", v0=True)
+    v = lmp.gather("v").reshape(n, 3)
+    assert (v[:, 0] == 0.5).all() and (v[:, 2] == -0.25).all() and np.allclose(v[:, 1], s["v"][:, 1], rtol=0, atol=1e-15)
+    lmp.command("velocity all set 0.5 0.5 0.5 sum yes")
+    v2 = lmp.gather("v").reshape(n, 3)
+    assert np.abs(v2 - (v + 0.5)).max() == 0.0
+    lmp.command("velocity all zero linear")
+    v3 = lmp.gather("v").reshape(n, 3)
+    assert np.abs((m[:, None] * v3).sum(axis=0)).max() < 1e-10
+    lmp.command("velocity all scale 0.7")
+    v4 = lmp.gather("v").reshape(n, 3)
+    assert abs((m[:, None] * v4 * v4).sum() / (3 * n - 3) - 0.7) < 1e-12
+    lmp.command("velocity all create 2.0 77 sum yes")
+    v5 = lmp.gather("v").reshape(n, 3)
+    w = v5 - v4
+    assert abs((m[:, None] * w * w).sum() / (3 * n - 3) - 2.0) < 1e-9
+    with pytest.raises(LammpsError, match="Illegal velocity create command"):     # src/velocity.cpp:167
+        lmp.command("velocity all create 1.0 0")
+    with pytest.raises(LammpsError, match="Illegal velocity command"):
+        lmp.command("velocity all create 1.0 5 dist cauchy")
+    with pytest.raises(LammpsError, match="Illegal velocity command"):
+        lmp.command("velocity all spin 1.0")
+    lmp.command("velocity all set 0 0 0")
+    with pytest.raises(LammpsError, match="Attempting to rescale a 0.0 temperature"):   # src/velocity.cpp:735
+        lmp.command("velocity all scale 1.0")
