@@ -36,6 +36,8 @@ WORKLOADS = {
     "chains10x100k": (1000000, 10, 200, 1000, 1000, 0.01, 0.5),
     "chain100k": (100000, 1, 0, 17500, 7000, 0.001, 1.0),     # README.md:17,33-34 parameters
     "chain32k": (32000, 1, 0, 1000, 1000, 0.01, 1.0),
+    "chain250k": (250000, 1, 200, 1000, 1000, 0.01, 0.5),
+    "chain500k": (500000, 1, 200, 1000, 1000, 0.01, 0.5),
     "chain8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5),        # per-GPU size of the 8 x 1M weak-scaling config, on one GPU
 }
 

@@ -66,7 +66,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   double expect = (double)n / vol * 4.18879020478639 * cutneigh * cutneigh * cutneigh;
   int mn = (int)(expect * 1.5) + 24;
   dalloc(d.numneigh, np);
-  dalloc(d.bpart, (size_t)bpa * np);
+  dalloc(d.bpart, (size_t)std::max(bpa, 1) * np);   // >= 1 row: the step kernel loads before it masks
   dev_alloc_neigh(d, mn);
   dalloc(d.pairtab, (size_t)6 * (ntypes + 1) * (ntypes + 1));
   d.nred_blocks = (n + 255) / 256 + 8;
@@ -129,16 +129,19 @@ void dev_free(DeviceState &d) {
 // The host does not call hipStreamSynchronize for these hand-overs (its wake-up costs 30-50 us, twice per rebuild):
 // the kernel writes a sequence number behind the flags and the host spins on the mapped page.
 __global__ void k_publish_flags(int *__restrict__ flags, int *__restrict__ host, unsigned reset, int seq) {
-  // ONE thread writes the flags and then, behind a system-scope release, the sequence number the host spins on: the
-  // host must never see the new number next to old flags (flags and number sit in different 64-byte sectors of the
-  // mapped page, and stores of different lanes have no order among themselves)
-  if (threadIdx.x != 0) return;
-  for (int k = 0; k < NFLAGS; k++) {
+  // ONE wavefront: lane k writes flag k, then - behind the barrier and a system-scope release, which on this
+  // hardware waits for every outstanding store of the wave - lane 0 writes the sequence number the host spins on.
+  // The host must never see the new number next to old flags: flags and number sit in different 64-byte sectors
+  // of the mapped page, and stores of one instruction have no order among themselves, hence the separate store.
+  // (Sixteen serial stores from one lane cost 10 us over PCIe; this is one round trip.)
+  const int k = threadIdx.x;
+  if (k < NFLAGS) {
     int v = flags[k];
     __hip_atomic_store(&host[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((reset >> k) & 1u) flags[k] = 0;
   }
-  __hip_atomic_store(&host[NFLAGS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  if (k == 0) __hip_atomic_store(&host[NFLAGS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void publish_flags(DeviceState &d, unsigned reset) {
   const int seq = ++d.flags_seq;

@@ -16,6 +16,9 @@
 namespace lmp_le {
 
 constexpr int BLOCK = 256;
+constexpr int BOND_AHEAD = 3;             // bond slots whose partner loads are issued ahead of the neighbor loop
+constexpr int AHEAD_MAX_BEADS = 64000;   // k_step: partner / first-stage loads issued ahead of their use up to this size
+constexpr int LPB4_MAX_BEADS = 50000;   // k_step: four lanes per bead up to this many (owned) beads, see k_step
 #define TWO_1_3 1.2599210498948732
 
 // XCD-aware block remap (cdna_hip_programming.md T1): blocks b and b+8 share an XCD, so give
@@ -151,6 +154,8 @@ struct ForceArgs {
   double u_cutsq, u_lj1, u_lj2, u_lj3, u_lj4, u_off;
   int has_sb;            // some special weight is neither 0 nor 1 -> list entries carry special bits
   double margin;         // beads farther than this from every box face need no minimum image
+  int maxrow;            // highest list row a lane may touch before it knows its count: (maxneigh - 1 - sub) / LPB >= this
+  int bprow;             // last row of the bond-partner table (max(bpa, 1) - 1)
   int nn_limit;          // diagnostics only (LAMMPS_LE_NN_LIMIT): cap on neighbors visited per bead
   int diag;              // diagnostics only (LAMMPS_LE_DIAG_STEP): extra launch with parts off, see launch_step
   // decomposed runs: border beads also write their new position into the halo send buffer (no pack launch per step)
@@ -158,6 +163,35 @@ struct ForceArgs {
   double4 *sendbuf;
   int nsend0;
 };
+
+// reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp from the IEEE quotient 1/x; an IEEE divide is ~35 instructions)
+__device__ __forceinline__ double rcp_nr(double x) {
+#pragma clang fp contract(fast)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  r = r * (2.0 - x * r);
+  return r;
+}
+
+// bond coefficients in LDS, one row per bond type, with the per-type constants of BondFENE::compute folded once per
+// block: a by-value table indexed by a per-lane type is read through memory (a dependent load for every coefficient)
+constexpr int BT_W = 8;   // style, K, 1/R0^2 (fene) or r0 (harmonic), 48 eps, sigma^2, 2^(1/3) sigma^2, R0^2, eps
+__device__ __forceinline__ void fill_bond_table(const BondTable &bt, double *__restrict__ s_bt) {
+  const int t = threadIdx.x;
+  if (t <= MAXTYPES) {
+    const int st = bt.style[t];
+    const double K = bt.p0[t], R0 = bt.p1[t], epsb = bt.p2[t], sigb = bt.p3[t];
+    double *row = s_bt + t * BT_W;
+    row[0] = (double)st;
+    row[1] = K;
+    row[2] = (st == 1) ? 1.0 / (R0 * R0) : R0;
+    row[3] = 48.0 * epsb;
+    row[4] = sigb * sigb;
+    row[5] = TWO_1_3 * sigb * sigb;
+    row[6] = R0 * R0;
+    row[7] = epsb;
+  }
+}
 
 // one pair term.  The hot loop is written for issue-bound FP64 on CDNA4: branch-free minimum image
 // (v_rndne), reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp from the reference's IEEE divide),
@@ -205,19 +239,57 @@ __device__ __forceinline__ void pair_term(const ForceArgs &A, const Box &box, co
   }
 }
 
-template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB>
+// everything a bead's force needs that is addressed by the bead's own index alone: fetched in ONE batch at the top of
+// the kernel, before any of it is used.  A small system's step time is the chain of dependent loads one wavefront
+// walks (every level costs a trip to the memory-side cache: each kernel starts with a cold L2), so the chain is kept
+// at own data -> partners' positions -> next list stage.
+struct BeadPre {
+  int nall;                // list length
+  int j0, j1, j2, j3;      // first list stage (rows below maxneigh always exist; masked once the length is known)
+  int eb[BOND_AHEAD];      // first bond slots (rows clamped to the table; masked by the bond count)
+};
+template <bool HAS_PAIR, int LPB, bool AHEAD>
+__device__ __forceinline__ BeadPre bead_preload(const ForceArgs &A, int p, int sub) {
+  BeadPre L;
+  if (!AHEAD) {            // throughput-bound sizes: loads stay where they are consumed (measured faster at 1M beads)
+    L.nall = HAS_PAIR ? A.numneigh[p] : 0;
+    L.j0 = L.j1 = L.j2 = L.j3 = p;
+#pragma unroll
+    for (int u = 0; u < BOND_AHEAD; u++) L.eb[u] = -1;
+    return L;
+  }
+  if (HAS_PAIR) {
+    const size_t st = (size_t)LPB * A.npad;
+    const int *col = A.neigh + p + (size_t)sub * A.npad;
+    L.nall = A.numneigh[p];
+    L.j0 = col[0]; L.j1 = col[min(1, A.maxrow) * st]; L.j2 = col[min(2, A.maxrow) * st]; L.j3 = col[min(3, A.maxrow) * st];
+  } else {
+    L.nall = 0; L.j0 = L.j1 = L.j2 = L.j3 = p;
+  }
+#pragma unroll
+  for (int u = 0; u < BOND_AHEAD; u++) L.eb[u] = A.bpart[(size_t)min(sub + u * LPB, A.bprow) * A.npad + p];
+  return L;
+}
+
+// LPB = lanes per bead: lane `sub` of a bead's LPB lanes takes list entries sub, sub + LPB, ... (see k_step)
+template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB, int LPB, bool AHEAD, bool DIAGP = false>
 __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, const double *__restrict__ s_tab, int p,
-                                          const double4 &ri, double &fxi, double &fyi, double &fzi,
-                                          double (&e)[14]) {
-  const int itype = (int)ri.w, npad = A.npad;
-  const int nn = (A.diag & 2) ? 0 : min(A.numneigh[p], A.nn_limit);
-  const int *col = A.neigh + p;
+                                          int sub, const BeadPre &L, int nall, const double4 &ri, double &fxi,
+                                          double &fyi, double &fzi, double (&e)[14]) {
+  const int itype = (int)ri.w;
+  const size_t npad = (size_t)LPB * A.npad;                                             // stride between a lane's entries
+  const int *col = A.neigh + p + (size_t)sub * A.npad;
   // software pipeline, 4 neighbors per stage: while the four position gathers of the current stage are in
   // flight the (coalesced) index loads of the next stage are issued, so a stage costs one exposed round trip.
   // Lists are consumed in groups of 4; slots past the end are predicated off (index = own bead, cached).
-  int j0 = (0 < nn) ? col[0] : p, j1 = (1 < nn) ? col[(size_t)npad] : p, j2 = (2 < nn) ? col[(size_t)2 * npad] : p,
-      j3 = (3 < nn) ? col[(size_t)3 * npad] : p;
+  const int nn = (LPB == 1) ? nall : (nall > sub ? (nall - sub + LPB - 1) / LPB : 0);   // entries of this lane
+  int j0, j1, j2, j3;
+  if (AHEAD) { j0 = (0 < nn) ? L.j0 : p; j1 = (1 < nn) ? L.j1 : p; j2 = (2 < nn) ? L.j2 : p; j3 = (3 < nn) ? L.j3 : p; }
+  else { j0 = (0 < nn) ? col[0] : p; j1 = (1 < nn) ? col[npad] : p; j2 = (2 < nn) ? col[2 * npad] : p; j3 = (3 < nn) ? col[3 * npad] : p; }
   for (int k = 0; k < nn; k += 4) {
+    if (DIAGP && (A.diag & 8)) {          // diagnostics: same arithmetic, gathers replaced by coalesced loads
+      j0 = min(p + k + 1, A.n - 1); j1 = min(p + k + 2, A.n - 1); j2 = min(p + k + 3, A.n - 1); j3 = min(p + k + 4, A.n - 1);
+    }
     double4 r0 = A.pos[j0 & NEIGH_MASK], r1 = A.pos[j1 & NEIGH_MASK], r2 = A.pos[j2 & NEIGH_MASK],
             r3 = A.pos[j3 & NEIGH_MASK];
     const int c0 = j0, c1 = j1, c2 = j2, c3 = j3;
@@ -233,14 +305,26 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
   }
 }
 
-template <bool EFLAG, bool HAS_PAIR>
+template <bool EFLAG, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD>
 __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &bt, const Box &box,
-                                           const double *__restrict__ s_tab, int p, const double4 &ri,
-                                           double &fxi, double &fyi, double &fzi, double (&e)[14],
-                                           int *__restrict__ flags) {
+                                           const double *__restrict__ s_tab, const double *__restrict__ s_bt, int p,
+                                           int sub, const BeadPre &L, const double4 &ri, double &fxi, double &fyi,
+                                           double &fzi, double (&e)[14], int *__restrict__ flags) {
   const int npad = A.npad;
   const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
   const double px = box.prd[0], py = box.prd[1], pz = box.prd[2];
+  const int nbond = (DIAG && (A.diag & 1)) ? 0 : A.bpa;
+  const int nall = (DIAG && (A.diag & 2)) ? 0 : min(L.nall, A.nn_limit);
+  // bonded partners of the first BOND_AHEAD slots: positions requested together with the first list stage
+  int eb_a[BOND_AHEAD];
+  double4 rb_a[BOND_AHEAD];
+  if (AHEAD) {
+#pragma unroll
+    for (int u = 0; u < BOND_AHEAD; u++) {
+      eb_a[u] = (sub + u * LPB < nbond) ? L.eb[u] : -1;
+      rb_a[u] = A.pos[eb_a[u] >= 0 ? (eb_a[u] & BOND_IDX_MASK) : p];
+    }
+  }
   if (HAS_PAIR) {
     // wave-uniform choice: a wavefront whose 64 beads all sit deeper than `margin` inside the box skips
     // the minimum-image arithmetic (cell order makes most wavefronts interior)
@@ -249,22 +333,32 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
                     ri.z > box.lo[2] + m && ri.z < box.hi[2] - m;
     bool all_in = __all(interior);
     if (A.uniform && !A.has_sb) {
-      if (all_in) pair_loop<EFLAG, false, true, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
-      else pair_loop<EFLAG, true, true, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+      if (all_in) pair_loop<EFLAG, false, true, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
+      else pair_loop<EFLAG, true, true, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
     } else if (!A.has_sb) {
-      if (all_in) pair_loop<EFLAG, false, false, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
-      else pair_loop<EFLAG, true, false, false>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+      if (all_in) pair_loop<EFLAG, false, false, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
+      else pair_loop<EFLAG, true, false, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
     } else {
-      pair_loop<EFLAG, true, false, true>(A, box, s_tab, p, ri, fxi, fyi, fzi, e);
+      pair_loop<EFLAG, true, false, true, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
     }
   }
-  for (int m = 0; m < ((A.diag & 1) ? 0 : A.bpa); m++) {
-    int eb = A.bpart[(size_t)m * npad + p];
+  for (int u = 0, m = sub; m < nbond; m += LPB, u++) {
+    int eb;
+    double4 rj;
+    if (AHEAD && u < BOND_AHEAD) {
+      // (static indexing keeps the prefetched values in registers)
+      eb = eb_a[0]; rj = rb_a[0];
+#pragma unroll
+      for (int w = 1; w < BOND_AHEAD; w++) if (u == w) { eb = eb_a[w]; rj = rb_a[w]; }
+    } else {
+      eb = A.bpart[(size_t)m * npad + p];
+      rj = A.pos[eb >= 0 ? (eb & BOND_IDX_MASK) : p];
+    }
     if (eb < 0) continue;
     int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
-    int style = bt.style[type];
+    const double *row = s_bt + type * BT_W;
+    const int style = (int)row[0];
     if (style == 0) continue;
-    double4 rj = A.pos[q];
     double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
     if (delx > hx) delx -= px; else if (delx < -hx) delx += px;
     if (dely > hy) dely -= py; else if (dely < -hy) dely += py;
@@ -272,9 +366,9 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
     double rsq = delx * delx + dely * dely + delz * delz;
     double fbond, ebond = 0.0;
     if (style == 1) {
-      double K = bt.p0[type], R0 = bt.p1[type], epsb = bt.p2[type], sigb = bt.p3[type];
-      double r0sq = R0 * R0;
-      double rlogarg = 1.0 - rsq / r0sq;
+      // BondFENE::compute with its four divisions done as products with reciprocals (each <= 1 ulp from the quotient)
+      const double K = row[1], inv_r0sq = row[2];
+      double rlogarg = 1.0 - rsq * inv_r0sq;
       double sr6 = 0.0;
       if (rlogarg < 0.1) {
         // each bond is visited from both ends: count the warning once (lower index)
@@ -282,20 +376,21 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
         if (rlogarg <= -3.0) flags[FLAG_ERROR] = ERR_BAD_FENE;
         rlogarg = 0.1;
       }
-      fbond = -K / rlogarg;
-      if (rsq < TWO_1_3 * sigb * sigb) {
-        double sr2 = sigb * sigb / rsq;
+      fbond = -K * rcp_nr(rlogarg);
+      if (rsq < row[5]) {
+        const double rinv = rcp_nr(rsq);
+        double sr2 = row[4] * rinv;
         sr6 = sr2 * sr2 * sr2;
-        fbond += 48.0 * epsb * sr6 * (sr6 - 0.5) / rsq;
+        fbond += row[3] * sr6 * (sr6 - 0.5) * rinv;
       }
       if (EFLAG) {
-        ebond = -0.5 * K * r0sq * log(rlogarg);
-        if (rsq < TWO_1_3 * sigb * sigb) ebond += 4.0 * epsb * sr6 * (sr6 - 1.0) + epsb;
+        ebond = -0.5 * K * row[6] * log(rlogarg);
+        if (rsq < row[5]) ebond += 4.0 * row[7] * sr6 * (sr6 - 1.0) + row[7];
       }
     } else {
       double r = sqrt(rsq);
-      double dr = r - bt.p1[type];
-      double rk = bt.p0[type] * dr;
+      double dr = r - row[2];
+      double rk = row[1] * dr;
       fbond = (r > 0.0) ? -2.0 * rk / r : 0.0;
       if (EFLAG) ebond = rk * dr;
     }
@@ -314,10 +409,11 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
                                                  double *__restrict__ fy, double *__restrict__ fz,
                                                  double *__restrict__ partial, int *__restrict__ flags) {
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
-  if (HAS_PAIR && !(A.uniform && !A.has_sb)) {   // one coefficient set and no fractional special weights: scalars, no table
+  __shared__ double s_bt[(MAXTYPES + 1) * BT_W];
+  fill_bond_table(bt, s_bt);
+  if (HAS_PAIR && !(A.uniform && !A.has_sb))     // one coefficient set and no fractional special weights: scalars, no table
     for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
-    __syncthreads();
-  }
+  __syncthreads();
   int lb = logical_block(A.nblocks);
   int p = lb * BLOCK + threadIdx.x;
   double e[14];
@@ -325,8 +421,9 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
   for (int k = 0; k < 14; k++) e[k] = 0.0;
   if (lb < A.nblocks && p < A.n) {
     double4 ri = A.pos[p];
+    const BeadPre L = bead_preload<HAS_PAIR, 1, true>(A, p, 0);
     double fxi = 0.0, fyi = 0.0, fzi = 0.0;
-    bead_force<EFLAG, HAS_PAIR>(A, bt, box, s_tab, p, ri, fxi, fyi, fzi, e, flags);
+    bead_force<EFLAG, HAS_PAIR, 1, false, true>(A, bt, box, s_tab, s_bt, p, 0, L, ri, fxi, fyi, fzi, e, flags);
     fx[p] = fxi; fy[p] = fyi; fz[p] = fzi;
   }
   if (EFLAG && lb < A.nblocks) block_reduce_store<14>(e, partial, lb, 0);
@@ -337,7 +434,12 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
 //   -> [NEXT: first half-kick + drift of step n+1 (FixNVE::initial_integrate) into the second position
 //       buffer + the skin/2 displacement test of Neighbor::check_distance]
 // x, v never round-trip through HBM between these stages and f is only stored when a later kernel needs it.
-template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR>
+// LPB (lanes per bead) = 4 is the small-system variant: below ~10^5 beads the kernel is not bound by throughput but by
+// the chain of dependent loads ONE wavefront walks (index -> position, five stages deep for 18 neighbors, then the
+// bonds one after the other: 10 us at 32k beads whatever the chip could stream).  Four lanes share a bead, each takes
+// every fourth list entry and every fourth bond slot, the partial forces meet in a two-step butterfly and lane 0
+// integrates: the chain shrinks to one or two stages.
+template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD>
 __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
                                                 const int *__restrict__ tag, const int *__restrict__ crank,
                                                 const uint32_t *__restrict__ draws, double *__restrict__ vx,
@@ -348,29 +450,41 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
                                                 int check, int *__restrict__ flags,
                                                 const unsigned char *__restrict__ phase, int which) {
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
-  if (HAS_PAIR && !(A.uniform && !A.has_sb)) {   // one coefficient set and no fractional special weights: scalars, no table
+  __shared__ double s_bt[(MAXTYPES + 1) * BT_W];
+  fill_bond_table(bt, s_bt);
+  if (HAS_PAIR && !(A.uniform && !A.has_sb))     // one coefficient set and no fractional special weights: scalars, no table
     for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
-    __syncthreads();
-  }
+  __syncthreads();
   int lb = logical_block(A.nblocks);
-  int p = lb * BLOCK + threadIdx.x;
-  if (lb >= A.nblocks || p >= A.n) return;
+  const int sub = (LPB == 1) ? 0 : (int)(threadIdx.x % LPB);
+  int p = lb * (BLOCK / LPB) + threadIdx.x / LPB;
+  if (lb >= A.nblocks || p >= A.n) return;         // (the LPB lanes of a bead always leave together)
   if (which >= 0 && phase[p] != which) return;     // decomposed runs: this launch handles one phase of the step
   // a list of the build this launch follows did not fit: the host has not looked yet (Engine::reneighbor defers the
   // check behind this kernel); store nothing, it will rebuild and launch again
-  const int poisoned = flags[FLAG_NEIGH_OVERFLOW];
+  // ---- level 0: all loads addressed by p, issued back to back before any of them is used ----
   double4 ri = A.pos[p];
-  // streaming operands first: their latency overlaps the neighbor loop
   double a = vx[p], b = vy[p], c = vz[p];
+  int t = 0;
+  if (LANGEVIN) t = tag[p];
+  const BeadPre L = bead_preload<HAS_PAIR, LPB, AHEAD>(A, p, sub);
+  double4 hold = ri;
+  if (AHEAD && NEXT && check) hold = xhold[p];
+  const int poisoned = flags[FLAG_NEIGH_OVERFLOW];
+  // ---- level 1: the draws (by canonical rank), then - inside bead_force - the partners' positions ----
   uint32_t d0 = 0, d1 = 0, d2 = 0;
-  if (LANGEVIN && !(A.diag & 4)) {
-    int t = tag[p];
+  if (LANGEVIN && !(DIAG && (A.diag & 4))) {
     int rank = IDENT ? (t - 1) : crank[t];
     d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
   }
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
   double e[14];
-  bead_force<false, HAS_PAIR>(A, bt, box, s_tab, p, ri, f0, f1, f2, e, flags);
+  bead_force<false, HAS_PAIR, LPB, DIAG, AHEAD>(A, bt, box, s_tab, s_bt, p, sub, L, ri, f0, f1, f2, e, flags);
+  if (LPB > 1) {
+#pragma unroll
+    for (int o = 1; o < LPB; o <<= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); }
+    if (sub) return;
+  }
   const int type = (int)ri.w;
   if (LANGEVIN) {
     double gamma1 = tt.g1[type], gamma2 = tt.g2[type];
@@ -396,14 +510,14 @@ __global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box b
       if (sl >= 0) A.sendbuf[(sl & ((1 << 30) - 1)) + ((sl >> 30) ? A.nsend0 : 0)] = ri;
     }
     if (check) {
-      double4 h = xhold[p];
+      const double4 h = AHEAD ? hold : xhold[p];
       double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
-      if (dx * dx + dy * dy + dz * dz > triggersq && !A.diag) flags[FLAG_MOVED] = 1;
+      if (dx * dx + dy * dy + dz * dz > triggersq && !(DIAG && A.diag)) flags[FLAG_MOVED] = 1;
     }
   } else {
     fx[p] = f0; fy[p] = f1; fz[p] = f2;
   }
-  if (A.diag & 64) { if (a == 1.2345e300) vx[p] = a; return; }   // diagnostic launch: v is left alone (the value is still computed)
+  if (DIAG && (A.diag & 64)) { if (a == 1.2345e300) vx[p] = a; return; }   // diagnostic launch: v is left alone (the value is still computed)
   vx[p] = a; vy[p] = b; vz[p] = c;
 }
 
@@ -443,6 +557,8 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.margin = d.cutneigh;
   static int lim = getenv("LAMMPS_LE_NN_LIMIT") ? atoi(getenv("LAMMPS_LE_NN_LIMIT")) : (1 << 30);
   A.nn_limit = lim;
+  A.maxrow = d.maxneigh - 1;
+  A.bprow = std::max(d.bpa, 1) - 1;
   A.diag = 0;
   A.sendslot = nullptr; A.sendbuf = nullptr; A.nsend0 = 0;
   return A;
@@ -466,24 +582,32 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
     A.sendslot = d.sendslot; A.sendbuf = d.sendbuf; A.nsend0 = d.nsend[0];
     d.packed_ahead = true;
   }
+  // lanes per bead: 4 while the launch is latency-bound (few wavefronts per SIMD), 1 once it is throughput-bound
+  static const int lpb_env = getenv("LAMMPS_LE_LPB") ? atoi(getenv("LAMMPS_LE_LPB")) : 0;
+  static const int lpb_max_n = getenv("LAMMPS_LE_LPB_MAX_N") ? atoi(getenv("LAMMPS_LE_LPB_MAX_N")) : LPB4_MAX_BEADS;
+  const bool lpb4 = lpb_env ? lpb_env == 4 : d.n <= lpb_max_n;
+  static const int ahead_max_n = getenv("LAMMPS_LE_AHEAD_MAX_N") ? atoi(getenv("LAMMPS_LE_AHEAD_MAX_N")) : AHEAD_MAX_BEADS;
+  const bool ahead = d.n <= ahead_max_n;
+  if (lpb4) { A.nblocks = (d.n + BLOCK / 4 - 1) / (BLOCK / 4); A.maxrow = (d.maxneigh - 4) / 4; }
   int grid = xcd_grid(A.nblocks);
   // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
   // the same clock rocprofv3 --kernel-trace reports
-#define STP(L, N, I, P)                                                                                      \
-  hipExtLaunchKernelGGL((k_step<L, N, I, P>), dim3(grid), dim3(BLOCK), 0, d.stream, ev_start, ev_stop, 0, A, bt, \
+#define STPL(L, N, I, P, W, D, H)                                                                            \
+  hipExtLaunchKernelGGL((k_step<L, N, I, P, W, D, H>), dim3(grid), dim3(BLOCK), 0, d.stream, ev_start, ev_stop, 0, A, bt, \
                         d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],    \
                         d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which)
+#define STP(L, N, I, P) do { if (lpb4) STPL(L, N, I, P, 4, false, true); else if (ahead) STPL(L, N, I, P, 1, false, true); else STPL(L, N, I, P, 1, false, false); } while (0)
   int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
   // LAMMPS_LE_DIAG_STEP=bits: the same kernel is launched once more BEFORE the real launch with parts switched off
-  // (1 bonds, 2 pair loop, 4 draws, 128 nothing); it writes only the second position buffer, which the real launch
+  // (1 bonds, 2 pair loop, 4 draws, 8 pair gathers replaced by coalesced loads, 128 nothing); it writes only the second position buffer, which the real launch
   // overwrites, so the run is physically unchanged and a kernel trace shows what each part costs
   static const int diag_step = getenv("LAMMPS_LE_DIAG_STEP") ? atoi(getenv("LAMMPS_LE_DIAG_STEP")) : 0;
-  if (diag_step && key == 15 && which < 0) {
+  if (diag_step && key == 15 && which < 0 && !lpb4) {
     ForceArgs R = A;
     A.diag = diag_step | 64;
     hipEvent_t e0 = ev_start, e1 = ev_stop;
     ev_start = ev_stop = nullptr;
-    STP(true, true, true, true);
+    STPL(true, true, true, true, 1, true, false);
     A = R; ev_start = e0; ev_stop = e1;
   }
   switch (key) {
@@ -497,6 +621,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
     case 14: STP(true, true, true, false); break;    case 15: STP(true, true, true, true); break;
   }
 #undef STP
+#undef STPL
   if (next && swap_buffers) std::swap(d.pos, d.pos_tmp);
 }
 

@@ -92,6 +92,45 @@ def test_velocity_create_between_runs(tmp_path):
     assert p.stat("neigh_builds") == o.neigh_builds()
 
 
+@pytest.mark.parametrize("env", [
+    {"LAMMPS_LE_LPB": "1", "LAMMPS_LE_AHEAD_MAX_N": "0"},           # throughput variant (what >64k-bead systems run)
+    {"LAMMPS_LE_LPB": "1", "LAMMPS_LE_AHEAD_MAX_N": "1000000000"},  # loads issued ahead
+    {"LAMMPS_LE_LPB": "4"},                                          # four lanes per bead
+], ids=["plain", "ahead", "lpb4"])
+def test_step_kernel_variants(tmp_path, env):
+    """Every variant of the fused step kernel (chosen by system size in production) on the same system: hybrid bonds,
+    fractional special weights, two atom types, Langevin; against the oracle."""
+    import pickle
+    import subprocess
+    import sys
+    n = 6000
+    s = lattice_chain(n, seed=17, jitter=0.05, types=1 + (np.arange(n) % 5 == 0))
+    s["mass"] = [1.0, 1.7]
+    extra = np.array([(2, i, i + 2) for i in range(10, n - 10, 41)], dtype=np.int32)
+    s["bonds"] = np.concatenate([s["bonds"], extra])
+    script = CHAIN_SCRIPT.replace("special_bonds fene", "special_bonds lj 0.0 0.4 0.8") \
+        .replace("bond_style fene", "bond_style hybrid fene harmonic") \
+        .replace("bond_coeff 1 30.0 1.5 1.0 1.0", "bond_coeff 1 fene 30.0 1.5 1.0 1.0") \
+        .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 harmonic 10.0 1.2") \
+        .replace("pair_coeff * * 1.0 1.0 1.12", "pair_coeff * * 1.0 1.0 1.12\npair_coeff 2 2 1.3 0.9 1.05") \
+        + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 5544\nthermo 25\nrun 60\n"
+    o = run_oracle(script, s)
+    sysfile, scriptfile, out = str(tmp_path / "sys.pkl"), str(tmp_path / "in.txt"), str(tmp_path / "out.npz")
+    pickle.dump(s, open(sysfile, "wb"))
+    open(scriptfile, "w").write(script)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "variant_worker.py"),
+                        sysfile, scriptfile, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = np.load(out)
+    assert relerr(res["x"].reshape(-1, 3), o.x()) < 1e-9
+    assert relerr(res["v"].reshape(-1, 3), o.v()) < 1e-8
+    assert (res["image"].reshape(-1, 3) == o.image()).all()
+    assert int(res["builds"][0]) == o.neigh_builds()
+    to = o.thermo()
+    for k in range(5):
+        assert abs(res["thermo"][k] - to[k]) <= 1e-9 * max(1.0, abs(to[k]))
+
+
 def test_chain_benchmark_golden(tmp_path):
     """BASELINE configs[0]: bench/in.chain settings on bench/data.chain; the published 1-rank log's
     step-0 / step-100 thermo (reference default atom_modify sort 1000 -> Atom::sort order emulated)."""
