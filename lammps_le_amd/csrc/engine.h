@@ -131,8 +131,9 @@ struct FixExLoad : Fix {
   double compute_vector(int n) override;
 };
 
-struct FixExUnload : Fix {
+struct FixExUnload : Fix {   // also the stock `bond/break` (src/MC/fix_bond_break.cpp), which differs only in the firing step
   int nevery, btype;
+  int phase = 2;             // fires when ntimestep % nevery == phase: 2 for ex_unload, 0 for bond/break
   double cutsq, fraction = 1.0;
   int seed = 12345;
   RanMarsInt rng;

@@ -131,24 +131,28 @@ double FixExLoad::compute_vector(int n) { return n == 0 ? (double)last_create : 
 // fix ID group ex_unload Nevery bondtype Rmax [prob fraction seed]  (src/USER-LE/fix_ex_unload.cpp:34-115)
 FixExUnload::FixExUnload(Engine *e, const std::vector<std::string> &arg) {
   eng = e; id = arg[0]; group = arg[1]; style = arg[2];
-  if (arg.size() < 6) throw LammpsError("Illegal fix ex_unload command");
+  // the reference's two files are the same text but for the firing step (src/MC/fix_bond_break.cpp:178 `% nevery`,
+  // src/USER-LE/fix_ex_unload.cpp:178 `% nevery - 2`)
+  phase = (style == "bond/break") ? 0 : 2;
+  const std::string ill = "Illegal fix " + style + " command";
+  if (arg.size() < 6) throw LammpsError(ill);
   need_all(arg);
   nevery = inumeric(arg[3]);
-  if (nevery <= 0) throw LammpsError("Illegal fix ex_unload command");
+  if (nevery <= 0) throw LammpsError(ill);
   btype = inumeric(arg[4]);
   double cutoff = numeric(arg[5]);
-  if (btype < 1 || btype > e->nbondtypes) throw LammpsError("Invalid bond type in fix ex_unload command");
-  if (cutoff < 0.0) throw LammpsError("Illegal fix ex_unload command");
+  if (btype < 1 || btype > e->nbondtypes) throw LammpsError("Invalid bond type in fix " + style + " command");
+  if (cutoff < 0.0) throw LammpsError(ill);
   cutsq = cutoff * cutoff;
   size_t iarg = 6;
   while (iarg < arg.size()) {
     if (arg[iarg] == "prob") {
-      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_unload command");
+      if (iarg + 3 > arg.size()) throw LammpsError(ill);
       fraction = numeric(arg[iarg + 1]); seed = inumeric(arg[iarg + 2]);
-      if (fraction < 0.0 || fraction > 1.0) throw LammpsError("Illegal fix ex_unload command");
-      if (seed <= 0) throw LammpsError("Illegal fix ex_unload command");
+      if (fraction < 0.0 || fraction > 1.0) throw LammpsError(ill);
+      if (seed <= 0) throw LammpsError(ill);
       iarg += 3;
-    } else throw LammpsError("Illegal fix ex_unload command");
+    } else throw LammpsError(ill);
   }
   rng.seed(seed);
   force_reneighbor = true;
@@ -222,7 +226,7 @@ void FixExLoad::post_integrate() {
 }
 
 void FixExUnload::post_integrate() {
-  if (eng->ntimestep % nevery - 2) return;               // src/USER-LE/fix_ex_unload.cpp:178
+  if (eng->ntimestep % nevery - phase) return;           // src/USER-LE/fix_ex_unload.cpp:178, src/MC/fix_bond_break.cpp:178
   DeviceState &d = *eng->dev;
   int slot = le_slot(eng, this);
   if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
@@ -232,7 +236,7 @@ void FixExUnload::post_integrate() {
   launch_ex_unload(d, p, slot);
   d.topo_dirty = true;
   sync_flags(d);
-  check_le_error(d, "ex_unload");
+  check_le_error(d, style.c_str());
   last_break = d.flags_h[FLAG_COUNT_A];
   total_break += last_break;
   eng->nbonds -= last_break;

@@ -17,6 +17,12 @@ namespace lmp_le {
 
 constexpr int BLOCK = 256;
 constexpr int BOND_AHEAD = 3;             // bond slots whose partner loads are issued ahead of the neighbor loop
+// the throughput variant of k_step is bound by (resident wavefronts) / (lifetime of one wavefront): occupancy was
+// varied on purpose with unused LDS and 16 -> 12 -> 8 waves per CU cost x1.22 and x1.79.  Asking the compiler for five
+// waves per SIMD makes it fit 92 VGPRs without scratch (it takes 126 when left alone).
+#ifndef STEP_WAVES_PER_SIMD
+#define STEP_WAVES_PER_SIMD 5
+#endif
 constexpr int AHEAD_MAX_BEADS = 64000;   // k_step: partner / first-stage loads issued ahead of their use up to this size
 constexpr int LPB4_MAX_BEADS = 50000;   // k_step: four lanes per bead up to this many (owned) beads, see k_step
 #define TWO_1_3 1.2599210498948732
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
 // every fourth list entry and every fourth bond slot, the partial forces meet in a two-step butterfly and lane 0
 // integrates: the chain shrinks to one or two stages.
 template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD>
-__global__ __launch_bounds__(BLOCK) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
+__global__ __launch_bounds__(BLOCK, (AHEAD ? 4 : STEP_WAVES_PER_SIMD)) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
                                                 const int *__restrict__ tag, const int *__restrict__ crank,
                                                 const uint32_t *__restrict__ draws, double *__restrict__ vx,
                                                 double *__restrict__ vy, double *__restrict__ vz,
@@ -588,12 +594,14 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   const bool lpb4 = lpb_env ? lpb_env == 4 : d.n <= lpb_max_n;
   static const int ahead_max_n = getenv("LAMMPS_LE_AHEAD_MAX_N") ? atoi(getenv("LAMMPS_LE_AHEAD_MAX_N")) : AHEAD_MAX_BEADS;
   const bool ahead = d.n <= ahead_max_n;
+  // diagnostics only (LAMMPS_LE_STEP_LDS_PAD=bytes): unused dynamic LDS per workgroup, to lower the occupancy on purpose
+  static const unsigned lds_pad = getenv("LAMMPS_LE_STEP_LDS_PAD") ? (unsigned)atoi(getenv("LAMMPS_LE_STEP_LDS_PAD")) : 0u;
   if (lpb4) { A.nblocks = (d.n + BLOCK / 4 - 1) / (BLOCK / 4); A.maxrow = (d.maxneigh - 4) / 4; }
   int grid = xcd_grid(A.nblocks);
   // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
   // the same clock rocprofv3 --kernel-trace reports
 #define STPL(L, N, I, P, W, D, H)                                                                            \
-  hipExtLaunchKernelGGL((k_step<L, N, I, P, W, D, H>), dim3(grid), dim3(BLOCK), 0, d.stream, ev_start, ev_stop, 0, A, bt, \
+  hipExtLaunchKernelGGL((k_step<L, N, I, P, W, D, H>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, ev_start, ev_stop, 0, A, bt, \
                         d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],    \
                         d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which)
 #define STP(L, N, I, P) do { if (lpb4) STPL(L, N, I, P, 4, false, true); else if (ahead) STPL(L, N, I, P, 1, false, true); else STPL(L, N, I, P, 1, false, false); } while (0)

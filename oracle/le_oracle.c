@@ -25,6 +25,7 @@ typedef struct {
   leo_ranmars rng;
   /* LE common */
   int nevery, btype;
+  int phase;                 /* fires when ntimestep % nevery == phase */
   long next_reneighbor;
   double cutsq, fraction;
   /* extrusion */
@@ -346,23 +347,28 @@ void leo_fix_langevin(leo_t *s, double t_start, double t_stop, double damp, int 
 }
 void leo_fix_extrusion(leo_t *s, int nevery, int neutral, int l, int r, double tp, int btype, int lr) {
   leo_fix *f = &s->fix[s->nfix++]; memset(f, 0, sizeof *f);
-  f->kind = FIX_EXTRUSION; f->nevery = nevery; f->neutral = neutral; f->ctcf_left = l; f->ctcf_right = r;
+  f->kind = FIX_EXTRUSION; f->phase = 1; f->nevery = nevery; f->neutral = neutral; f->ctcf_left = l; f->ctcf_right = r;
   f->through_prob = tp; f->btype = btype; f->ctcf_lr = lr; f->next_reneighbor = -1;
   leo_ranmars_init(&f->rng, 12345);                          /* src/USER-LE/fix_extrusion.cpp:98-99 */
 }
 void leo_fix_ex_load(leo_t *s, int nevery, int it, int jt, double cutoff, int btype, int imax, int inew,
                      int jmax, int jnew, double fraction, int seed) {
   leo_fix *f = &s->fix[s->nfix++]; memset(f, 0, sizeof *f);
-  f->kind = FIX_EX_LOAD; f->nevery = nevery; f->iatomtype = it; f->jatomtype = jt; f->cutsq = cutoff * cutoff;
+  f->kind = FIX_EX_LOAD; f->phase = 3; f->nevery = nevery; f->iatomtype = it; f->jatomtype = jt; f->cutsq = cutoff * cutoff;
   f->btype = btype; f->imaxbond = imax; f->inewtype = inew; f->jmaxbond = jmax; f->jnewtype = jnew;
   f->fraction = fraction; f->seed = seed; f->next_reneighbor = -1;
   leo_ranmars_init(&f->rng, seed);                           /* src/USER-LE/fix_ex_load.cpp:137 */
 }
 void leo_fix_ex_unload(leo_t *s, int nevery, int btype, double cutoff, double fraction, int seed) {
   leo_fix *f = &s->fix[s->nfix++]; memset(f, 0, sizeof *f);
-  f->kind = FIX_EX_UNLOAD; f->nevery = nevery; f->btype = btype; f->cutsq = cutoff * cutoff;
+  f->kind = FIX_EX_UNLOAD; f->phase = 2; f->nevery = nevery; f->btype = btype; f->cutsq = cutoff * cutoff;
   f->fraction = fraction; f->seed = seed; f->next_reneighbor = -1;
   leo_ranmars_init(&f->rng, seed);                           /* src/USER-LE/fix_ex_unload.cpp:88 */
+}
+/* stock fix bond/break: src/MC/fix_bond_break.cpp is the text of fix_ex_unload.cpp but for the firing step (:178) */
+void leo_fix_bond_break(leo_t *s, int nevery, int btype, double cutoff, double fraction, int seed) {
+  leo_fix_ex_unload(s, nevery, btype, cutoff, fraction, seed);
+  s->fix[s->nfix - 1].phase = 0;
 }
 
 /* ===================== domain ===================== */
@@ -1202,8 +1208,7 @@ int leo_run(leo_t *s, int nsteps) {
     for (int k = 0; k < s->nfix; k++) {
       leo_fix *fx = &s->fix[k];
       if (fx->kind < FIX_EXTRUSION) continue;
-      long off = (fx->kind == FIX_EXTRUSION) ? 1 : (fx->kind == FIX_EX_UNLOAD) ? 2 : 3;
-      if (s->ntimestep % fx->nevery - off) continue;               /* fix_extrusion.cpp:265 etc. */
+      if (s->ntimestep % fx->nevery - fx->phase) continue;               /* fix_extrusion.cpp:265 etc. */
       if (fire_fix(s, fx)) return 1;
     }
     s->t_modify += now() - t0;

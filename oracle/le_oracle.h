@@ -73,6 +73,7 @@ void   leo_fix_ex_load(leo_t *s, int nevery, int iatomtype, int jatomtype, doubl
                        int btype, int imaxbond, int inewtype, int jmaxbond, int jnewtype,
                        double fraction, int seed);
 void   leo_fix_ex_unload(leo_t *s, int nevery, int btype, double cutoff, double fraction, int seed);
+void   leo_fix_bond_break(leo_t *s, int nevery, int btype, double cutoff, double fraction, int seed);
 
 /* ---- running ---- */
 /* run N steps exactly as Run::command + Verlet::setup/run (src/run.cpp, src/verlet.cpp).

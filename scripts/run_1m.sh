@@ -1,7 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -m pytest tests/test_gpu_md.py tests/test_gpu_le.py -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
-tail -2 gpurun_out/gpu_tests.log
-for wl in chain1m chain100k chain32k; do
-  timeout -k 10 300 python bench.py --workload $wl --steps 2000 --warmup 500 --cpu-steps 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
+for i in 1 2; do
+  timeout -k 10 300 python bench.py --workload chain1m --steps 2000 --warmup 500 --cpu-steps 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('chain1m', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
 done

@@ -146,6 +146,10 @@ class Oracle:
         self.L.leo_fix_ex_unload(self.h, nevery, btype, C.c_double(cutoff), C.c_double(fraction), seed)
         self._reg(fid)
 
+    def fix_bond_break(self, nevery, btype, cutoff, fraction=1.0, seed=12345, fid="breaking"):
+        self.L.leo_fix_bond_break(self.h, nevery, btype, C.c_double(cutoff), C.c_double(fraction), seed)
+        self._reg(fid)
+
     # -- running --
     def run(self, n):
         rc = self.L.leo_run(self.h, C.c_int(n))

@@ -210,11 +210,11 @@ class OracleScript:
                         kw["fraction"], kw["seed"] = float(p[k + 1]), int(p[k + 2])
                     k += 3
                 o.fix_ex_load(int(p[0]), int(p[1]), int(p[2]), float(p[3]), int(p[4]), fid=fid, **kw)
-            elif style == "ex_unload":
+            elif style in ("ex_unload", "bond/break"):
                 kw = dict(fraction=1.0, seed=12345)
                 if len(p) > 3 and p[3] == "prob":
                     kw["fraction"], kw["seed"] = float(p[4]), int(p[5])
-                o.fix_ex_unload(int(p[0]), int(p[1]), float(p[2]), fid=fid, **kw)
+                (o.fix_ex_unload if style == "ex_unload" else o.fix_bond_break)(int(p[0]), int(p[1]), float(p[2]), fid=fid, **kw)
             else:
                 raise ValueError("oracle script: unknown fix " + style)
         elif c == "velocity":

@@ -96,6 +96,23 @@ def test_le_cycle_with_barriers(tmp_path, tp):
     assert len([b for b in o.bond_set() if b[0] == 2]) > 5
 
 
+def test_stock_bond_break_in_place_of_ex_unload(tmp_path):
+    """`fix bond/break` (src/MC) = the ex_unload text firing at step % N == 0: it then acts BEFORE the extrusion step
+    (N+1) and the loading (N+3) of the same cycle, on the bond list of the last reneighboring."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 7))
+    script = le_script().replace("fix unloading all ex_unload 10 2 0.5 prob 0.3 456456",
+                                 "fix unloading all bond/break 10 2 0.5 prob 0.3 456456") + "run 64\n"
+    assert "bond/break" in script
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    assert o.fix_vector("unloading")[1] > 0          # something was broken
+    # and it is not the ex_unload schedule in disguise
+    o2 = run_oracle(le_script() + "run 64\n", s)
+    assert o2.bond_set() != o.bond_set()
+
+
 def test_dense_extruders_collide_and_stall(tmp_path):
     """No prob keyword -> every eligible (i,i+2) pair loads (first-order recurrence over runs of candidates);
     extruders then collide head-on and stall; nothing unloads."""

@@ -48,7 +48,8 @@ def test_script_layer_and_queries(tmp_path):
     lmp.command("fix loop all extrusion 1000 1 1 1 1.0 2")
     lmp.command("fix loading all ex_load 1000 1 1 1.12 2 prob 0.5 684474 iparam 1 1 jparam 1 1")
     lmp.command("fix unloading all ex_unload 1000 2 0.5 prob 0.5 456456")
-    for style in ("nve", "langevin", "extrusion", "ex_load", "ex_unload"):
+    lmp.command("fix breaking all bond/break 1000 2 0.5 prob 0.5 456456")          # src/MC/fix_bond_break.cpp grammar
+    for style in ("nve", "langevin", "extrusion", "ex_load", "ex_unload", "bond/break"):
         assert lmp.has_style("fix", style)
 
 
@@ -61,6 +62,8 @@ def test_errors_match_reference_messages(tmp_path):
         lmp.command("fix bad all extrusion 1000 1 1 1 1.0")
     with pytest.raises(LammpsError, match="Illegal fix ex_load command"):
         lmp.command("fix bad2 all ex_load 1000 1 1 1.12 2 prob 1.5 1")
+    with pytest.raises(LammpsError, match="Illegal fix bond/break command"):
+        lmp.command("fix bad2b all bond/break 1000 2 0.5 prob 1.5 1")
     with pytest.raises(LammpsError, match="Unknown fix style"):
         lmp.command("fix bad3 all nvt temp 1 1 1")
     with pytest.raises(LammpsError, match="Fix langevin period must be > 0.0"):
