@@ -237,7 +237,7 @@ int lammps_get_last_error_message(void *handle, char *buffer, int buf_size) {
 int lammps_config_has_exceptions(void) { return 1; }
 int lammps_has_style(void *, const char *category, const char *name) {
   std::string c = category, s = name;
-  if (c == "fix") return s == "nve" || s == "langevin" || s == "extrusion" || s == "ex_load" || s == "ex_unload" || s == "bond/break";
+  if (c == "fix") return s == "nve" || s == "langevin" || s == "extrusion" || s == "ex_load" || s == "ex_unload" || s == "bond/break" || s == "bond/create";
   if (c == "pair") return s == "lj/cut" || s == "zero" || s == "none";
   if (c == "dump") return s == "atom" || s == "custom" || s == "local";
   if (c == "compute") return s == "property/local";

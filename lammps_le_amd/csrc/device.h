@@ -206,6 +206,9 @@ void le_rng_upload(DeviceState &d, int slot, const RanMarsInt &r);
 void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
 // each returns after enqueueing; counters are read back by the caller through flags_h
 void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
+// stock fix bond/create: `bondcount` (host, by tag, nt ints) goes up before the launch; bond_create_counts fetches it back
+void launch_bond_create(DeviceState &d, const ExLoadParams &p, int rng_slot, const int *bondcount, int nt);
+void bond_create_counts(DeviceState &d, int *bondcount, int nt);
 void launch_ex_unload(DeviceState &d, const ExUnloadParams &p, int rng_slot);
 void launch_extrusion(DeviceState &d, const ExtrusionParams &p, int rng_slot);
 void sync_flags(DeviceState &d, unsigned reset_mask = 0);   // copy flags to flags_h, zero the masked ones, wait

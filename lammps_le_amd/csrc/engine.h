@@ -117,8 +117,12 @@ struct FixExtrusion : Fix {
   double compute_vector(int n) override;
 };
 
-struct FixExLoad : Fix {
+struct FixExLoad : Fix {    // also the stock `bond/create` (src/MC/fix_bond_create.cpp), the style ex_load was derived from
   int nevery, iatomtype, jatomtype, btype, imaxbond = 0, inewtype, jmaxbond = 0, jnewtype;
+  bool stock = false;        // bond/create: candidates = every pair of the pair list (not only (i, i+2)), fires at step % N == 0,
+  int phase = 3;             //   bonds of btype per bead counted at the first setup and from then on only incremented
+  std::vector<int> bondcount;   // [natoms + 2] by tag (stock only)
+  bool counted = false;
   double cutsq, fraction = 1.0;
   int seed = 12345;
   RanMarsInt rng;
@@ -127,6 +131,7 @@ struct FixExLoad : Fix {
   long total_create = 0;
   FixExLoad(Engine *e, const std::vector<std::string> &arg);
   void init() override;
+  void setup() override;
   void post_integrate() override;
   double compute_vector(int n) override;
 };

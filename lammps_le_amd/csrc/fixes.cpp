@@ -72,59 +72,74 @@ double FixExtrusion::compute_vector(int n) { return n == 0 ? (double)last_break 
 // fix ID group ex_load Nevery itype jtype Rmin bondtype [iparam ..] [jparam ..] [prob f seed] (:39-176)
 FixExLoad::FixExLoad(Engine *e, const std::vector<std::string> &arg) {
   eng = e; id = arg[0]; group = arg[1]; style = arg[2];
-  if (arg.size() < 8) throw LammpsError("Illegal fix ex_load command");
+  stock = (style == "bond/create");
+  phase = stock ? 0 : 3;                                  // src/MC/fix_bond_create.cpp:356 vs src/USER-LE/fix_ex_load.cpp:338
+  const std::string ill = "Illegal fix " + style + " command";
+  if (arg.size() < 8) throw LammpsError(ill);
   need_all(arg);
   nevery = inumeric(arg[3]);
-  if (nevery <= 0) throw LammpsError("Illegal fix ex_load command");
+  if (nevery <= 0) throw LammpsError(ill);
   iatomtype = inumeric(arg[4]); jatomtype = inumeric(arg[5]);
   double cutoff = numeric(arg[6]);
   btype = inumeric(arg[7]);
   if (iatomtype < 1 || iatomtype > e->ntypes || jatomtype < 1 || jatomtype > e->ntypes)
-    throw LammpsError("Invalid atom type in fix ex_load command");
-  if (cutoff < 0.0) throw LammpsError("Illegal fix ex_load command");
-  if (btype < 1 || btype > e->nbondtypes) throw LammpsError("Invalid bond type in fix ex_load command");
+    throw LammpsError("Invalid atom type in fix " + style + " command");
+  if (cutoff < 0.0) throw LammpsError(ill);
+  if (btype < 1 || btype > e->nbondtypes) throw LammpsError("Invalid bond type in fix " + style + " command");
   cutsq = cutoff * cutoff;
   inewtype = iatomtype; jnewtype = jatomtype;
   size_t iarg = 8;
   while (iarg < arg.size()) {
     if (arg[iarg] == "iparam") {
-      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      if (iarg + 3 > arg.size()) throw LammpsError(ill);
       imaxbond = inumeric(arg[iarg + 1]); inewtype = inumeric(arg[iarg + 2]);
-      if (imaxbond < 0) throw LammpsError("Illegal fix ex_load command");
-      if (inewtype < 1 || inewtype > e->ntypes) throw LammpsError("Invalid atom type in fix ex_load command");
+      if (imaxbond < 0) throw LammpsError(ill);
+      if (inewtype < 1 || inewtype > e->ntypes) throw LammpsError("Invalid atom type in fix " + style + " command");
       iarg += 3;
     } else if (arg[iarg] == "jparam") {
-      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      if (iarg + 3 > arg.size()) throw LammpsError(ill);
       jmaxbond = inumeric(arg[iarg + 1]); jnewtype = inumeric(arg[iarg + 2]);
-      if (jmaxbond < 0) throw LammpsError("Illegal fix ex_load command");
-      if (jnewtype < 1 || jnewtype > e->ntypes) throw LammpsError("Invalid atom type in fix ex_load command");
+      if (jmaxbond < 0) throw LammpsError(ill);
+      if (jnewtype < 1 || jnewtype > e->ntypes) throw LammpsError("Invalid atom type in fix " + style + " command");
       iarg += 3;
     } else if (arg[iarg] == "prob") {
-      if (iarg + 3 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      if (iarg + 3 > arg.size()) throw LammpsError(ill);
       fraction = numeric(arg[iarg + 1]); seed = inumeric(arg[iarg + 2]);
-      if (fraction < 0.0 || fraction > 1.0) throw LammpsError("Illegal fix ex_load command");
-      if (seed <= 0) throw LammpsError("Illegal fix ex_load command");
+      if (fraction < 0.0 || fraction > 1.0) throw LammpsError(ill);
+      if (seed <= 0) throw LammpsError(ill);
       iarg += 3;
     } else if (arg[iarg] == "atype" || arg[iarg] == "dtype" || arg[iarg] == "itype") {
-      if (iarg + 2 > arg.size()) throw LammpsError("Illegal fix ex_load command");
+      if (iarg + 2 > arg.size()) throw LammpsError(ill);
       if (inumeric(arg[iarg + 1]) != 0)
-        throw LammpsError("MI355X engine: fix ex_load angle/dihedral/improper creation is not supported");
+        throw LammpsError("MI355X engine: fix " + style + " angle/dihedral/improper creation is not supported");
       iarg += 2;
-    } else throw LammpsError("Illegal fix ex_load command");
+    } else throw LammpsError(ill);
   }
-  if (e->atom_style == "atomic") throw LammpsError("Cannot use fix ex_load with non-molecular systems");
+  if (e->atom_style == "atomic") throw LammpsError("Cannot use fix " + style + " with non-molecular systems");
   if (iatomtype == jatomtype && (imaxbond != jmaxbond || inewtype != jnewtype))
-    throw LammpsError("Inconsistent iparam/jparam values in fix ex_load command");
+    throw LammpsError("Inconsistent iparam/jparam values in fix " + style + " command");
   rng.seed(seed);
   force_reneighbor = true;
   has_post_integrate = true;
 }
 void FixExLoad::init() {
   // src/USER-LE/fix_ex_load.cpp:217-218
-  if (!eng->pair_lj) throw LammpsError("Fix ex_load cutoff is longer than pairwise cutoff");
+  if (!eng->pair_lj) throw LammpsError("Fix " + style + " cutoff is longer than pairwise cutoff");
   int nt = eng->ntypes + 1;
   if (cutsq > eng->cutsq[iatomtype * nt + jatomtype])
-    throw LammpsError("Fix ex_load cutoff is longer than pairwise cutoff");
+    throw LammpsError("Fix " + style + " cutoff is longer than pairwise cutoff");
+}
+// FixBondCreate::setup (src/MC/fix_bond_create.cpp:302-345): count the bonds of btype each bead stores, once
+void FixExLoad::setup() {
+  if (!stock || counted) return;
+  counted = true;
+  const bool was_current = eng->host_current;
+  eng->download();                   // setup runs with the device already holding the newest state
+  eng->host_current = was_current;   // ... and the run that follows will change it again
+  bondcount.assign((size_t)eng->natoms + 2, 0);
+  for (int i = 0; i < eng->natoms; i++)
+    for (int m = 0; m < eng->num_bond[i]; m++)
+      if (eng->bond_type[(size_t)i * eng->bpa + m] == btype) bondcount[i + 1]++;
 }
 double FixExLoad::compute_vector(int n) { return n == 0 ? (double)last_create : (double)total_create; }
 
@@ -208,21 +223,27 @@ void FixExtrusion::post_integrate() {
 }
 
 void FixExLoad::post_integrate() {
-  if (eng->ntimestep % nevery - 3) return;               // src/USER-LE/fix_ex_load.cpp:338
+  if (eng->ntimestep % nevery - phase) return;           // src/USER-LE/fix_ex_load.cpp:338, src/MC/fix_bond_create.cpp:356
   DeviceState &d = *eng->dev;
   int slot = le_slot(eng, this);
   if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
-  if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction};
-  launch_ex_load(d, p, slot);
+  if (stock) {
+    if (eng->world > 1) throw LammpsError("MI355X engine: fix bond/create is not available in decomposed runs");
+    launch_bond_create(d, p, slot, bondcount.data(), (int)bondcount.size());
+  } else {
+    if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
+    launch_ex_load(d, p, slot);
+  }
   d.topo_dirty = true;
   sync_flags(d);
-  check_le_error(d, "ex_load");
+  check_le_error(d, style.c_str());
   last_create = d.flags_h[FLAG_COUNT_A];
   total_create += last_create;
   eng->nbonds += last_create;
   if (last_create) eng->le_reneigh_step[fix_index(eng, this)] = eng->ntimestep;
+  if (stock && last_create) bond_create_counts(d, bondcount.data(), (int)bondcount.size());
 }
 
 void FixExUnload::post_integrate() {

@@ -325,7 +325,7 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
     if (st == "nve") f.reset(new FixNVE(this, arg));
     else if (st == "langevin") f.reset(new FixLangevin(this, arg));
     else if (st == "extrusion") f.reset(new FixExtrusion(this, arg));
-    else if (st == "ex_load") f.reset(new FixExLoad(this, arg));
+    else if (st == "ex_load" || st == "bond/create") f.reset(new FixExLoad(this, arg));
     else if (st == "ex_unload" || st == "bond/break") f.reset(new FixExUnload(this, arg));
     else throw LammpsError("Unknown fix style " + st);
     apply_restart_state(f.get());     // a fix re-specified after read_restart continues its RNG stream (Fix::restart)

@@ -349,6 +349,81 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot) {
   hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, d.flags);
 }
 
+// ========================================= bond/create =========================================
+// stock FixBondCreate::post_integrate (src/MC/fix_bond_create.cpp:349-640).  Its candidate scan walks the pair list
+// (:422-485): with newton off every owned bead meets each of its candidates, as i or as j, so a bead can pick its
+// closest admissible partner from its own FULL list without looking at anyone else's choice.  The list is the one of
+// the last reneighboring (the reference rebuilds an occasional list at the firing step; any pair now within the
+// fix cutoff <= pair cutoff is in both).  From `partner` on the path is ex_load's (draws, creation, special lists).
+__global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams P, Box box, int n, int npad,
+                                                           const double4 *__restrict__ pos, const int *__restrict__ tag,
+                                                           const int *__restrict__ neigh, const int *__restrict__ numneigh,
+                                                           const int *__restrict__ bc, int *__restrict__ partner,
+                                                           int *__restrict__ haspartner) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const int t = tag[p];
+  const int itype = tp.type_t[t];
+  int best_tag = 0;
+  if (itype == P.iatomtype || itype == P.jatomtype) {
+    const double4 ri = pos[p];
+    const int bci = bc[t];
+    const int *sl = tp.special + (size_t)t * tp.ms;
+    const int n1 = tp.nspecial[3 * (size_t)t];
+    const int nn = numneigh[p];
+    double best = 1.0e20;
+    for (int k = 0; k < nn; k++) {
+      const int j = neigh[(size_t)k * npad + p] & NEIGH_MASK;
+      const int tj = tag[j];
+      const int jtype = tp.type_t[tj];
+      bool possible = false;
+      if (itype == P.iatomtype && jtype == P.jatomtype) {
+        if ((P.imaxbond == 0 || bci < P.imaxbond) && (P.jmaxbond == 0 || bc[tj] < P.jmaxbond)) possible = true;
+      } else if (itype == P.jatomtype && jtype == P.iatomtype) {
+        if ((P.jmaxbond == 0 || bci < P.jmaxbond) && (P.imaxbond == 0 || bc[tj] < P.imaxbond)) possible = true;
+      }
+      if (!possible) continue;
+      for (int q = 0; q < n1; q++) if (sl[q] == tj) possible = false;     // :455-458 no duplicate bond
+      if (!possible) continue;
+      const double4 rj = pos[j];
+      double dx = ri.x - rj.x, dy = ri.y - rj.y, dz = ri.z - rj.z;
+      if (dx > box.half[0]) dx -= box.prd[0]; else if (dx < -box.half[0]) dx += box.prd[0];
+      if (dy > box.half[1]) dy -= box.prd[1]; else if (dy < -box.half[1]) dy += box.prd[1];
+      if (dz > box.half[2]) dz -= box.prd[2]; else if (dz < -box.half[2]) dz += box.prd[2];
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq >= P.cutsq) continue;
+      if (rsq < best) { best = rsq; best_tag = tj; }
+    }
+  }
+  partner[t] = best_tag;
+  haspartner[t] = best_tag != 0;
+}
+void launch_bond_create(DeviceState &d, const ExLoadParams &P, int slot, const int *bondcount, int nt_host) {
+  Topo tp = topo_of(d);
+  int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
+  hipStream_t st = d.stream;
+  int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
+  if (nt_host != nt || d.n != T) throw LammpsError("fix bond/create: atom IDs must be 1..N on one rank");
+  if (!d.neigh) throw LammpsError("fix bond/create needs a pair neighbor list");
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
+  HIP_CHECK(hipMemcpyAsync(bc, bondcount, (size_t)nt * sizeof(int), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemsetAsync(partner, 0, (size_t)nt * sizeof(int), st));
+  HIP_CHECK(hipMemsetAsync(has, 0, (size_t)nt * sizeof(int), st));
+  hipLaunchKernelGGL(k_bcreate_partner, dim3((d.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tp, P, d.box, d.n, d.npad, d.pos,
+                     d.tag, d.neigh, d.numneigh, bc, partner, has);
+  if (P.fraction < 1.0) {
+    scan_ex(d, has, didx, nt, FLAG_NDRAW);
+    launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
+  }
+  hipLaunchKernelGGL(k_exload_create, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, bc, fin, d.pos,
+                     d.map, d.flags);
+  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, d.flags);
+}
+void bond_create_counts(DeviceState &d, int *bondcount, int nt) {
+  HIP_CHECK(hipMemcpyAsync(bondcount, d.le_i[I_BC], (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, d.stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+}
+
 // ========================================= ex_unload ==========================================
 __global__ __launch_bounds__(BLOCK) void k_exunload_partner(Topo tp, ExUnloadParams P, Box box,
                                                             const double4 *__restrict__ xt,

@@ -15,7 +15,7 @@
 #define TWO_1_3 1.2599210498948732  /* src/math_const.h MY_CUBEROOT2 */
 #define MAXFIX 16
 
-enum { FIX_NVE = 1, FIX_LANGEVIN, FIX_EXTRUSION, FIX_EX_LOAD, FIX_EX_UNLOAD };
+enum { FIX_NVE = 1, FIX_LANGEVIN, FIX_EXTRUSION, FIX_EX_LOAD, FIX_EX_UNLOAD, FIX_BOND_CREATE };
 
 typedef struct {
   int kind;
@@ -32,6 +32,8 @@ typedef struct {
   int neutral, ctcf_left, ctcf_right, ctcf_lr; double through_prob;
   /* ex_load */
   int iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype;
+  /* bond/create: bonds of btype per atom, by tag, counted at the first setup and then only incremented (stock rule) */
+  int *bc_tag; int counted;
   /* counters */
   int lastcount; long totalcount;
 } leo_fix;
@@ -177,7 +179,7 @@ void leo_free(leo_t *s) {
   free(s->bstyle); free(s->bp0); free(s->bp1); free(s->bp2); free(s->bp3);
   free(s->firstneigh); free(s->pj); free(s->pi_); free(s->pshift);
   free(s->bl_i); free(s->bl_j); free(s->bl_t); free(s->bl_s);
-  for (int i = 0; i < s->nfix; i++) { free(s->fix[i].gfactor1); free(s->fix[i].gfactor2); }
+  for (int i = 0; i < s->nfix; i++) { free(s->fix[i].gfactor1); free(s->fix[i].gfactor2); free(s->fix[i].bc_tag); }
   free(s->thermo_hist);
   free(s->bondcount); free(s->ia); free(s->ib); free(s->ic); free(s->id); free(s->ie);
   free(s->da); free(s->db); free(s->copy);
@@ -364,6 +366,14 @@ void leo_fix_ex_unload(leo_t *s, int nevery, int btype, double cutoff, double fr
   f->kind = FIX_EX_UNLOAD; f->phase = 2; f->nevery = nevery; f->btype = btype; f->cutsq = cutoff * cutoff;
   f->fraction = fraction; f->seed = seed; f->next_reneighbor = -1;
   leo_ranmars_init(&f->rng, seed);                           /* src/USER-LE/fix_ex_unload.cpp:88 */
+}
+/* stock fix bond/create (src/MC/fix_bond_create.cpp): the parent of ex_load; same arguments */
+void leo_fix_bond_create(leo_t *s, int nevery, int it, int jt, double cutoff, int btype, int imax, int inew,
+                         int jmax, int jnew, double fraction, int seed) {
+  leo_fix_ex_load(s, nevery, it, jt, cutoff, btype, imax, inew, jmax, jnew, fraction, seed);
+  leo_fix *f = &s->fix[s->nfix - 1];
+  f->kind = FIX_BOND_CREATE; f->phase = 0;
+  f->bc_tag = calloc((size_t)s->n + 2, sizeof(int)); f->counted = 0;
 }
 /* stock fix bond/break: src/MC/fix_bond_break.cpp is the text of fix_ex_unload.cpp but for the firing step (:178) */
 void leo_fix_bond_break(leo_t *s, int nevery, int btype, double cutoff, double fraction, int seed) {
@@ -1066,6 +1076,84 @@ static int fire_ex_load(leo_t *s, leo_fix *fx) {
   return rc;
 }
 
+/* ===================== fix bond/create: src/MC/fix_bond_create.cpp:302-345 setup, :349-640 post_integrate =====================
+   Candidates are ALL pairs of the pair neighbor list (the reference rebuilds an occasional list at the firing step;
+   here the list of the last reneighboring is walked, which holds every pair now within the fix cutoff <= pair cutoff;
+   a pair whose special status changed earlier in the same step is still seen with its old status).  Exact ties of two
+   candidate distances are broken by visit order, which is the order of this list, not the reference's bin order. */
+static void bond_create_setup(leo_t *s, leo_fix *fx) {            /* :302-345, once ("countflag") */
+  if (fx->counted) return;
+  fx->counted = 1;
+  for (int i = 0; i < s->n; i++) {
+    int c = 0;
+    for (int j = 0; j < s->num_bond[i]; j++) if (s->bond_type[i * s->bpa + j] == fx->btype) c++;
+    fx->bc_tag[s->tag[i]] = c;
+  }
+}
+static int fire_bond_create(leo_t *s, leo_fix *fx) {
+  int n = s->n; const int *tag = s->tag;
+  int *partner = s->ia, *finalpartner = s->ib; double *distsq = s->da;
+  fx->lastcount = 0;
+  if (s->brute) return seterr(s, "oracle: fix bond/create needs a box of at least 3 neighbor cutoffs per dimension");
+  for (int i = 0; i < n; i++) { partner[i] = 0; finalpartner[i] = 0; distsq[i] = BIG; s->bondcount[i] = fx->bc_tag[tag[i]]; }
+  if (s->pair_on)
+    for (int i = 0; i < n; i++) {
+      int itype = s->type[i];
+      for (int p = s->firstneigh[i]; p < s->firstneigh[i + 1]; p++) {
+        int j = s->pj[p] & 0x3FFFFFFF;
+        int jtype = s->type[j], possible = 0;
+        if (itype == fx->iatomtype && jtype == fx->jatomtype) {
+          if ((fx->imaxbond == 0 || s->bondcount[i] < fx->imaxbond) && (fx->jmaxbond == 0 || s->bondcount[j] < fx->jmaxbond)) possible = 1;
+        } else if (itype == fx->jatomtype && jtype == fx->iatomtype) {
+          if ((fx->jmaxbond == 0 || s->bondcount[i] < fx->jmaxbond) && (fx->imaxbond == 0 || s->bondcount[j] < fx->imaxbond)) possible = 1;
+        }
+        if (!possible) continue;
+        const int *sl = s->special + (size_t)i * s->maxspecial;                     /* :455-458 no duplicate bond */
+        for (int k = 0; k < s->nspecial[3 * i]; k++) if (sl[k] == tag[j]) possible = 0;
+        if (!possible) continue;
+        double d[3] = { s->x[3 * i] - s->x[3 * j], s->x[3 * i + 1] - s->x[3 * j + 1], s->x[3 * i + 2] - s->x[3 * j + 2] };
+        signed char sh[3]; minimg(s, d, sh);
+        double rsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (rsq >= fx->cutsq) continue;
+        if (rsq < distsq[i]) { partner[i] = tag[j]; distsq[i] = rsq; }
+        if (rsq < distsq[j]) { partner[j] = tag[i]; distsq[j] = rsq; }
+      }
+    }
+  double *probability = distsq;
+  if (fx->fraction < 1.0)
+    for (int i = 0; i < n; i++) if (partner[i]) probability[i] = leo_ranmars_uniform(&fx->rng);
+  int ncreate = 0;
+  for (int i = 0; i < n; i++) {
+    if (partner[i] == 0) continue;
+    int j = map_(s, partner[i]);
+    if (partner[j] != tag[i]) continue;
+    if (fx->fraction < 1.0) {
+      if (tag[i] < tag[j]) { if (probability[i] >= fx->fraction) continue; }
+      else { if (probability[j] >= fx->fraction) continue; }
+    }
+    if (s->num_bond[i] == s->bpa) return seterr(s, "New bond exceeded bonds per atom in fix bond/create");
+    s->bond_type[i * s->bpa + s->num_bond[i]] = fx->btype; s->bond_atom[i * s->bpa + s->num_bond[i]] = tag[j]; s->num_bond[i]++;
+    if (special_insert12(s, i, tag[j], "New bond exceeded special list size in fix bond/create")) return 1;
+    s->bondcount[i]++; fx->bc_tag[tag[i]]++;
+    if (s->type[i] == fx->iatomtype) { if (s->bondcount[i] == fx->imaxbond) s->type[i] = fx->inewtype; }
+    else { if (s->bondcount[i] == fx->jmaxbond) s->type[i] = fx->jnewtype; }
+    finalpartner[i] = tag[j]; finalpartner[j] = tag[i];
+    if (tag[i] < tag[j]) ncreate++;
+  }
+  fx->lastcount = ncreate; fx->totalcount += ncreate; s->nbonds += ncreate;
+  if (!ncreate) return 0;
+  fx->next_reneighbor = s->ntimestep;
+  int *created = malloc(2 * (size_t)ncreate * sizeof(int)), nc = 0;
+  for (int i = 0; i < n; i++) {
+    if (finalpartner[i] == 0) continue;
+    int j = map_(s, finalpartner[i]);
+    if (j < 0 || tag[i] < tag[j]) { created[2 * nc] = tag[i]; created[2 * nc + 1] = finalpartner[i]; nc++; }
+  }
+  int rc = topo_created(s, nc, created);
+  free(created);
+  return rc;
+}
+
 /* ===================== fix ex_unload: src/USER-LE/fix_ex_unload.cpp:172-372 ===================== */
 static int fire_ex_unload(leo_t *s, leo_fix *fx) {
   int n = s->n; const int *tag = s->tag;
@@ -1122,6 +1210,7 @@ static int fire_fix(leo_t *s, leo_fix *fx) {
     case FIX_EXTRUSION: return fire_extrusion(s, fx);
     case FIX_EX_LOAD: return fire_ex_load(s, fx);
     case FIX_EX_UNLOAD: return fire_ex_unload(s, fx);
+    case FIX_BOND_CREATE: return fire_bond_create(s, fx);
   }
   return 0;
 }
@@ -1181,6 +1270,7 @@ static int verlet_setup(leo_t *s) {
   if (bond_compute(s, 1)) return 1;
   /* modify->setup: FixLangevin::setup -> post_force (src/fix_langevin.cpp:372-373) */
   for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_post_force(s, &s->fix[k]);
+  for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_BOND_CREATE) bond_create_setup(s, &s->fix[k]);
   thermo_record(s);
   return 0;
 }

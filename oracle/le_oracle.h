@@ -73,6 +73,8 @@ void   leo_fix_ex_load(leo_t *s, int nevery, int iatomtype, int jatomtype, doubl
                        int btype, int imaxbond, int inewtype, int jmaxbond, int jnewtype,
                        double fraction, int seed);
 void   leo_fix_ex_unload(leo_t *s, int nevery, int btype, double cutoff, double fraction, int seed);
+void   leo_fix_bond_create(leo_t *s, int nevery, int it, int jt, double cutoff, int btype, int imax, int inew,
+                           int jmax, int jnew, double fraction, int seed);
 void   leo_fix_bond_break(leo_t *s, int nevery, int btype, double cutoff, double fraction, int seed);
 
 /* ---- running ---- */

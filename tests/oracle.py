@@ -146,6 +146,14 @@ class Oracle:
         self.L.leo_fix_ex_unload(self.h, nevery, btype, C.c_double(cutoff), C.c_double(fraction), seed)
         self._reg(fid)
 
+    def fix_bond_create(self, nevery, it, jt, cutoff, btype, imax=0, inew=None, jmax=0, jnew=None, fraction=1.0,
+                        seed=12345, fid="creating"):
+        inew = it if inew is None else inew
+        jnew = jt if jnew is None else jnew
+        self.L.leo_fix_bond_create(self.h, nevery, it, jt, C.c_double(cutoff), btype, imax, inew, jmax, jnew,
+                                   C.c_double(fraction), seed)
+        self._reg(fid)
+
     def fix_bond_break(self, nevery, btype, cutoff, fraction=1.0, seed=12345, fid="breaking"):
         self.L.leo_fix_bond_break(self.h, nevery, btype, C.c_double(cutoff), C.c_double(fraction), seed)
         self._reg(fid)

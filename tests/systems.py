@@ -198,7 +198,7 @@ class OracleScript:
             elif style == "extrusion":
                 o.fix_extrusion(int(p[0]), int(p[1]), int(p[2]), int(p[3]), float(p[4]), int(p[5]),
                                 int(p[6]) if len(p) > 6 else -1, fid)
-            elif style == "ex_load":
+            elif style in ("ex_load", "bond/create"):
                 kw = dict(imax=0, inew=None, jmax=0, jnew=None, fraction=1.0, seed=12345)
                 k = 5
                 while k < len(p):
@@ -209,7 +209,7 @@ class OracleScript:
                     elif p[k] == "prob":
                         kw["fraction"], kw["seed"] = float(p[k + 1]), int(p[k + 2])
                     k += 3
-                o.fix_ex_load(int(p[0]), int(p[1]), int(p[2]), float(p[3]), int(p[4]), fid=fid, **kw)
+                (o.fix_ex_load if style == "ex_load" else o.fix_bond_create)(int(p[0]), int(p[1]), int(p[2]), float(p[3]), int(p[4]), fid=fid, **kw)
             elif style in ("ex_unload", "bond/break"):
                 kw = dict(fraction=1.0, seed=12345)
                 if len(p) > 3 and p[3] == "prob":

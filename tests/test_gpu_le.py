@@ -113,6 +113,53 @@ def test_stock_bond_break_in_place_of_ex_unload(tmp_path):
     assert o2.bond_set() != o.bond_set()
 
 
+@pytest.mark.parametrize("prob", ["", "prob 0.5 8847"])
+def test_stock_bond_create_sticky_beads(tmp_path, prob):
+    """`fix bond/create` (src/MC): any two type-2 beads closer than 1.1 may bond (closest mutual partner wins), one bond
+    per bead, bonded beads become type 3; `fix bond/break` opens stretched ones again (it does not lower the creator's
+    bond count: a bead that was bonded once stays type 3, as in the reference)."""
+    n = 4000
+    rng = np.random.RandomState(3)
+    types = np.where(rng.rand(n) < 0.3, 2, 1).astype(np.int32)
+    s = melted(n, types=types)
+    s["ntypes"], s["mass"] = 3, [1.0, 1.0, 1.0]
+    script = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0") + (
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
+        "fix creating all bond/create 10 2 2 1.1 2 iparam 1 3 jparam 1 3 %s\n"
+        "fix breaking all bond/break 15 2 1.3 prob 0.5 2211\nthermo 10\nrun 65\n" % prob)
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("creating", "breaking"))
+    assert o.fix_vector("creating")[1] > 20 and o.fix_vector("breaking")[1] > 0
+    assert (o.types() == 3).sum() >= 2 * o.fix_vector("creating")[1] - 2 * o.fix_vector("breaking")[1]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_stock_bond_create_randomised(tmp_path, seed):
+    """bond/create between two DIFFERENT types with unequal bond limits and new types, random cadence and probability;
+    natural reneighbor schedule (the fix scans the pair list of the last build)."""
+    rng = np.random.RandomState(100 + seed)
+    n = 3000
+    u = rng.rand(n)
+    types = np.where(u < 0.2, 2, np.where(u < 0.45, 3, 1)).astype(np.int32)
+    s = melted(n, seed=1 + seed % 2, types=types)
+    s["ntypes"], s["mass"] = 5, [1.0] * 5
+    imax, jmax = 1, 1      # (two extra bonds per bead would overflow the 32-entry special lists the device handles)
+    prob = "" if seed % 3 == 0 else "prob %.2f %d" % (rng.uniform(0.2, 0.9), rng.randint(1, 900000))
+    script = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0") \
+        .replace("1 extra bond per atom", "2 extra bond per atom") + (
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 %d\n"
+        "fix creating all bond/create %d 2 3 %.3f 2 iparam %d 4 jparam %d 5 %s\n"
+        "fix breaking all bond/break %d 2 %.2f prob 0.4 %d\nthermo 10\nrun %d\n"
+        % (rng.randint(1, 900000), rng.randint(3, 12), rng.uniform(1.0, 1.12), imax, jmax, prob, rng.randint(4, 15),
+           rng.uniform(1.2, 1.5), rng.randint(1, 900000), 70))
+    s["extra_bond"], s["extra_special"] = 2, 26
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("creating", "breaking"))
+    assert o.fix_vector("creating")[1] > 5
+
+
 def test_dense_extruders_collide_and_stall(tmp_path):
     """No prob keyword -> every eligible (i,i+2) pair loads (first-order recurrence over runs of candidates);
     extruders then collide head-on and stall; nothing unloads."""

@@ -49,7 +49,8 @@ def test_script_layer_and_queries(tmp_path):
     lmp.command("fix loading all ex_load 1000 1 1 1.12 2 prob 0.5 684474 iparam 1 1 jparam 1 1")
     lmp.command("fix unloading all ex_unload 1000 2 0.5 prob 0.5 456456")
     lmp.command("fix breaking all bond/break 1000 2 0.5 prob 0.5 456456")          # src/MC/fix_bond_break.cpp grammar
-    for style in ("nve", "langevin", "extrusion", "ex_load", "ex_unload", "bond/break"):
+    lmp.command("fix creating all bond/create 1000 1 1 1.1 2 iparam 2 1 jparam 2 1 prob 0.5 8847")   # src/MC/fix_bond_create.cpp grammar
+    for style in ("nve", "langevin", "extrusion", "ex_load", "ex_unload", "bond/break", "bond/create"):
         assert lmp.has_style("fix", style)
 
 
