@@ -286,8 +286,16 @@ class Engine {
   void say(const std::string &s);
   void warning(const std::string &s);
   std::string last_cmd;
-  std::map<std::string, std::string> variables;
+  std::map<std::string, std::string> variables;       // name -> current value (index / loop / string) or formula (equal)
+  struct VarInfo { std::string style; std::vector<std::string> values; size_t which = 0; };
+  std::map<std::string, VarInfo> var_info;            // style + value list of variables made by the `variable` command
   std::string substitute(const std::string &line);
+  double evaluate(const std::string &expr);           // equal-style formulas, $(...) and `if` conditions
+  double variable_value(const std::string &name);
+  // script control flow (src/input.cpp: label :1057, jump :1011, next :1079, if :851, include :989)
+  std::string jump_file, jump_label;                  // set by `jump`, consumed by file()
+  bool jump_pending = false, jump_skip = false, quit_requested = false;
+  int file_depth = 0;
 
   // error state for the C API (src/library.cpp LAMMPS_EXCEPTIONS behaviour)
   std::string last_error;

@@ -50,12 +50,151 @@ std::vector<std::string> split_words(const std::string &line) {
   return w;
 }
 
-// ${name} and $x substitution (src/input.cpp:473- substitute), index/string/equal-constant variables only
+// ---------------------------------------------------------------------------------------------
+// formulas (src/variable.cpp Variable::evaluate, the subset a bead-spring script uses): numbers, + - * / % ^, unary -,
+// comparisons and && || !, parentheses, sqrt exp ln log abs sin cos tan floor ceil round min max, thermo keywords
+// (step dt atoms bonds vol temp press pe ke etotal epair emol), v_name, f_ID[k]
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Parser {
+  Engine *e; const std::string &s; size_t i = 0;
+  Parser(Engine *eng, const std::string &str) : e(eng), s(str) {}
+  void ws() { while (i < s.size() && isspace((unsigned char)s[i])) i++; }
+  bool eat(const char *tok) { ws(); size_t n = strlen(tok); if (s.compare(i, n, tok) == 0) { i += n; return true; } return false; }
+  [[noreturn]] void bad() { throw LammpsError("Invalid syntax in variable formula: " + s); }
+  double expr() { return lor(); }
+  double lor() { double v = land(); while (eat("||")) { double r = land(); v = (v != 0.0 || r != 0.0) ? 1.0 : 0.0; } return v; }
+  double land() { double v = cmp(); while (eat("&&")) { double r = cmp(); v = (v != 0.0 && r != 0.0) ? 1.0 : 0.0; } return v; }
+  double cmp() {
+    double v = add();
+    for (;;) {
+      if (eat("==")) v = (v == add()) ? 1.0 : 0.0;
+      else if (eat("!=")) v = (v != add()) ? 1.0 : 0.0;
+      else if (eat("<=")) v = (v <= add()) ? 1.0 : 0.0;
+      else if (eat(">=")) v = (v >= add()) ? 1.0 : 0.0;
+      else if (eat("<")) v = (v < add()) ? 1.0 : 0.0;
+      else if (eat(">")) v = (v > add()) ? 1.0 : 0.0;
+      else return v;
+    }
+  }
+  double add() { double v = mul(); for (;;) { if (eat("+")) v += mul(); else if (eat("-")) v -= mul(); else return v; } }
+  double mul() {
+    double v = unary();
+    for (;;) {
+      if (eat("*")) v *= unary();
+      else if (eat("/")) { double r = unary(); if (r == 0.0) throw LammpsError("Divide by 0 in variable formula"); v /= r; }
+      else if (eat("%")) { double r = unary(); if (r == 0.0) throw LammpsError("Modulo 0 in variable formula"); v = fmod(v, r); }
+      else return v;
+    }
+  }
+  double unary() { if (eat("-")) return -unary(); if (eat("!")) return unary() == 0.0 ? 1.0 : 0.0; return power(); }
+  double power() { double v = atom(); if (eat("^")) { double r = unary(); v = pow(v, r); } return v; }
+  double atom() {
+    ws();
+    if (i >= s.size()) bad();
+    if (s[i] == '(') { i++; double v = expr(); if (!eat(")")) bad(); return v; }
+    if (isdigit((unsigned char)s[i]) || s[i] == '.') {
+      char *end = nullptr;
+      double v = strtod(s.c_str() + i, &end);
+      if (end == s.c_str() + i) bad();
+      i = end - s.c_str();
+      return v;
+    }
+    size_t j = i;
+    while (j < s.size() && (isalnum((unsigned char)s[j]) || s[j] == '_')) j++;
+    if (j == i) bad();
+    std::string name = s.substr(i, j - i);
+    i = j;
+    if (name.rfind("v_", 0) == 0) return e->variable_value(name.substr(2));
+    if (name.rfind("f_", 0) == 0) {
+      int idx = 1;
+      if (i < s.size() && s[i] == '[') { size_t k = s.find(']', i); if (k == std::string::npos) bad(); idx = atoi(s.c_str() + i + 1); i = k + 1; }
+      Fix *f = e->find_fix(name.substr(2));
+      if (!f) throw LammpsError("Invalid fix ID in variable formula");
+      return f->compute_vector(idx - 1);
+    }
+    ws();
+    if (i < s.size() && s[i] == '(') {   // function
+      i++;
+      double a = expr(), b = 0.0;
+      bool two = eat(",");
+      if (two) b = expr();
+      if (!eat(")")) bad();
+      if (name == "sqrt") { if (a < 0.0) throw LammpsError("Sqrt of negative value in variable formula"); return sqrt(a); }
+      if (name == "exp") return exp(a);
+      if (name == "ln") { if (a <= 0.0) throw LammpsError("Log of zero/negative value in variable formula"); return log(a); }
+      if (name == "log") { if (a <= 0.0) throw LammpsError("Log of zero/negative value in variable formula"); return log10(a); }
+      if (name == "abs") return fabs(a);
+      if (name == "sin") return sin(a);
+      if (name == "cos") return cos(a);
+      if (name == "tan") return tan(a);
+      if (name == "floor") return floor(a);
+      if (name == "ceil") return ceil(a);
+      if (name == "round") return (double)llround(a);
+      if (name == "min" && two) return a < b ? a : b;
+      if (name == "max" && two) return a > b ? a : b;
+      throw LammpsError("Invalid math function in variable formula: " + name);
+    }
+    const ThermoRow &r = e->last_thermo;
+    if (name == "step") return (double)e->ntimestep;
+    if (name == "dt") return e->dt;
+    if (name == "atoms") return (double)e->natoms;
+    if (name == "bonds") return (double)e->nbonds;
+    if (name == "vol") return e->box.prd[0] * e->box.prd[1] * e->box.prd[2];
+    if (name == "temp") return r.temp;
+    if (name == "press") return r.press;
+    if (name == "pe") return r.pe;
+    if (name == "ke") return r.ke;
+    if (name == "etotal") return r.etotal;
+    if (name == "epair" || name == "evdwl") return r.epair;
+    if (name == "emol" || name == "ebond") return r.emol;
+    if (name == "PI") return 3.14159265358979323846;
+    throw LammpsError("Invalid thermo keyword in variable formula: " + name);
+  }
+};
+std::string fmt_g15(double v) { char buf[64]; snprintf(buf, sizeof buf, "%.15g", v); return buf; }
+}  // namespace
+
+double Engine::evaluate(const std::string &expr) {
+  Parser p(this, expr);
+  double v = p.expr();
+  p.ws();
+  if (p.i != expr.size()) throw LammpsError("Invalid syntax in variable formula: " + expr);
+  return v;
+}
+double Engine::variable_value(const std::string &name) {
+  auto it = variables.find(name);
+  if (it == variables.end()) throw LammpsError("Invalid variable name in variable formula: " + name);
+  auto vi = var_info.find(name);
+  if (vi != var_info.end() && vi->second.style == "equal") return evaluate(it->second);
+  char *end = nullptr;
+  double v = strtod(it->second.c_str(), &end);
+  if (end == it->second.c_str() || *end) throw LammpsError("Variable " + name + " is not a number in variable formula");
+  return v;
+}
+
+// ${name}, $x and $(formula[:format]) substitution (src/input.cpp:473-640 substitute)
 std::string Engine::substitute(const std::string &line) {
   std::string out;
+  char quote = 0;          // no replacement inside single / double quotes (src/input.cpp:513); print and if re-substitute
   for (size_t i = 0; i < line.size(); i++) {
+    if (quote) { if (line[i] == quote) quote = 0; out += line[i]; continue; }
+    if (line[i] == '"' || line[i] == '\'') { quote = line[i]; out += line[i]; continue; }
     if (line[i] != '$') { out += line[i]; continue; }
     std::string name;
+    if (i + 1 < line.size() && line[i + 1] == '(') {            // immediate formula
+      int depth = 0; size_t j = i + 1;
+      for (; j < line.size(); j++) { if (line[j] == '(') depth++; else if (line[j] == ')' && --depth == 0) break; }
+      if (j >= line.size()) throw LammpsError("Invalid immediate variable");
+      std::string body = line.substr(i + 2, j - i - 2), f = "%.15g";
+      size_t colon = body.rfind(':');
+      if (colon != std::string::npos && body.find('%', colon) != std::string::npos) { f = body.substr(colon + 1); body = body.substr(0, colon); }
+      char buf[128];
+      snprintf(buf, sizeof buf, f.c_str(), evaluate(body));
+      out += buf;
+      i = j;
+      continue;
+    }
     if (i + 1 < line.size() && line[i + 1] == '{') {
       size_t j = line.find('}', i);
       if (j == std::string::npos) throw LammpsError("Invalid variable name");
@@ -67,24 +206,55 @@ std::string Engine::substitute(const std::string &line) {
     }
     auto it = variables.find(name);
     if (it == variables.end()) throw LammpsError("Substitution for illegal variable " + name);
-    out += it->second;
+    auto vi = var_info.find(name);
+    if (vi != var_info.end() && vi->second.style == "equal") out += fmt_g15(evaluate(it->second));
+    else out += it->second;
   }
   return out;
 }
 
-void Engine::file(const std::string &path) {
-  std::ifstream in(path);
-  if (!in) throw LammpsError("Cannot open input script " + path);
-  std::string line, acc;
-  while (std::getline(in, line)) {
-    // '&' continuation (src/input.cpp:210-231)
-    size_t e = line.find_last_not_of(" \t\r\n");
-    if (e != std::string::npos && line[e] == '&') { acc += line.substr(0, e) + " "; continue; }
-    acc += line;
-    one(acc);
-    acc.clear();
+// Input::file (src/input.cpp:181-290) incl. label / jump: `jump` re-opens a file (or SELF) and skips to the label
+void Engine::file(const std::string &path_in) {
+  std::string path = path_in, want_label;
+  if (++file_depth > 16) { file_depth--; throw LammpsError("Too many nested levels of input scripts"); }
+  struct Depth { int &d; ~Depth() { d--; } } guard{file_depth};
+  for (;;) {
+    std::ifstream in(path);
+    if (!in) throw LammpsError("Cannot open input script " + path);
+    std::vector<std::string> lines;
+    std::string line, acc;
+    while (std::getline(in, line)) {
+      // '&' continuation (src/input.cpp:210-231)
+      size_t e = line.find_last_not_of(" \t\r\n");
+      if (e != std::string::npos && line[e] == '&') { acc += line.substr(0, e) + " "; continue; }
+      acc += line;
+      lines.push_back(acc);
+      acc.clear();
+    }
+    if (!acc.empty()) lines.push_back(acc);
+    bool jumped = false;
+    for (size_t k = 0; k < lines.size(); k++) {
+      if (!want_label.empty()) {            // skipping to a label: only `label X` lines are looked at
+        std::vector<std::string> w = split_words(lines[k].substr(0, lines[k].find('#')));
+        if (w.size() == 2 && w[0] == "label" && w[1] == want_label) want_label.clear();
+        continue;
+      }
+      jump_pending = false;
+      one(lines[k]);
+      if (quit_requested) return;
+      if (jump_pending) {
+        jump_pending = false;
+        if (jump_file != "SELF") path = jump_file;
+        want_label = jump_label;
+        jumped = true;
+        break;
+      }
+    }
+    if (!jumped) {
+      if (!want_label.empty()) throw LammpsError("Label wasn't found in input script");
+      return;
+    }
   }
-  if (!acc.empty()) one(acc);
 }
 
 const char *Engine::one(const std::string &raw) {
@@ -361,7 +531,12 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
     ntimestep = atol(arg[0].c_str());
   } else if (cmd == "run") {
     need(1);
-    run(atol(arg[0].c_str()));
+    long nrun = atol(arg[0].c_str());
+    for (size_t k = 1; k < arg.size(); k++) {
+      if (arg[k] == "upto") { nrun -= ntimestep; if (nrun < 0) throw LammpsError("Run command upto value is before current timestep"); }
+      else throw LammpsError("MI355X engine: run keyword " + arg[k] + " is not supported");
+    }
+    run(nrun);
   } else if (cmd == "write_data") {
     need(1);
     write_data(arg[0]);
@@ -444,15 +619,118 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
       if (dumps[k].id == arg[0]) { if (dumps[k].fp) fclose(dumps[k].fp); dumps.erase(dumps.begin() + k); found = true; break; }
     if (!found) throw LammpsError("Could not find undump ID");
   } else if (cmd == "variable") {
+    // variable name style args   (src/variable.cpp:82-520: index, loop, string, equal, delete)
+    need(2);
+    const std::string &name = arg[0], &st = arg[1];
+    if (st == "delete") { variables.erase(name); var_info.erase(name); return; }
     need(3);
-    if (arg[1] == "index" || arg[1] == "string" || arg[1] == "equal") {
-      if (arg[1] == "index" && variables.count(arg[0])) return;   // command-line -var wins
-      variables[arg[0]] = arg[2];
-    } else throw LammpsError("MI355X engine: variable style " + arg[1] + " not supported");
+    if (st == "index") {
+      if (variables.count(name)) return;                          // already defined (incl. command-line -var): ignored
+      VarInfo vi; vi.style = st; vi.values.assign(arg.begin() + 2, arg.end());
+      variables[name] = vi.values[0]; var_info[name] = vi;
+    } else if (st == "loop") {
+      if (variables.count(name)) return;
+      // loop N | loop N pad | loop N1 N2 | loop N1 N2 pad
+      long n1 = 1, n2 = 0; bool pad = false;
+      std::vector<std::string> a(arg.begin() + 2, arg.end());
+      if (!a.empty() && a.back() == "pad") { pad = true; a.pop_back(); }
+      if (a.size() == 1) n2 = atol(a[0].c_str());
+      else if (a.size() == 2) { n1 = atol(a[0].c_str()); n2 = atol(a[1].c_str()); }
+      else throw LammpsError("Illegal variable command");
+      if (n2 < n1 || n1 < 0) throw LammpsError("Illegal variable command");
+      VarInfo vi; vi.style = st;
+      size_t width = std::to_string(n2).size();
+      for (long v = n1; v <= n2; v++) {
+        std::string sv = std::to_string(v);
+        if (pad && sv.size() < width) sv = std::string(width - sv.size(), '0') + sv;
+        vi.values.push_back(sv);
+      }
+      variables[name] = vi.values[0]; var_info[name] = vi;
+    } else if (st == "string") {
+      VarInfo vi; vi.style = st; vi.values = {arg[2]};
+      variables[name] = arg[2]; var_info[name] = vi;
+    } else if (st == "equal") {
+      std::string f;
+      for (size_t k = 2; k < arg.size(); k++) f += arg[k];
+      VarInfo vi; vi.style = st; vi.values = {f};
+      variables[name] = f; var_info[name] = vi;
+    } else throw LammpsError("MI355X engine: variable style " + st + " not supported");
+  } else if (cmd == "next") {
+    // src/variable.cpp:560-700: advance every listed variable; an exhausted one is deleted and the next jump is skipped
+    need(1);
+    for (auto &name : arg) {
+      auto vi = var_info.find(name);
+      if (vi == var_info.end()) {
+        if (!variables.count(name)) throw LammpsError("Invalid variable in next command");
+        variables.erase(name); jump_skip = true;                 // a -var command-line value has no successor
+        continue;
+      }
+      if (vi->second.style != "index" && vi->second.style != "loop") throw LammpsError("Invalid variable style with next command");
+      if (++vi->second.which >= vi->second.values.size()) { variables.erase(name); var_info.erase(vi); jump_skip = true; }
+      else variables[name] = vi->second.values[vi->second.which];
+    }
+  } else if (cmd == "label") {
+    need(1);
+  } else if (cmd == "jump") {
+    need(1);
+    if (jump_skip) { jump_skip = false; return; }
+    if (file_depth == 0) throw LammpsError("MI355X engine: jump is only available inside an input script");
+    jump_file = arg[0];
+    jump_label = arg.size() > 1 ? arg[1] : "";
+    jump_pending = true;
+  } else if (cmd == "include") {
+    need(1);
+    file(arg[0]);
+  } else if (cmd == "if") {
+    // if boolean then t1 t2 ... elif boolean f1 ... else e1 ...   (src/input.cpp:851-986)
+    need(3);
+    if (arg[1] != "then") throw LammpsError("Illegal if command");
+    auto truth = [&](const std::string &b0) {
+      const std::string b = substitute(b0);                       // src/input.cpp:842, :901 (the Boolean may be quoted)
+      try { return evaluate(b) != 0.0; }
+      catch (LammpsError &) {
+        for (const char *op : {"==", "!="}) {                    // string comparison
+          size_t k = b.find(op);
+          if (k == std::string::npos) continue;
+          auto trim = [](std::string t) { size_t x = t.find_first_not_of(" \t"), y = t.find_last_not_of(" \t"); return x == std::string::npos ? std::string() : t.substr(x, y - x + 1); };
+          bool eq = trim(b.substr(0, k)) == trim(b.substr(k + 2));
+          return (op[0] == '=') ? eq : !eq;
+        }
+        throw;
+      }
+    };
+    std::vector<std::string> todo;
+    bool done = false, cond = truth(arg[0]);
+    size_t k = 2;
+    for (;;) {
+      size_t first = k;
+      while (k < arg.size() && arg[k] != "elif" && arg[k] != "else") k++;
+      if (first == k) throw LammpsError("Illegal if command");
+      if (cond && !done) { todo.assign(arg.begin() + first, arg.begin() + k); done = true; }
+      if (k == arg.size()) break;
+      if (arg[k] == "elif") {
+        if (k + 1 >= arg.size()) throw LammpsError("Illegal if command");
+        cond = done ? false : truth(arg[k + 1]);
+        k += 2;
+      } else { cond = true; k++; }
+    }
+    for (auto &c : todo) { one(c); if (jump_pending || quit_requested) break; }
+  } else if (cmd == "quit") {
+    quit_requested = true;
+  } else if (cmd == "log") {
+    need(1);
+    if (logfile) { fclose(logfile); logfile = nullptr; }
+    if (arg[0] != "none") {
+      logfile = fopen(arg[0].c_str(), (arg.size() > 1 && arg[1] == "append") ? "a" : "w");
+      if (!logfile) throw LammpsError("Cannot open logfile " + arg[0]);
+    }
+  } else if (cmd == "echo") {
+    need(1);
+    echo_screen = (arg[0] == "screen" || arg[0] == "both");
   } else if (cmd == "print") {
     need(1);
-    say(arg[0] + "\n");
-  } else if (cmd == "echo" || cmd == "log" || cmd == "timer" || cmd == "processors" || cmd == "package" ||
+    say(substitute(arg[0]) + "\n");                              // src/input.cpp:1093
+  } else if (cmd == "timer" || cmd == "processors" || cmd == "package" ||
              cmd == "suffix" || cmd == "group" || cmd == "velocity_zero") {
     if (cmd == "group" && !(arg.size() >= 1 && arg[0] == "all"))
       throw LammpsError("MI355X engine: only group all is supported");

@@ -233,3 +233,71 @@ def test_velocity_set_scale_zero_sum(tmp_path):
     lmp.command("velocity all set 0 0 0")
     with pytest.raises(LammpsError, match="Attempting to rescale a 0.0 temperature"):   # src/velocity.cpp:735
         lmp.command("velocity all scale 1.0")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# script control flow: variable index / loop / equal, next, label, jump, if, include, $(...) (src/input.cpp, variable.cpp)
+def test_script_control_flow(tmp_path):
+    from lammps_le_amd import lammps
+    s = lattice_chain(200)
+    data = os.path.join(str(tmp_path), "data.chain")
+    write_data(data, s)
+    log = tmp_path / "log.flow"
+    inc = tmp_path / "in.inc"
+    inc.write_text('print "included ${tag}"\n')
+    script = tmp_path / "in.flow"
+    script.write_text(CHAIN_SCRIPT.replace("data.chain", data) + f'''
+log {log}
+variable tag string alpha
+variable i loop 3
+variable f index {tmp_path}/a.data {tmp_path}/b.data
+variable twice equal 2*v_i+atoms/100
+label top
+print "pass $i of 3: twice=${{twice}} next=$(v_i+1) fmt=$(v_i/4:%.3f)"
+if "$i == 2" then "print 'second pass'" "variable tag string beta" elif "$i > 2" "print 'late'" else "print 'first pass'"
+include {inc}
+next i
+jump SELF top
+print "after loop"
+variable k loop 2 4 pad
+label again
+write_data ${{f}}
+next f
+next k
+jump SELF again
+if "${{tag}} == beta" then "print 'string compare ok'"
+print "done $(step)"
+''')
+    lmp = lammps(cmdargs=["-screen", "none"])
+    lmp.file(str(script))
+    lmp.close()
+    text = log.read_text().split("\n")
+    assert "pass 1 of 3: twice=4 next=2 fmt=0.250" in text
+    assert "pass 2 of 3: twice=6 next=3 fmt=0.500" in text
+    assert "pass 3 of 3: twice=8 next=4 fmt=0.750" in text
+    assert [t for t in text if t in ("first pass", "second pass", "late")] == ["first pass", "second pass", "late"]
+    assert [t for t in text if t.startswith("included")] == ["included alpha", "included beta", "included beta"]
+    assert "after loop" in text and "string compare ok" in text and "done 0" in text
+    assert os.path.exists(tmp_path / "a.data") and os.path.exists(tmp_path / "b.data")   # f ran out first: loop left after 2
+
+
+def test_script_control_flow_errors(tmp_path):
+    from lammps_le_amd import LammpsError
+    lmp, _ = _open(tmp_path, 50)
+    with pytest.raises(LammpsError, match="Substitution for illegal variable"):
+        lmp.command("print ${nope}")
+    with pytest.raises(LammpsError, match="Illegal if command"):
+        lmp.command('if "1 > 0" print')
+    with pytest.raises(LammpsError, match="Divide by 0"):
+        lmp.command("variable z equal 1/0")
+        lmp.command("print ${z}")
+    with pytest.raises(LammpsError, match="jump is only available inside an input script"):
+        lmp.command("jump SELF x")
+    p = tmp_path / "in.nolabel"
+    p.write_text("jump SELF missing\n")
+    with pytest.raises(LammpsError, match="Label wasn't found"):
+        lmp.file(str(p))
+    lmp.command("variable a equal (3+4)*2^2-sqrt(16)")
+    lmp.command("variable b equal v_a>=24&&!(v_a>24)")
+    lmp.command('if "${b}" then "variable ok string yes"')
+    lmp.command("print ${ok}")
