@@ -682,7 +682,8 @@ void Engine::iterate(long nsteps) {
   for (long it = 0; it < nsteps; it++) {
     ntimestep++;
     bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
-    const bool dump_now = !dumps.empty() && dump_due(ntimestep);   // needs x, v AND f of this step: unfused path
+    const bool restart_now = restart_every > 0 && ntimestep % restart_every == 0;
+    const bool dump_now = (!dumps.empty() && dump_due(ntimestep)) || restart_now;   // needs the complete state of this step: unfused path
     TypeTables tt = make_tables(this, lg);
     if (!pre_integrated) {
       bool will_check = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
@@ -746,6 +747,7 @@ void Engine::iterate(long nsteps) {
         print_thermo(last_thermo);
       }
       if (dump_now) write_dumps(ntimestep);
+      if (restart_now) write_periodic_restart(ntimestep);
     }
   }
   HIP_CHECK(hipStreamSynchronize(d.stream));

@@ -254,6 +254,11 @@ class Engine {
   // ---- restart: own binary format, bit-continuous incl. the RNG streams of the fixes ----
   void write_restart(const std::string &path);
   void read_restart(const std::string &path);
+  // `restart N root` | `restart N fileA fileB` | `restart 0` (src/output.cpp:603-700 create_restart, :360-420 write_restart)
+  long restart_every = 0;
+  std::string restart_a, restart_b;
+  int restart_toggle = 0;
+  void write_periodic_restart(long step);
   std::map<std::string, std::vector<unsigned char>> restart_fix_state;   // fix ID -> saved state, applied by `fix`
   void apply_restart_state(Fix *f);
   bool dump_due(long step) const;

@@ -545,6 +545,16 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
   } else if (cmd == "write_restart") {
     need(1);
     write_restart(arg[0]);
+  } else if (cmd == "restart") {
+    need(1);
+    restart_every = atol(arg[0].c_str());
+    if (restart_every < 0) throw LammpsError("Illegal restart command");
+    restart_a.clear(); restart_b.clear(); restart_toggle = 0;
+    if (restart_every > 0) {
+      if (arg.size() != 2 && arg.size() != 3) throw LammpsError("Illegal restart command");
+      restart_a = arg[1];
+      if (arg.size() == 3) restart_b = arg[2];
+    }
   } else if (cmd == "read_restart") {
     need(1);
     if (box_exist) throw LammpsError("Cannot read_restart after simulation box is defined");   // src/read_restart.cpp:60
@@ -1307,6 +1317,21 @@ template <class T> void blob_get(const std::vector<unsigned char> &b, size_t &of
 }  // namespace
 
 void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
+
+// Output::write_restart (src/output.cpp:360-420): one file per due step (`root.step`, or `*` replaced by the step), or two
+// files written in turn
+void Engine::write_periodic_restart(long step) {
+  std::string path;
+  if (!restart_b.empty()) { path = restart_toggle ? restart_b : restart_a; restart_toggle ^= 1; }
+  else {
+    size_t star = restart_a.find('*');
+    path = (star == std::string::npos) ? restart_a + "." + std::to_string(step)
+                                        : restart_a.substr(0, star) + std::to_string(step) + restart_a.substr(star + 1);
+  }
+  host_current = false;       // mid-run: the device holds the state of this step
+  write_restart(path);
+  host_current = false;
+}
 
 void Engine::write_restart(const std::string &path) {
   if (!box_exist) throw LammpsError("Write_restart command before simulation box is defined");   // src/write_restart.cpp:62

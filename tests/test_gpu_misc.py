@@ -221,6 +221,41 @@ def test_restart_is_bit_continuous(tmp_path):
         b.command("read_restart " + rfile)
 
 
+def test_periodic_restart_files(tmp_path):
+    """`restart N root` writes root.N, root.2N, ... DURING a run (state of that step, incl. the generator positions):
+    reading root.25, written inside `run 50`, and running 25 more steps equals `run 25; run 25` bit for bit; the run
+    that wrote the files is the same run to FP tolerance; `restart N a b` alternates two files."""
+    from lammps_le_amd import lammps
+    n = 3000
+    s = melted(n, seed=5, types=barrier_types(n, 7))
+    base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0")
+    le = LE.format(n1=6, nl=5, nu=7, neutral=1, left=2, right=3, tp=0.5, lr="4", lprob="prob 0.6 101", uprob="prob 0.3 202",
+                   rmax=1.3)
+    a = run_product(base + le + "run 25\nrun 25\n", s, tmp_path)
+    root = str(tmp_path / "poly.restart")
+    w = run_product(base + le + "restart 25 %s\nrun 50\n" % root, s, tmp_path)
+    plain = run_product(base + le + "run 50\n", s, tmp_path)
+    # (a step that writes a file runs the unfused kernels, as a thermo step does: same arithmetic, other rounding)
+    assert np.abs(w.gather("x") - plain.gather("x")).max() < 1e-9 and w.bond_set() == plain.bond_set()
+    assert os.path.exists(root + ".25") and os.path.exists(root + ".50")
+    b = lammps(cmdargs=["-screen", "none"])
+    b.command("read_restart " + root + ".25")
+    for ln in (le + "run 25\n").split("\n"):
+        b.command(ln)
+    for name in ("x", "v", "image", "type", "num_bond", "bond_type", "bond_atom", "nspecial", "special"):
+        assert np.array_equal(a.gather(name), b.gather(name)), name
+    for fid in ("loop", "loading", "unloading"):
+        assert a.extract_fix(fid, 0, 1, 1) == b.extract_fix(fid, 0, 1, 1)
+    fa, fb = str(tmp_path / "t.a"), str(tmp_path / "t.b")
+    w.command("restart 10 %s %s" % (fa, fb))
+    w.command("run 30")
+    assert os.path.exists(fa) and os.path.exists(fb)
+    c = lammps(cmdargs=["-screen", "none"])
+    c.command("read_restart " + fa)          # third write (step 80) went to file a again
+    assert c.get_thermo("step") == 80
+    w.command("restart 0")
+
+
 def test_neighbor_table_overflow_is_recovered(tmp_path, monkeypatch):
     """A list that does not fit the ELL table: at setup the build is repeated at once; inside the loop the step kernel
     has already been enqueued behind the build (deferred check) - it must leave the state untouched, and the host must
