@@ -207,6 +207,17 @@ def comm_unique_id():
     return buf.raw
 
 
+def use_torch_rccl():
+    """Point the engine at the RCCL copy PyTorch has already loaded (torch/lib/librccl.so), so that the process runs one
+    RCCL instance.  No effect when LAMMPS_LE_RCCL_LIB is set by the user or torch ships no copy."""
+    if os.environ.get("LAMMPS_LE_RCCL_LIB"):
+        return
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(cand):
+        os.environ["LAMMPS_LE_RCCL_LIB"] = cand
+
+
 def init_from_torch_distributed(lmp):
     """Give every rank of an initialised torch.distributed group the same RCCL unique id and join the engine's
     own communicator (RANK / WORLD_SIZE from the process group).  Used by bench.py."""
@@ -215,6 +226,7 @@ def init_from_torch_distributed(lmp):
     rank, world = dist.get_rank(), dist.get_world_size()
     if world == 1:
         return
+    use_torch_rccl()
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.zeros(128, dtype=torch.uint8, device=dev)
     if rank == 0:

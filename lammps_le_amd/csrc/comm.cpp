@@ -51,7 +51,10 @@ struct Rccl {
   const char *(*GetErrorString)(int) = nullptr;
   void load() {
     if (h) return;
-    h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // a process that already runs an RCCL (PyTorch ships its own copy under torch/lib) names it here, so that both
+    // users share ONE library instance instead of two different builds living side by side
+    if (const char *lib = getenv("LAMMPS_LE_RCCL_LIB")) h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) throw LammpsError(std::string("cannot load librccl.so: ") + dlerror());
 #define SYM(f) *(void **)(&f) = dlsym(h, "nccl" #f); if (!f) throw LammpsError("librccl.so lacks nccl" #f)

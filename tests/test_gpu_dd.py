@@ -170,6 +170,20 @@ def test_rccl_bindings_on_one_rank():
     assert lib.lammps_le_rccl_selftest() == 0
 
 
+@pytest.mark.parametrize("mode", ["shared", "own"])
+def test_rccl_next_to_a_torch_process_group(mode):
+    """bench.py --gpus N runs the engine's communicator in a process where torch.distributed (NCCL = RCCL) is alive.
+    `shared`: the engine binds the RCCL copy torch loaded (one library instance, what bench.py does);
+    `own`: it loads the system copy next to torch's.  Both must pass the binding self-test and leave torch working."""
+    port = 29000 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, os.path.join(HERE, "rccl_with_torch_worker.py"), str(port), mode],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    files = [ln for ln in r.stdout.split("\n") if ln.startswith("RCCL_FILES")][0].split()
+    if mode == "shared":
+        assert int(files[1]) == 1, files
+
+
 def test_eight_slabs_with_the_bench_script(tmp_path):
     """The shape of the 8-GPU scaling run: eight z-slabs, `comm_modify cutoff 5.0`, the bench input with the three LE
     fixes firing - here on 500k beads (slabs 10.5 thick, just above two ghost shells) with all ranks on the test GPU."""
