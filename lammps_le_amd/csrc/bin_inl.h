@@ -1,0 +1,55 @@
+// bin_inl.h — cell of a position and the wave-aggregated cell counter, shared by the reneighbor kernels and the step
+// kernel (which bins the positions it has just produced when a rebuild may follow, see k_step).
+#pragma once
+#include "device.h"
+
+namespace lmp_le {
+
+// cell of a (wrapped) position.  z cells are counted from zlo_ext (the bottom of this rank's slab + ghost shell;
+// = box.lo[2] on one rank) with a periodic wrap, so owned and ghost beads of a slab land in one local grid.
+__device__ __forceinline__ int cell_index(const double4 &r, const Box &box, int ncx, int ncy, int ncz, double cix,
+                                          double ciy, double ciz, double zlo_ext) {
+  double zrel = r.z - zlo_ext;
+  if (zrel < 0.0) zrel += box.prd[2];
+  if (zrel >= box.prd[2]) zrel -= box.prd[2];
+  int cx = (int)((r.x - box.lo[0]) * cix), cy = (int)((r.y - box.lo[1]) * ciy), cz = (int)(zrel * ciz);
+  cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
+  return (cz * ncy + cy) * ncx + cx;
+}
+
+// Domain::pbc for one coordinate triple (src/domain.cpp:528-645, orthogonal box): wrapped copy + image deltas
+__device__ __forceinline__ void wrap_into_box(double4 &r, const Box &box, int &dix, int &diy, int &diz) {
+  double *c = &r.x;
+  int di[3] = {0, 0, 0};
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    double x = c[d];
+    if (x < box.lo[d]) { x += box.prd[d]; di[d]--; }
+    if (x >= box.hi[d]) { x -= box.prd[d]; x = fmax(x, box.lo[d]); di[d]++; }
+    c[d] = x;
+  }
+  dix = di[0]; diy = di[1]; diz = di[2];
+}
+
+// arrival order of a bead inside its cell + the cell's count.  Beads arrive nearly cell-sorted: one returning atomic per
+// run of equal cells inside the wavefront.  Every lane of the wavefront that is still active must call this, and the
+// inactive lanes may only trail (tail of the array).
+__device__ __forceinline__ int count_into_cell(int cell, int *__restrict__ cell_count) {
+  const int lane = threadIdx.x & 63;
+  int prev = __shfl_up(cell, 1, 64);
+  bool head = (lane == 0) || (prev != cell);
+  unsigned long long heads = __ballot(head);
+  unsigned long long act = __ballot(true);
+  unsigned long long below = heads & ((2ull << lane) - 1ull);  // heads at or below my lane
+  int hl = 63 - __clzll((long long)below);                     // lane of my run's head
+  unsigned long long after = heads & ~((2ull << lane) - 1ull);
+  after &= act;
+  int endl = after ? (__ffsll((long long)after) - 1) : (64 - __clzll((long long)act));   // first lane past my run
+  // the run is [hl, endl) restricted to active lanes; runs are contiguous because inactive lanes only trail
+  int base = 0;
+  if (head) base = atomicAdd(&cell_count[cell], endl - hl);
+  base = __shfl(base, hl, 64);
+  return base + (lane - hl);
+}
+
+}  // namespace lmp_le

@@ -11,6 +11,7 @@
 //   FixLangevin::post_force_templated<0,...>      src/fix_langevin.cpp:585-778
 //   Neighbor::check_distance                      src/neighbor.cpp:1962-2014
 #include "device.h"
+#include "bin_inl.h"
 #include <hip/hip_ext.h>
 
 namespace lmp_le {
@@ -164,6 +165,11 @@ struct ForceArgs {
   int bprow;             // last row of the bond-partner table (max(bpa, 1) - 1)
   int nn_limit;          // diagnostics only (LAMMPS_LE_NN_LIMIT): cap on neighbors visited per bead
   int diag;              // diagnostics only (LAMMPS_LE_DIAG_STEP): extra launch with parts off, see launch_step
+  // a launch that tests the skin/2 displacement (a rebuild may follow) also bins the new positions: cell, arrival order
+  // inside the cell and the cell counts, i.e. everything k_wrap_bin would produce except Domain::pbc itself (k_permute)
+  int bin, ncx, ncy, ncz;
+  double cix, ciy, ciz, zlo_ext;
+  int *cell_of, *cell_count, *cell_rank;
   // decomposed runs: border beads also write their new position into the halo send buffer (no pack launch per step)
   const int *sendslot;
   double4 *sendbuf;
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
 // every fourth list entry and every fourth bond slot, the partial forces meet in a two-step butterfly and lane 0
 // integrates: the chain shrinks to one or two stages.
 template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD>
-__global__ __launch_bounds__(BLOCK, (AHEAD ? 4 : STEP_WAVES_PER_SIMD)) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
+__global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
                                                 const int *__restrict__ tag, const int *__restrict__ crank,
                                                 const uint32_t *__restrict__ draws, double *__restrict__ vx,
                                                 double *__restrict__ vy, double *__restrict__ vz,
@@ -519,6 +525,17 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 4 : STEP_WAVES_PER_SIMD)) void k_st
       const double4 h = AHEAD ? hold : xhold[p];
       double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
       if (dx * dx + dy * dy + dz * dz > triggersq && !(DIAG && A.diag)) flags[FLAG_MOVED] = 1;
+      if (LPB == 1 && !DIAG && A.bin) {     // (wave-uniform; the lanes still here are a leading run of the wavefront)
+        double4 w = ri;
+        int cell = 0;
+        if (isfinite(w.x) && isfinite(w.y) && isfinite(w.z)) {
+          int dix, diy, diz;
+          wrap_into_box(w, box, dix, diy, diz);
+          cell = cell_index(w, box, A.ncx, A.ncy, A.ncz, A.cix, A.ciy, A.ciz, A.zlo_ext);
+        } else flags[FLAG_ERROR] = ERR_NONFINITE;
+        A.cell_of[p] = cell;
+        A.cell_rank[p] = count_into_cell(cell, A.cell_count);
+      }
     }
   } else {
     fx[p] = f0; fy[p] = f1; fz[p] = f2;
@@ -530,6 +547,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 4 : STEP_WAVES_PER_SIMD)) void k_st
 // ------------------------------------------------------------------------------------------
 void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
+  d.bins_ready = false;     // the positions move: bins a step kernel may have left behind are stale
   hipLaunchKernelGGL(k_initial_integrate, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2],
                      d.f[0], d.f[1], d.f[2], d.xhold, tt, dtv, triggersq, check ? 1 : 0, d.flags);
 }
@@ -567,6 +585,9 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.bprow = std::max(d.bpa, 1) - 1;
   A.diag = 0;
   A.sendslot = nullptr; A.sendbuf = nullptr; A.nsend0 = 0;
+  A.bin = 0; A.ncx = d.ncell[0]; A.ncy = d.ncell[1]; A.ncz = d.ncell[2];
+  A.cix = d.cellinv[0]; A.ciy = d.cellinv[1]; A.ciz = d.cellinv[2]; A.zlo_ext = d.zlo_ext;
+  A.cell_of = d.cell_of; A.cell_count = d.cell_count; A.cell_rank = d.tag_tmp;
   return A;
 }
 void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool eflag, bool has_pair) {
@@ -597,6 +618,14 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   // diagnostics only (LAMMPS_LE_STEP_LDS_PAD=bytes): unused dynamic LDS per workgroup, to lower the occupancy on purpose
   static const unsigned lds_pad = getenv("LAMMPS_LE_STEP_LDS_PAD") ? (unsigned)atoi(getenv("LAMMPS_LE_STEP_LDS_PAD")) : 0u;
   if (lpb4) { A.nblocks = (d.n + BLOCK / 4 - 1) / (BLOCK / 4); A.maxrow = (d.maxneigh - 4) / 4; }
+  // positions binned by this launch: single GPU, whole-step launch, one lane per bead, and a displacement test in it
+  static const bool no_fused_bin = getenv("LAMMPS_LE_NO_FUSED_BIN") != nullptr;
+  const bool bin = check && next && !d.dd && which < 0 && !lpb4 && !no_fused_bin && d.cell_count && d.ncells > 0;
+  if (bin) {
+    HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(d.ncells + 1) * sizeof(int), d.stream));
+    A.bin = 1;
+  }
+  d.bins_ready = bin;
   int grid = xcd_grid(A.nblocks);
   // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
   // the same clock rocprofv3 --kernel-trace reports
@@ -612,7 +641,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   static const int diag_step = getenv("LAMMPS_LE_DIAG_STEP") ? atoi(getenv("LAMMPS_LE_DIAG_STEP")) : 0;
   if (diag_step && key == 15 && which < 0 && !lpb4) {
     ForceArgs R = A;
-    A.diag = diag_step | 64;
+    A.diag = diag_step | 64; A.bin = 0;
     hipEvent_t e0 = ev_start, e1 = ev_stop;
     ev_start = ev_stop = nullptr;
     STPL(true, true, true, true, 1, true, false);

@@ -14,23 +14,12 @@
 // column-major (neigh[k][p]) so that lane p's k-th neighbor load is coalesced and no force atomics
 // are needed.
 #include "device.h"
+#include "bin_inl.h"
 
 namespace lmp_le {
 
 constexpr int BLOCK = 256;
 constexpr int SCAN_BLOCK = 1024;
-
-// cell of a (wrapped) position.  z cells are counted from zlo_ext (the bottom of this rank's slab + ghost shell;
-// = box.lo[2] on one rank) with a periodic wrap, so owned and ghost beads of a slab land in one local grid.
-__device__ __forceinline__ int cell_index(const double4 &r, const Box &box, int ncx, int ncy, int ncz, double cix,
-                                          double ciy, double ciz, double zlo_ext) {
-  double zrel = r.z - zlo_ext;
-  if (zrel < 0.0) zrel += box.prd[2];
-  if (zrel >= box.prd[2]) zrel -= box.prd[2];
-  int cx = (int)((r.x - box.lo[0]) * cix), cy = (int)((r.y - box.lo[1]) * ciy), cz = (int)(zrel * ciz);
-  cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
-  return (cz * ncy + cy) * ncx + cx;
-}
 
 __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__ pos, int *__restrict__ img, int npad,
                                                     Box box, int ncx, int ncy, int ncz, double cix, double ciy,
@@ -47,38 +36,18 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
     rank[p] = atomicAdd(&cell_count[0], 1);
     return;
   }
-  double *c = &r.x;
-#pragma unroll
-  for (int d = 0; d < 3; d++) {
-    double x = c[d];
-    int im = img[d * npad + p];
-    if (x < box.lo[d]) { x += box.prd[d]; im--; }
-    if (x >= box.hi[d]) { x -= box.prd[d]; x = fmax(x, box.lo[d]); im++; }
-    c[d] = x;
-    img[d * npad + p] = im;
-  }
+  int dix, diy, diz;
+  wrap_into_box(r, box, dix, diy, diz);
+  if (dix) img[p] += dix;
+  if (diy) img[npad + p] += diy;
+  if (diz) img[2 * npad + p] += diz;
   pos[p] = r;
   int cell = cell_index(r, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
   // decomposed runs: a bead that has just migrated to another slab is binned into a sentinel cell behind all real
   // cells, so the sort that follows also compacts the array (no separate keep/scan/scatter pass)
   if (gone && gone[p]) cell = sentinel;
   cell_of[p] = cell;
-  // beads arrive nearly cell-sorted: one returning atomic per run of equal cells inside the wavefront
-  const int lane = threadIdx.x & 63;
-  int prev = __shfl_up(cell, 1, 64);
-  bool head = (lane == 0) || (prev != cell);
-  unsigned long long heads = __ballot(head);                  // all lanes of the wave are active here? no: tail
-  unsigned long long act = __ballot(true);
-  unsigned long long below = heads & ((2ull << lane) - 1ull);  // heads at or below my lane
-  int hl = 63 - __clzll((long long)below);                     // lane of my run's head
-  unsigned long long after = heads & ~((2ull << lane) - 1ull) ;
-  after &= act;
-  int endl = after ? (__ffsll((long long)after) - 1) : (64 - __clzll((long long)act));   // first lane past my run
-  // the run is [hl, endl) restricted to active lanes; runs are contiguous because inactive lanes only trail
-  int base = 0;
-  if (head) base = atomicAdd(&cell_count[cell], endl - hl);
-  base = __shfl(base, hl, 64);
-  rank[p] = base + (lane - hl);   // arrival order inside the cell; k_sort_cells makes it canonical
+  rank[p] = count_into_cell(cell, cell_count);   // arrival order inside the cell; k_sort_cells makes it canonical
 }
 
 // ---- exclusive scan of cell_count[0..m) into cell_start[0..m], three small kernels ----
@@ -156,17 +125,19 @@ __global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *_
                                                    double *__restrict__ vzn, const int *__restrict__ tag,
                                                    int *__restrict__ tagn, const int *__restrict__ img,
                                                    int *__restrict__ imgn, int *__restrict__ map,
-                                                   float4 *__restrict__ posf) {
+                                                   float4 *__restrict__ posf, int wrap, Box box) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= n) return;
   int p = perm[s];
   double4 r = pos[p];
+  int dix = 0, diy = 0, diz = 0;
+  if (wrap) wrap_into_box(r, box, dix, diy, diz);   // the step kernel binned these positions: Domain::pbc is applied here
   pos_new[s] = r;
   xhold[s] = r;
   vxn[s] = vx[p]; vyn[s] = vy[p]; vzn[s] = vz[p];
   int t = tag[p];
   tagn[s] = t;
-  imgn[s] = img[p]; imgn[npad + s] = img[npad + p]; imgn[2 * npad + s] = img[2 * npad + p];
+  imgn[s] = img[p] + dix; imgn[npad + s] = img[npad + p] + diy; imgn[2 * npad + s] = img[2 * npad + p] + diz;
   map[t] = s;
   posf[s] = make_float4((float)r.x, (float)r.y, (float)r.z, 0.f);
 }
@@ -485,10 +456,16 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
   int nb = std::max(1, (m_in + BLOCK - 1) / BLOCK);
   const int nc = d.ncells + (gone ? 1 : 0);     // + sentinel cell
   hipStream_t st = d.stream;
-  HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(nc + 1) * sizeof(int), st));
-  hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, m_in, d.pos, d.img, d.npad, d.box, d.ncell[0],
-                     d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of,
-                     d.cell_count, d.tag_tmp, d.flags, gone, d.ncells);
+  // the step kernel that produced these positions may already have binned them (cell_of, arrival ranks, counts): then
+  // only Domain::pbc is left, and k_permute applies it while it moves the beads
+  const bool prebinned = d.bins_ready && !gone && !d.dd && m_in == d.n;
+  d.bins_ready = false;
+  if (!prebinned) {
+    HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(nc + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, m_in, d.pos, d.img, d.npad, d.box, d.ncell[0],
+                       d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of,
+                       d.cell_count, d.tag_tmp, d.flags, gone, d.ncells);
+  }
   int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_count, d.cell_start, d.scan_tmp);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sb, d.scan_tmp);
@@ -499,7 +476,8 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
   const int n = n_out;
   nb = std::max(1, (n + BLOCK - 1) / BLOCK);
   hipLaunchKernelGGL(k_permute, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.perm, d.pos, d.pos_tmp, d.xhold, d.v[0],
-                     d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map, d.posf);
+                     d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map, d.posf,
+                     prebinned ? 1 : 0, d.box);
   std::swap(d.pos, d.pos_tmp);
   for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
   std::swap(d.tag, d.tag_tmp);
