@@ -50,7 +50,7 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
   rank[p] = count_into_cell(cell, cell_count);   // arrival order inside the cell; k_sort_cells makes it canonical
 }
 
-// ---- exclusive scan of cell_count[0..m) into cell_start[0..m], three small kernels ----
+// ---- exclusive scan of cell_count[0..m) into cell_start[0..m], two small kernels ----
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(int m, const int *__restrict__ in, int *__restrict__ out,
                                                            int *__restrict__ blocksum) {
   __shared__ int s[SCAN_BLOCK];
@@ -67,34 +67,22 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(int m, const int *__r
   if (i < m) out[i] = s[threadIdx.x] - v;   // exclusive
   if (threadIdx.x == SCAN_BLOCK - 1) blocksum[blockIdx.x] = s[threadIdx.x];
 }
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(int nb, int *__restrict__ blocksum) {
-  // single block: exclusive scan of up to many block sums, SCAN_BLOCK at a time with a running carry
-  __shared__ int s[SCAN_BLOCK];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nb; base += SCAN_BLOCK) {
-    int i = base + threadIdx.x;
-    int v = (i < nb) ? blocksum[i] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-      int t = (threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    int c = carry;
-    if (i < nb) blocksum[i] = c + s[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == SCAN_BLOCK - 1) carry = c + s[threadIdx.x];
-    __syncthreads();
-  }
-}
+// second and last pass: every block sums the block totals in front of it itself (a few hundred L2-resident words; the
+// separate single-block scan of the totals cost a launch) and adds the offset to its slice
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int m, int *__restrict__ out, const int *__restrict__ blocksum,
                                                          int total_slot_n) {
+  __shared__ int s[SCAN_BLOCK];
+  int part = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_BLOCK) part += blocksum[b];
+  s[threadIdx.x] = part;
+  __syncthreads();
+  for (int off = SCAN_BLOCK / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+    __syncthreads();
+  }
+  const int offset = s[0];
   int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  if (i < m) out[i] += blocksum[blockIdx.x];
+  if (i < m) out[i] += offset;
   if (i == 0) out[m] = total_slot_n;
 }
 
@@ -141,29 +129,36 @@ __global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *_
   map[t] = s;
   posf[s] = make_float4((float)r.x, (float)r.y, (float)r.z, 0.f);
 }
-__global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, int bpa, const int *__restrict__ tag,
-                                                      const int *__restrict__ map, const int *__restrict__ num_bond,
-                                                      const int *__restrict__ bond_type,
-                                                      const int *__restrict__ bond_atom, int maxtag,
-                                                      int *__restrict__ bpart, int *__restrict__ flags,
-                                                      unsigned char *__restrict__ phase) {
-  int s = blockIdx.x * BLOCK + threadIdx.x;
-  if (s >= n) return;
-  int t = tag[s];
-  int nb = num_bond[t];
+// bond-partner table of bead s: physical index + type of every stored bond (the step kernel's `bpart` rows)
+struct BondTabArgs {
+  int bpa, maxtag;
+  const int *num_bond, *bond_type, *bond_atom;
+  int *bpart;              // nullptr = nothing to do
+  unsigned char *phase;
+};
+__device__ __forceinline__ void bond_table_row(int s, int n, int npad, int t, const int *__restrict__ map,
+                                               const BondTabArgs &B, int *__restrict__ flags) {
+  int nb = B.num_bond[t];
   bool ghost = false;
-  for (int m = 0; m < bpa; m++) {
+  for (int m = 0; m < B.bpa; m++) {
     int e = -1;
     if (m < nb) {
-      int bt = bond_type[(size_t)t * bpa + m];
-      int u = bond_atom[(size_t)t * bpa + m];
-      int q = (u >= 1 && u <= maxtag) ? map[u] : -1;
+      int bt = B.bond_type[(size_t)t * B.bpa + m];
+      int u = B.bond_atom[(size_t)t * B.bpa + m];
+      int q = (u >= 1 && u <= B.maxtag) ? map[u] : -1;
       if (q < 0) flags[FLAG_ERROR] = ERR_BOND_MISSING;
       else if (bt > 0) { e = (bt << BOND_TYPE_SHIFT) | q; ghost = ghost || q >= n; }
     }
-    bpart[(size_t)m * npad + s] = e;
+    B.bpart[(size_t)m * npad + s] = e;
   }
-  if (phase && ghost) phase[s] = 1;     // reads a ghost position: phase 1 of a decomposed step
+  if (B.phase && ghost) B.phase[s] = 1;     // reads a ghost position: phase 1 of a decomposed step
+}
+__global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, const int *__restrict__ tag,
+                                                      const int *__restrict__ map, BondTabArgs B,
+                                                      int *__restrict__ flags) {
+  int s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= n) return;
+  bond_table_row(s, n, npad, tag[s], map, B, flags);
 }
 
 // full neighbor list of atom s.  The 27-cell sweep is done as 9 (dy,dz) row segments: the three x-cells of a
@@ -468,7 +463,6 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
   }
   int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_count, d.cell_start, d.scan_tmp);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, sb, d.scan_tmp);
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_start, d.scan_tmp, m_in);
   hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, m_in, d.cell_of, d.cell_start, d.tag_tmp, d.perm);
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
@@ -489,8 +483,10 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
   if (nb == 0) nb = 1;
   hipStream_t st = d.stream;
-  hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.bpa, d.tag, d.map, d.num_bond,
-                     d.bond_type, d.bond_atom, d.maxtag, d.bpart, d.flags, d.dd ? d.phase : nullptr);
+  BondTabArgs BT{d.bpa, d.maxtag, d.num_bond, d.bond_type, d.bond_atom, d.bpart, d.dd ? d.phase : nullptr};
+  // (a launch of its own: folded into the prologue of the list build it made that kernel 48 us slower to save 16, and
+  // even the unused extra kernel argument cost the build 32 us)
+  hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.tag, d.map, BT, d.flags);
   if (has_pair) {
     auto sflag = [](double w) { return w == 0.0 ? 0 : (w == 1.0 ? 1 : 2); };
     int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
