@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void k_rng_calls(long long total, unsigned long
   if (lane < 33) {   // draws 0..32 with the plain recurrence (the 64-wide form needs y_{i-130}, i >= 33)
     uint32_t y = (ring[lane] - ring[lane + 64]) & M24;
     ring[lane + 97] = y;
-    if (lane < total) out[lane] = (y - c_of_dev(raw0 + lane)) & M24;
+    if (lane < total) __builtin_nontemporal_store((uint32_t)((y - c_of_dev(raw0 + lane)) & M24), &out[lane]);
   }
   __syncthreads();
   long long G = total + 96;   // 96 values past the end feed the jump below
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_rng_calls(long long total, unsigned long
     int r = (int)(i & 255);
     uint32_t y = (ring[r] - ring[(r - 33) & 255] + ring[(r + 31) & 255]) & M24;   // y_{i-97} - y_{i-130} + y_{i-66}
     ring[(r + 97) & 255] = y;
-    if (i < total) out[i] = (y - (uint32_t)c) & M24;
+    if (i < total) __builtin_nontemporal_store((uint32_t)((y - (uint32_t)c) & M24), &out[i]);   // 6 GB per batch, read once 1..512 steps later: keep it out of the caches the step kernel lives in
     c -= STEP64;
     if (c < 0) c += CM;
     __syncthreads();
