@@ -241,7 +241,8 @@ class Engine {
   // ---- topology on the host (read_data path) ----
   void read_data(const std::string &path);
   void write_data(const std::string &path);
-  void velocity(std::vector<std::string> &arg);   // velocity all create|set|scale|zero (src/velocity.cpp)
+  void velocity(std::vector<std::string> &arg);
+  void set_command(std::vector<std::string> &arg);   // set atom|type|mol|group ... (src/set.cpp)   // velocity all create|set|scale|zero (src/velocity.cpp)
   // ---- dumps (src/dump_custom.cpp, dump_atom.cpp, dump_local.cpp; compute_property_local.cpp) ----
   struct Dump {
     std::string id, style, path, label = "ENTRIES";

@@ -542,6 +542,8 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
     write_data(arg[0]);
   } else if (cmd == "velocity") {
     velocity(arg);
+  } else if (cmd == "set") {
+    set_command(arg);
   } else if (cmd == "write_restart") {
     need(1);
     write_restart(arg[0]);
@@ -1166,6 +1168,103 @@ void Engine::velocity(std::vector<std::string> &arg) {
   }
   host_current = true;
   dev_current = false;   // the next run uploads the new velocities
+}
+
+// ---------------------------------------------------------------------------------------------
+// set style ID keyword values ...   (src/set.cpp:60-620 command, :626-700 selection, :706-1000 set, :1013-1041 setrandom)
+// styles atom | type | mol (ranges N, N*M, *M, N*, *) and group all; keywords type, type/fraction, mol, x y z, vx vy vz,
+// image.  Host-side like the reference; used for marking barrier (CTCF) beads and the like.
+// ---------------------------------------------------------------------------------------------
+void Engine::set_command(std::vector<std::string> &arg) {
+  if (!box_exist) throw LammpsError("Set command before simulation box is defined");
+  if (natoms == 0) throw LammpsError("Set command with no atoms existing");
+  if (arg.size() < 3) throw LammpsError("Illegal set command");
+  download();
+  const std::string &style = arg[0], &id = arg[1];
+  std::vector<char> select(natoms, 0);
+  auto range = [&](long nmax, long &lo, long &hi) {
+    size_t star = id.find('*');
+    auto num = [&](const std::string &t) { char *end; long v = strtol(t.c_str(), &end, 10); if (end == t.c_str() || *end) throw LammpsError("Invalid range string: " + id); return v; };
+    if (star == std::string::npos) lo = hi = num(id);
+    else { lo = (star == 0) ? 1 : num(id.substr(0, star)); hi = (star + 1 == id.size()) ? nmax : num(id.substr(star + 1)); }
+    if (lo < 1 || hi > nmax || lo > hi) throw LammpsError("Invalid range string: " + id);
+  };
+  long lo, hi;
+  if (style == "atom") { range(2147483647L, lo, hi); for (int i = 0; i < natoms; i++) select[i] = (i + 1 >= lo && i + 1 <= hi); }
+  else if (style == "type") { range(ntypes, lo, hi); for (int i = 0; i < natoms; i++) select[i] = (type[i] >= lo && type[i] <= hi); }
+  else if (style == "mol") {
+    if (molecule.empty()) throw LammpsError("Cannot use set mol with no molecule IDs defined");
+    range(2147483647L, lo, hi);
+    for (int i = 0; i < natoms; i++) select[i] = (molecule[i] >= lo && molecule[i] <= hi);
+  } else if (style == "group") {
+    if (id != "all") throw LammpsError("MI355X engine: only group all is supported");
+    std::fill(select.begin(), select.end(), 1);
+  } else if (style == "region") throw LammpsError("MI355X engine: set region is not supported");
+  else throw LammpsError("Illegal set command");
+  auto need = [&](size_t k, size_t n) { if (k + n > arg.size()) throw LammpsError("Illegal set command"); };
+  auto fnum = [&](const std::string &t) {
+    if (t.rfind("v_", 0) == 0) return variable_value(t.substr(2));
+    char *end; double v = strtod(t.c_str(), &end);
+    if (end == t.c_str() || *end) throw LammpsError("Expected floating point parameter instead of '" + t + "' in input script or data file");
+    return v;
+  };
+  long count = 0;
+  size_t k = 2;
+  while (k < arg.size()) {
+    const std::string &kw = arg[k];
+    count = 0;
+    if (kw == "type") {
+      need(k, 2);
+      int t = (int)fnum(arg[k + 1]);
+      if (t <= 0 || t > ntypes) throw LammpsError("Invalid value in set command");
+      for (int i = 0; i < natoms; i++) if (select[i]) { type[i] = t; count++; }
+      k += 2;
+    } else if (kw == "type/fraction") {
+      need(k, 4);
+      int t = (int)fnum(arg[k + 1]);
+      double fraction = fnum(arg[k + 2]);
+      int seed = (int)fnum(arg[k + 3]);
+      if (t <= 0 || t > ntypes) throw LammpsError("Invalid value in set command");
+      if (fraction < 0.0 || fraction > 1.0) throw LammpsError("Invalid value in set command");
+      if (seed <= 0) throw LammpsError("Invalid random number seed in set command");
+      RanPark rp(1);
+      for (int i = 0; i < natoms; i++)
+        if (select[i]) {
+          rp.reset(seed, &x[3 * (size_t)i]);                      // src/set.cpp:1034-1040: generator re-seeded from the coordinates
+          if (rp.uniform() > fraction) continue;
+          type[i] = t; count++;
+        }
+      k += 4;
+    } else if (kw == "mol") {
+      need(k, 2);
+      if (molecule.empty()) throw LammpsError("Cannot set this attribute for this atom style");
+      int m = (int)fnum(arg[k + 1]);
+      if (m < 0) throw LammpsError("Invalid value in set command");
+      for (int i = 0; i < natoms; i++) if (select[i]) { molecule[i] = m; count++; }
+      k += 2;
+    } else if (kw == "x" || kw == "y" || kw == "z" || kw == "vx" || kw == "vy" || kw == "vz") {
+      need(k, 2);
+      double val = fnum(arg[k + 1]);
+      const bool vel = kw[0] == 'v';
+      const int d = kw.back() - 'x';
+      for (int i = 0; i < natoms; i++) if (select[i]) { (vel ? v : x)[3 * (size_t)i + d] = val; count++; }
+      k += 2;
+    } else if (kw == "image") {
+      need(k, 4);
+      for (int d = 0; d < 3; d++) {
+        if (arg[k + 1 + d] == "NULL") continue;
+        int val = (int)fnum(arg[k + 1 + d]);
+        for (int i = 0; i < natoms; i++) if (select[i]) image[3 * (size_t)i + d] = val;
+      }
+      for (int i = 0; i < natoms; i++) if (select[i]) count++;
+      k += 4;
+    } else throw LammpsError("MI355X engine: set keyword " + kw + " is not supported");
+    char buf[96];
+    snprintf(buf, sizeof buf, "Setting atom values ...\n  %ld settings made for %s\n", count, kw.c_str());
+    say(buf);
+  }
+  host_current = true;
+  dev_current = false;
 }
 
 // write_data (src/write_data.cpp): header, Masses, Atoms (with image flags), Velocities, Bonds (each once)

@@ -301,3 +301,48 @@ def test_script_control_flow_errors(tmp_path):
     lmp.command("variable b equal v_a>=24&&!(v_a>24)")
     lmp.command('if "${b}" then "variable ok string yes"')
     lmp.command("print ${ok}")
+
+
+def test_set_command(tmp_path):
+    """`set atom|type|mol|group ... type | type/fraction | mol | x.. | vx.. | image` (src/set.cpp); the fraction variant
+    re-seeds RanPark from each bead's coordinates, checked against the numpy restatement."""
+    import sys
+    from lammps_le_amd import LammpsError
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from velocity_oracle import RanPark
+    n = 400
+    lmp, s = _open(tmp_path, n)
+    lmp.command("set atom 100*120 type 1")
+    with pytest.raises(LammpsError, match="Invalid value in set command"):
+        lmp.command("set atom 5 type 9")
+    # the chain script defines one type: re-open with three
+    from lammps_le_amd import lammps
+    sys3 = lattice_chain(n, types=np.ones(n, dtype=np.int32))
+    sys3["ntypes"], sys3["mass"] = 3, [1.0, 1.0, 1.0]
+    path = os.path.join(str(tmp_path), "data3.chain")
+    write_data(path, sys3)
+    lmp = lammps(cmdargs=["-screen", "none"])
+    for ln in CHAIN_SCRIPT.split("\n"):
+        lmp.command(ln.replace("data.chain", path))
+    lmp.command("set atom 100*120 type 2")
+    lmp.command("set atom 7 type 3 vx 0.5 image 1 NULL -2")
+    t = lmp.gather("type")
+    assert (t[99:120] == 2).all() and t[6] == 3 and (np.delete(t, list(range(99, 120)) + [6]) == 1).all()
+    assert lmp.gather("v").reshape(n, 3)[6, 0] == 0.5 and list(lmp.gather("image").reshape(n, 3)[6]) == [1, 0, -2]
+    lmp.command("set type 2 type/fraction 3 0.4 12345")
+    t2 = lmp.gather("type")
+    x = lmp.gather("x").reshape(n, 3)
+    rp = RanPark(1)
+    expect = t.copy()
+    for i in range(n):
+        if t[i] == 2:
+            rp.reset(12345, x[i])
+            if rp.uniform() <= 0.4:
+                expect[i] = 3
+    assert (t2 == expect).all() and 0 < (t2[99:120] == 3).sum() < 21
+    lmp.command("set group all mol 5")
+    lmp.command("variable sh equal 0.25")
+    lmp.command("set mol 5 vz v_sh")
+    assert (lmp.gather("v").reshape(n, 3)[:, 2] == 0.25).all()
+    with pytest.raises(LammpsError, match="set keyword charge is not supported"):
+        lmp.command("set atom 1 charge 1.0")
