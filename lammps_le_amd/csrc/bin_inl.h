@@ -32,24 +32,26 @@ __device__ __forceinline__ void wrap_into_box(double4 &r, const Box &box, int &d
 }
 
 // arrival order of a bead inside its cell + the cell's count.  Beads arrive nearly cell-sorted: one returning atomic per
-// run of equal cells inside the wavefront.  Every lane of the wavefront that is still active must call this, and the
-// inactive lanes may only trail (tail of the array).
+// run of equal cells inside the wavefront.  The lanes that call this are every STRIDE-th lane of the wavefront, from lane 0
+// up to wherever the array ends (STRIDE = lanes per bead of the calling kernel); all of them must call it.
+template <int STRIDE = 1>
 __device__ __forceinline__ int count_into_cell(int cell, int *__restrict__ cell_count) {
   const int lane = threadIdx.x & 63;
-  int prev = __shfl_up(cell, 1, 64);
-  bool head = (lane == 0) || (prev != cell);
-  unsigned long long heads = __ballot(head);
+  int prev = __shfl_up(cell, STRIDE, 64);                      // the previous calling lane's cell
+  bool head = (lane < STRIDE) || (prev != cell);
+  unsigned long long heads = __ballot(head);                   // (only calling lanes vote)
   unsigned long long act = __ballot(true);
-  unsigned long long below = heads & ((2ull << lane) - 1ull);  // heads at or below my lane
+  const unsigned long long upto = (2ull << lane) - 1ull;       // lanes 0..lane
+  unsigned long long below = heads & upto;                     // heads at or below my lane
   int hl = 63 - __clzll((long long)below);                     // lane of my run's head
-  unsigned long long after = heads & ~((2ull << lane) - 1ull);
-  after &= act;
-  int endl = after ? (__ffsll((long long)after) - 1) : (64 - __clzll((long long)act));   // first lane past my run
-  // the run is [hl, endl) restricted to active lanes; runs are contiguous because inactive lanes only trail
+  unsigned long long after = heads & ~upto;
+  int endl = after ? (__ffsll((long long)after) - 1) : 64;     // first head past my run
+  const unsigned long long from_head = ~((1ull << hl) - 1ull);
+  const unsigned long long run = act & from_head & (endl >= 64 ? ~0ull : ((1ull << endl) - 1ull));
   int base = 0;
-  if (head) base = atomicAdd(&cell_count[cell], endl - hl);
+  if (head) base = atomicAdd(&cell_count[cell], __popcll(run));
   base = __shfl(base, hl, 64);
-  return base + (lane - hl);
+  return base + __popcll(run & ((1ull << lane) - 1ull));       // calling lanes of my run in front of me
 }
 
 }  // namespace lmp_le

@@ -149,6 +149,7 @@ void Engine::upload() {
                         "not supported by the MI355X engine (minimum-image cell lists)");
   }
   DeviceState &d = *dev;
+  d.bins_ready = false;      // the device arrays are about to be replaced (tag order): bins of the old arrays are void
   bool realloc = (d.ntotal != natoms || d.bpa != bpa || d.maxspecial != maxspecial || d.ntypes != ntypes || !d.pos);
   double cellcut = cutneighmax > 0.0 ? cutneighmax : std::max({box.prd[0], box.prd[1], box.prd[2]}) / 3.0;
   if (world > 1) {

@@ -525,7 +525,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
       const double4 h = AHEAD ? hold : xhold[p];
       double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
       if (dx * dx + dy * dy + dz * dz > triggersq && !(DIAG && A.diag)) flags[FLAG_MOVED] = 1;
-      if (LPB == 1 && !DIAG && A.bin) {     // (wave-uniform; the lanes still here are a leading run of the wavefront)
+      if (!DIAG && A.bin) {     // (wave-uniform; the lanes still here: every LPB-th one up to the end of the array)
         double4 w = ri;
         int cell = 0;
         if (isfinite(w.x) && isfinite(w.y) && isfinite(w.z)) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
           cell = cell_index(w, box, A.ncx, A.ncy, A.ncz, A.cix, A.ciy, A.ciz, A.zlo_ext);
         } else flags[FLAG_ERROR] = ERR_NONFINITE;
         A.cell_of[p] = cell;
-        A.cell_rank[p] = count_into_cell(cell, A.cell_count);
+        A.cell_rank[p] = count_into_cell<LPB>(cell, A.cell_count);
       }
     }
   } else {
@@ -618,7 +618,8 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   // diagnostics only (LAMMPS_LE_STEP_LDS_PAD=bytes): unused dynamic LDS per workgroup, to lower the occupancy on purpose
   static const unsigned lds_pad = getenv("LAMMPS_LE_STEP_LDS_PAD") ? (unsigned)atoi(getenv("LAMMPS_LE_STEP_LDS_PAD")) : 0u;
   if (lpb4) { A.nblocks = (d.n + BLOCK / 4 - 1) / (BLOCK / 4); A.maxrow = (d.maxneigh - 4) / 4; }
-  // positions binned by this launch: single GPU, whole-step launch, one lane per bead, and a displacement test in it
+  // positions binned by this launch: single GPU, whole-step launch with a displacement test in it, one lane per bead (with
+  // four lanes per bead - small systems - it was measured slower than the separate k_wrap_bin: 62.2k vs 64.5k steps/s at 32k)
   static const bool no_fused_bin = getenv("LAMMPS_LE_NO_FUSED_BIN") != nullptr;
   const bool bin = check && next && !d.dd && which < 0 && !lpb4 && !no_fused_bin && d.cell_count && d.ncells > 0;
   if (bin) {

@@ -77,11 +77,12 @@ def test_langevin_stream_parity(tmp_path):
     assert p.stat("neigh_builds") == o.neigh_builds()
 
 
-def test_velocity_create_between_runs(tmp_path):
+@pytest.mark.parametrize("n", [3000, 70000])
+def test_velocity_create_between_runs(tmp_path, n):
     """`velocity all create` before the first run and again between two runs (the second call has to fetch the
     newest state from the device, replace v and upload it again); oracle driven from the same script."""
-    s = lattice_chain(3000, seed=13)
-    s["v"] = np.zeros_like(s["v"])
+    s = lattice_chain(n, seed=13)       # (70000: the one-lane-per-bead shape of the step kernel; the second `velocity`
+    s["v"] = np.zeros_like(s["v"])      #  replaces the device arrays while bins of the old ones are still around)
     script = CHAIN_SCRIPT + ("velocity all create 1.0 4928459 dist gaussian\nfix 1 all nve\nthermo 20\nrun 40\n"
                              "velocity all create 0.6 8723 loop local\nrun 30\n")
     o = run_oracle(script, s)
