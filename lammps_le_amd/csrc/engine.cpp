@@ -380,7 +380,9 @@ static void check_device_error(Engine *e, DeviceState &d) {
 void Engine::reneighbor(bool defer_check) {
   DeviceState &d = *dev;
   double t0 = wall();
-  static const long test_overflow_at = getenv("LAMMPS_LE_TEST_OVERFLOW_AT") ? atol(getenv("LAMMPS_LE_TEST_OVERFLOW_AT")) : -1;
+  // (read at every rebuild, not cached: the test that sets it shares its process with tests that must not see it)
+  const char *ovf = getenv("LAMMPS_LE_TEST_OVERFLOW_AT");
+  const long test_overflow_at = ovf ? atol(ovf) : -1;
   if (test_overflow_at >= 0 && neigh_builds == test_overflow_at) dev_alloc_neigh(d, 4);   // test hook: force an overflow
   // FLAG_MOVED / NEIGH_OVERFLOW / MAXNEIGH are zero here: they are reset by the publish kernel that reports them
   if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);

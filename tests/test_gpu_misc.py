@@ -256,12 +256,14 @@ def test_periodic_restart_files(tmp_path):
     w.command("restart 0")
 
 
-def test_neighbor_table_overflow_is_recovered(tmp_path, monkeypatch):
+@pytest.mark.parametrize("n", [4000, 70000])
+def test_neighbor_table_overflow_is_recovered(tmp_path, monkeypatch, n):
     """A list that does not fit the ELL table: at setup the build is repeated at once; inside the loop the step kernel
     has already been enqueued behind the build (deferred check) - it must leave the state untouched, and the host must
-    grow the table, rebuild and launch the step again.  Test hook: the table is shrunk to 4 entries before build 0."""
+    grow the table, rebuild and launch the step again.  Test hook: the table is shrunk to 4 entries before build 0.
+    70000 beads: the step kernel shape that also bins the new positions (the relaunch has to bin them again)."""
     monkeypatch.setenv("LAMMPS_LE_TEST_OVERFLOW_AT", "0")
-    s = lattice_chain(4000, seed=11, jitter=0.08)
+    s = lattice_chain(n, seed=11, jitter=0.08)
     script = CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nrun 40\n"
     o = run_oracle(script, s)
     p = run_product(script, s, tmp_path)
