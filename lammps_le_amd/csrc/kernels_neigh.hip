@@ -282,8 +282,9 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   for (int k = 0; k < SPMAX; k++) { spi[k] = -1; spc[k] = 0; }
   if (!NOSPECIAL && active && !(diag & 4)) {
     int t = tag[s];
-    n1 = nspecial[3 * (size_t)t]; n2 = nspecial[3 * (size_t)t + 1];
-    int n3 = nspecial[3 * (size_t)t + 2];
+    // (tag-indexed tables, one or two lines per bead out of 100 MB, read once per rebuild: kept out of the caches)
+    n1 = __builtin_nontemporal_load(&nspecial[3 * (size_t)t]); n2 = __builtin_nontemporal_load(&nspecial[3 * (size_t)t + 1]);
+    int n3 = __builtin_nontemporal_load(&nspecial[3 * (size_t)t + 2]);
     slist = special + (size_t)t * ms;
     kmax = (sf3 != 1) ? n3 : (sf2 != 1) ? n2 : (sf1 != 1) ? n1 : 0;
     nrel = ((sf1 != 1) ? n1 : 0) + ((sf2 != 1) ? n2 - n1 : 0) + ((sf3 != 1) ? n3 - n2 : 0);
@@ -293,7 +294,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
         int which = (k < n1) ? 1 : (k < n2) ? 2 : 3;
         int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
         if (sf == 1) continue;
-        int qi = map[slist[k]], code = (sf == 0) ? -1 : which;
+        int qi = map[__builtin_nontemporal_load(&slist[k])], code = (sf == 0) ? -1 : which;
 #pragma unroll
         for (int j = 0; j < SPMAX; j++) if (j == m) { spi[j] = qi; spc[j] = code; }
         m++;

@@ -1,8 +1,22 @@
 set -e
-cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
-tail -2 gpurun_out/gpu_tests.log
-for wl in chain32k chain100k chain1m; do
-  timeout -k 10 300 python bench.py --workload $wl --steps 3000 --warmup 500 --cpu-steps 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
-done
+timeout -k 10 300 python bench.py --workload chain1m --steps 2000 --warmup 500 --cpu-steps 0 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('chain1m', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'])"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof1m -o f --output-format csv -- python3 bench.py --cpu-steps 0 > gpurun_out/prof1m.json 2> gpurun_out/prof1m.err
+python3 - <<'PY'
+import csv, numpy as np
+rows=list(csv.DictReader(open('gpurun_out/prof1m/f_kernel_trace.csv')))
+ks=sorted([(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows])
+rng=[(s,e) for s,e,n in ks if 'k_rng_calls' in n]
+def overl(s,e): return any(not (e<=a or s>=b) for a,b in rng)
+pos=-1; byp={}; bd=[]
+for s,e,n in ks:
+    if 'k_build_neigh' in n:
+        pos=0
+        if not overl(s,e): bd.append((e-s)/1e3)
+        continue
+    if 'k_step<' in n and pos>=0:
+        if not overl(s,e): byp.setdefault(pos,[]).append((e-s)/1e3)
+        pos+=1
+print('build clear mean %.1f' % np.mean(bd), ' k_step by position:', ' '.join('%d:%.1f' % (p, np.mean(byp[p])) for p in sorted(byp)[:10]))
+PY
