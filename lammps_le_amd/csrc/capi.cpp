@@ -239,7 +239,7 @@ int lammps_has_style(void *, const char *category, const char *name) {
   std::string c = category, s = name;
   if (c == "fix") return s == "nve" || s == "langevin" || s == "extrusion" || s == "ex_load" || s == "ex_unload" || s == "bond/break" || s == "bond/create";
   if (c == "pair") return s == "lj/cut" || s == "zero" || s == "none";
-  if (c == "dump") return s == "atom" || s == "custom" || s == "local";
+  if (c == "dump") return s == "atom" || s == "custom" || s == "local" || s == "dcd";
   if (c == "compute") return s == "property/local";
   if (c == "bond") return s == "fene" || s == "harmonic" || s == "hybrid" || s == "zero" || s == "none";
   if (c == "atom") return s == "bond" || s == "molecular" || s == "atomic" || s == "full" || s == "angle";

@@ -247,6 +247,8 @@ class Engine {
   struct Dump {
     std::string id, style, path, label = "ENTRIES";
     long every = 0, last = -1;
+    bool unwrap = false;           // dcd: coordinates unwrapped by the image flags (dump_modify unwrap yes)
+    int nframes = 0;               // dcd: snapshots written so far (header fields are patched after each one)
     std::vector<std::string> cols;
     FILE *fp = nullptr;
   };

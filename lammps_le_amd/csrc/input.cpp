@@ -610,6 +610,11 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
         }
         dp.cols.push_back(a);
       }
+    } else if (dp.style == "dcd") {
+      // src/dump_dcd.cpp:60-95: no extra arguments, one file for all snapshots, atoms in ID order
+      if (arg.size() != 5) throw LammpsError("Illegal dump dcd command");
+      if (dp.path.find('*') != std::string::npos || dp.path.find('%') != std::string::npos)
+        throw LammpsError("Invalid dump dcd filename");
     } else throw LammpsError("Unknown dump style " + dp.style);
     dumps.push_back(dp);
   } else if (cmd == "dump_modify") {
@@ -622,6 +627,11 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
       if (arg[k] == "every") { dp->every = atol(arg[k + 1].c_str()); if (dp->every <= 0) throw LammpsError("Illegal dump_modify command"); }
       else if (arg[k] == "sort") { if (arg[k + 1] != "id" && arg[k + 1] != "off") throw LammpsError("MI355X engine: dump_modify sort id|off only (rows are always written in ID order)"); }
       else if (arg[k] == "label") dp->label = arg[k + 1];
+      else if (arg[k] == "unwrap") {                                             // src/dump_dcd.cpp:262-272
+        if (dp->style != "dcd") throw LammpsError("Illegal dump_modify command");
+        if (arg[k + 1] == "yes") dp->unwrap = true; else if (arg[k + 1] == "no") dp->unwrap = false;
+        else throw LammpsError("Illegal dump_modify command");
+      }
       else throw LammpsError("MI355X engine: dump_modify " + arg[k] + " is not supported");
     }
   } else if (cmd == "undump") {
@@ -1328,6 +1338,42 @@ void Engine::write_dumps(long step) {
       fp = fopen(name.c_str(), "w");
     } else if (!fp) fp = dp.fp = fopen(dp.path.c_str(), "w");
     if (!fp) throw LammpsError("Cannot open dump file " + dp.path);
+    if (dp.style == "dcd") {
+      // CHARMM/NAMD DCD as DumpDCD writes it (src/dump_dcd.cpp:127-200 unit cell, :278-303 frame, :307-357 header):
+      // Fortran records (length word before and after), "CORD", float32 coordinates, one x / y / z record per snapshot
+      if (dp.fp == nullptr) fp = dp.fp = fopen(dp.path.c_str(), "wb+");
+      if (!fp) throw LammpsError("Cannot open dump file " + dp.path);
+      auto w32 = [&](uint32_t val) { fwrite(&val, 4, 1, fp); };
+      if (dp.nframes == 0) {
+        w32(84); fwrite("CORD", 4, 1, fp);
+        w32(0); w32((uint32_t)step); w32((uint32_t)dp.every); w32((uint32_t)step);
+        for (int k = 0; k < 5; k++) w32(0);
+        float fdt = (float)dt; fwrite(&fdt, 4, 1, fp);
+        w32(1);
+        for (int k = 0; k < 8; k++) w32(0);
+        w32(24); w32(84);
+        w32(164); w32(2);
+        char title[81];
+        memset(title, 0, sizeof title); strncpy(title, "Written by LAMMPS", 80); title[79] = 0; fwrite(title, 80, 1, fp);
+        memset(title, ' ', 80); memcpy(title, "REMARKS Created by the MI355X engine", 36); fwrite(title, 80, 1, fp);
+        w32(164);
+        w32(4); w32((uint32_t)natoms); w32(4);
+      }
+      double dim[6] = {box.prd[0], 0.0, box.prd[1], 0.0, 0.0, box.prd[2]};
+      w32(48); fwrite(dim, 8, 6, fp); w32(48);
+      std::vector<float> c(natoms);
+      for (int d = 0; d < 3; d++) {
+        for (int i = 0; i < natoms; i++)
+          c[i] = (float)(dp.unwrap ? x[3 * (size_t)i + d] + image[3 * (size_t)i + d] * box.prd[d] : x[3 * (size_t)i + d]);
+        w32((uint32_t)(natoms * 4)); fwrite(c.data(), 4, natoms, fp); w32((uint32_t)(natoms * 4));
+      }
+      dp.nframes++;
+      fseek(fp, 8, SEEK_SET); w32((uint32_t)dp.nframes);      // NFILE
+      fseek(fp, 20, SEEK_SET); w32((uint32_t)step);            // NSTEP
+      fseek(fp, 0, SEEK_END);
+      fflush(fp);
+      continue;
+    }
     long nrows = natoms;
     std::vector<std::array<int, 3>> bonds;     // (type, atom1, atom2) as compute property/local lists them
     if (dp.style == "local") {

@@ -190,6 +190,54 @@ def test_dump_custom_atom_and_local(tmp_path):
     assert np.abs(p.gather("x") - o.x()).max() < 1e-9 and p.bond_set() == o.bond_set()
 
 
+def test_dump_dcd(tmp_path):
+    """`dump ID all dcd N file` (+ `dump_modify unwrap yes`): CHARMM/NAMD DCD as src/dump_dcd.cpp writes it - header with
+    the snapshot count patched after every frame, unit-cell record, float32 x / y / z records in atom-ID order."""
+    import struct
+    n = 1500
+    s = lattice_chain(n, seed=9)
+    wrapped, unwrapped = str(tmp_path / "w.dcd"), str(tmp_path / "u.dcd")
+    script = CHAIN_SCRIPT + ("fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 77\n"
+                             "dump 1 all dcd 20 %s\ndump 2 all dcd 20 %s\ndump_modify 2 unwrap yes\nrun 40\n" % (wrapped, unwrapped))
+    p = run_product(script, s, tmp_path)
+    x, img = p.gather("x").reshape(n, 3), p.gather("image").reshape(n, 3)
+    prd = s["box"][:, 1] - s["box"][:, 0]
+    p.command("undump 1")
+    p.command("undump 2")
+
+    def read(path):
+        b = open(path, "rb").read()
+        assert struct.unpack("<i4s", b[:8]) == (84, b"CORD")
+        nfile, start, skip, nstep = struct.unpack("<4i", b[8:24])
+        assert struct.unpack("<f", b[44:48])[0] == np.float32(0.005) and struct.unpack("<i", b[48:52])[0] == 1
+        assert struct.unpack("<2i", b[84:92]) == (24, 84)
+        assert struct.unpack("<2i", b[92:100]) == (164, 2) and b[100:117] == b"Written by LAMMPS"
+        off = 100 + 160
+        assert struct.unpack("<4i", b[off:off + 16]) == (164, 4, n, 4)
+        off += 16
+        frames = []
+        for _ in range(nfile):
+            assert struct.unpack("<i", b[off:off + 4])[0] == 48
+            cell = struct.unpack("<6d", b[off + 4:off + 52])
+            off += 56
+            xyz = []
+            for d in range(3):
+                assert struct.unpack("<i", b[off:off + 4])[0] == 4 * n
+                xyz.append(np.frombuffer(b[off + 4:off + 4 + 4 * n], dtype="<f4"))
+                off += 8 + 4 * n
+            frames.append((cell, np.stack(xyz, axis=1)))
+        assert off == len(b)
+        return (nfile, start, skip, nstep), frames
+
+    hw, fw = read(wrapped)
+    hu, fu = read(unwrapped)
+    assert hw == (3, 0, 20, 40) and hu == (3, 0, 20, 40)
+    assert fw[0][0] == (prd[0], 0.0, prd[1], 0.0, 0.0, prd[2])
+    assert np.abs(fw[0][1] - (s["x"] % prd)).max() < 2e-5 or np.abs(fw[0][1] - s["x"]).max() < 2e-5
+    assert np.abs(fw[2][1] - x.astype(np.float32)).max() == 0.0
+    assert np.abs(fu[2][1] - (x + img * prd).astype(np.float32)).max() == 0.0
+
+
 def test_restart_is_bit_continuous(tmp_path):
     """write_restart / read_restart keep the RanMars streams of fix langevin and of the three LE fixes (the reference
     does not): `run 25; write_restart` + a NEW instance `read_restart; fix ...; run 25` is bit-identical to
