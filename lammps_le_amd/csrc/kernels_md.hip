@@ -167,6 +167,8 @@ struct ForceArgs {
   int diag;              // diagnostics only (LAMMPS_LE_DIAG_STEP): extra launch with parts off, see launch_step
   // a launch that tests the skin/2 displacement (a rebuild may follow) also bins the new positions: cell, arrival order
   // inside the cell and the cell counts, i.e. everything k_wrap_bin would produce except Domain::pbc itself (k_permute)
+  const float4 *holdf;   // float copy of xhold (= posf of the last build; nullptr: use xhold only)
+  double hold_band;
   int bin, ncx, ncy, ncz;
   double cix, ciy, ciz, zlo_ext;
   int *cell_of, *cell_count, *cell_rank;
@@ -522,9 +524,26 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
       if (sl >= 0) A.sendbuf[(sl & ((1 << 30) - 1)) + ((sl >> 30) ? A.nsend0 : 0)] = ri;
     }
     if (check) {
-      const double4 h = AHEAD ? hold : xhold[p];
-      double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
-      if (dx * dx + dy * dy + dz * dz > triggersq && !(DIAG && A.diag)) flags[FLAG_MOVED] = 1;
+      // Neighbor::check_distance.  Throughput shape: the float copy of the build-time positions (posf, 16 B, what the
+      // list build reads anyway) decides unless the squared displacement lies within an error band of skin^2/4; only
+      // then is the double reference fetched, so the flag is the one the FP64 test sets (32 MB less per test at 1M).
+      bool moved;
+      if (!AHEAD && A.holdf) {
+        const float4 hf = A.holdf[p];
+        double dx = ri.x - (double)hf.x, dy = ri.y - (double)hf.y, dz = ri.z - (double)hf.z;
+        const double dsq = dx * dx + dy * dy + dz * dz;
+        moved = dsq > triggersq;
+        if (fabs(dsq - triggersq) < A.hold_band) {
+          const double4 h = xhold[p];
+          dx = ri.x - h.x; dy = ri.y - h.y; dz = ri.z - h.z;
+          moved = dx * dx + dy * dy + dz * dz > triggersq;
+        }
+      } else {
+        const double4 h = AHEAD ? hold : xhold[p];
+        double dx = ri.x - h.x, dy = ri.y - h.y, dz = ri.z - h.z;
+        moved = dx * dx + dy * dy + dz * dz > triggersq;
+      }
+      if (moved && !(DIAG && A.diag)) flags[FLAG_MOVED] = 1;
       if (!DIAG && A.bin) {     // (wave-uniform; the lanes still here: every LPB-th one up to the end of the array)
         double4 w = ri;
         int cell = 0;
@@ -585,6 +604,15 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.bprow = std::max(d.bpa, 1) - 1;
   A.diag = 0;
   A.sendslot = nullptr; A.sendbuf = nullptr; A.nsend0 = 0;
+  {
+    // posf = (float)xhold: a coordinate is off by <= M * 2^-24, a squared displacement d^2 <= skin^2/4 .. by
+    // <= 2 * sqrt(3) * |d| * e + 3 e^2; |d| <= ~skin near the threshold.  Band = four times that bound.
+    double M = 0.0;
+    for (int k = 0; k < 3; k++) M = std::max({M, fabs(d.box.lo[k]), fabs(d.box.hi[k])});
+    const double e = M * 5.97e-8, dmax = 2.0 * d.cutneigh;
+    A.holdf = (d.posf && !d.dd) ? d.posf : nullptr;
+    A.hold_band = 4.0 * (2.0 * 1.7320508 * dmax * e + 3.0 * e * e);
+  }
   A.bin = 0; A.ncx = d.ncell[0]; A.ncy = d.ncell[1]; A.ncz = d.ncell[2];
   A.cix = d.cellinv[0]; A.ciy = d.cellinv[1]; A.ciz = d.cellinv[2]; A.zlo_ext = d.zlo_ext;
   A.cell_of = d.cell_of; A.cell_count = d.cell_count; A.cell_rank = d.tag_tmp;
