@@ -206,6 +206,7 @@ struct ExtrusionParams {
 void le_rng_upload(DeviceState &d, int slot, const RanMarsInt &r);
 void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
 // each returns after enqueueing; counters are read back by the caller through flags_h
+void launch_topo_snapshot(DeviceState &d);   // num_bond0 / bond_type0 / bond_atom0 := current bond tables
 void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
 // stock fix bond/create: `bondcount` (host, by tag, nt ints) goes up before the launch; bond_create_counts fetches it back
 void launch_bond_create(DeviceState &d, const ExLoadParams &p, int rng_slot, const int *bondcount, int nt);

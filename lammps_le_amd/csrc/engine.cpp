@@ -397,10 +397,7 @@ void Engine::reneighbor(bool defer_check) {
   }
   if (d.le_snapshot && d.topo_dirty) {   // NTopoBond::build: the bond list the LE fixes will see until the next reneighbor
     d.topo_dirty = false;
-    size_t nt = (size_t)d.maxtag + 2;
-    HIP_CHECK(hipMemcpyAsync(d.num_bond0, d.num_bond, nt * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
-    HIP_CHECK(hipMemcpyAsync(d.bond_type0, d.bond_type, nt * d.bpa * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
-    HIP_CHECK(hipMemcpyAsync(d.bond_atom0, d.bond_atom, nt * d.bpa * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
+    launch_topo_snapshot(d);
   }
   ago = 0;
   neigh_builds++;

@@ -227,6 +227,25 @@ __device__ __forceinline__ double d2(const double4 &a, const double4 &b) {
 }
 __global__ void k_zero_int(int n, int *a) { int i = blockIdx.x * BLOCK + threadIdx.x; if (i < n) a[i] = 0; }
 
+// NTopoBond::build as the LE fixes see it: the bond tables of this reneighbor, kept until the next one.  One streaming
+// kernel for the three tables (three blit copies of 4 + 12 + 12 MB took 255 us at 1M beads, this takes ~15)
+__global__ __launch_bounds__(BLOCK) void k_topo_snapshot(size_t n1, size_t n2, const int *__restrict__ nb,
+                                                         const int *__restrict__ bt, const int *__restrict__ ba,
+                                                         int *__restrict__ nb0, int *__restrict__ bt0, int *__restrict__ ba0) {
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n2; i += stride) {
+    if (i < n1) nb0[i] = nb[i];
+    bt0[i] = bt[i];
+    ba0[i] = ba[i];
+  }
+}
+void launch_topo_snapshot(DeviceState &d) {
+  const size_t nt = (size_t)d.maxtag + 2, n2 = nt * d.bpa;
+  int grid = (int)std::min<size_t>((n2 + BLOCK - 1) / BLOCK, 8192);
+  hipLaunchKernelGGL(k_topo_snapshot, dim3(std::max(grid, 1)), dim3(BLOCK), 0, d.stream, nt, n2, d.num_bond, d.bond_type,
+                     d.bond_atom, d.num_bond0, d.bond_type0, d.bond_atom0);
+}
+
 // ========================================= ex_load ============================================
 // base(a): every test of the candidate scan that does not depend on earlier pairs (fix_ex_load.cpp:453-494)
 __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, const double4 *__restrict__ xt,
