@@ -77,6 +77,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   for (int k = 0; k < NFLAGS + 16; k++) d.flags_h[k] = 0;
   d.flags_seq = 0;
   d.bins_ready = false;
+  d.cell_count_dirty = false;    // (freshly allocated arrays are zeroed)
   HIP_CHECK(hipHostGetDevicePointer((void **)&d.flags_h_dev, d.flags_h, 0));
   // LE fix scratch
   dalloc(d.xt, nt);

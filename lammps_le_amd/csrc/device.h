@@ -99,6 +99,7 @@ struct DeviceState {
   int *flags = nullptr;          // device
   int *flags_h = nullptr;        // pinned, mapped host copy
   int *flags_h_dev = nullptr;    // device-side address of flags_h
+  bool cell_count_dirty = false; // cell_count holds counts that no scan has consumed (and zeroed) yet
   bool bins_ready = false;       // cell_of / cell_count / arrival ranks hold the bins of the CURRENT positions (written by k_step)
   int flags_seq = 0;             // sequence number of the last publish (flags_h[NFLAGS] echoes it)
   // ---- Langevin RNG (block-parallel RanMars) ----

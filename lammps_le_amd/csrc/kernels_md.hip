@@ -651,7 +651,9 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   static const bool no_fused_bin = getenv("LAMMPS_LE_NO_FUSED_BIN") != nullptr;
   const bool bin = check && next && !d.dd && which < 0 && !lpb4 && !no_fused_bin && d.cell_count && d.ncells > 0;
   if (bin) {
-    HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(d.ncells + 1) * sizeof(int), d.stream));
+    // the counts are zero unless an earlier launch binned and no rebuild consumed them (the scan zeroes what it reads)
+    if (d.cell_count_dirty) HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(d.ncells + 1) * sizeof(int), d.stream));
+    d.cell_count_dirty = true;
     A.bin = 1;
   }
   d.bins_ready = bin;

@@ -51,11 +51,14 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
 }
 
 // ---- exclusive scan of cell_count[0..m) into cell_start[0..m], two small kernels ----
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(int m, const int *__restrict__ in, int *__restrict__ out,
+// (the counts are zeroed as they are read: the next binning pass - in the step kernel or in k_wrap_bin - finds a clean
+// array without a memset, which as a blit costs two launches, 11 us, between two step kernels)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(int m, int *__restrict__ in, int *__restrict__ out,
                                                            int *__restrict__ blocksum) {
   __shared__ int s[SCAN_BLOCK];
   int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  int v = (i < m) ? in[i] : 0;
+  int v = 0;
+  if (i < m) { v = in[i]; in[i] = 0; }
   s[threadIdx.x] = v;
   __syncthreads();
   for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
@@ -457,7 +460,7 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
   const bool prebinned = d.bins_ready && !gone && !d.dd && m_in == d.n;
   d.bins_ready = false;
   if (!prebinned) {
-    HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(nc + 1) * sizeof(int), st));
+    if (d.cell_count_dirty) HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(nc + 1) * sizeof(int), st));   // bins nobody consumed
     hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, m_in, d.pos, d.img, d.npad, d.box, d.ncell[0],
                        d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of,
                        d.cell_count, d.tag_tmp, d.flags, gone, d.ncells);
@@ -465,6 +468,7 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
   int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_count, d.cell_start, d.scan_tmp);
   hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_start, d.scan_tmp, m_in);
+  d.cell_count_dirty = false;      // k_scan_local left the counts at zero
   hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, m_in, d.cell_of, d.cell_start, d.tag_tmp, d.perm);
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
                      d.cell_start, d.perm, d.tag);
