@@ -161,6 +161,23 @@ def test_le_fixes_across_three_slabs_in_process(tmp_path, overlap, monkeypatch):
     assert np.abs(r["x"] - o.x()).max() < 1e-7
 
 
+def test_script_commands_between_runs_when_decomposed(tmp_path):
+    """Host-side commands between two runs of a decomposed system (three slabs, in process): `velocity create` replaces
+    the velocities on every rank's replicated host copy (the download before it is collective), periodic restart files
+    are written by rank 0 during the run, `write_data` after it; trajectories as on one rank."""
+    s = lattice_chain(20000, nchains=2, seed=23)
+    rfile = str(tmp_path / "dd.restart")
+    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + (
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 20\nrun 30\n"
+        "velocity all create 0.8 77123 dist gaussian loop local\nrestart 20 %s\nrun 40\n" % rfile)
+    o = run_oracle(script.replace("restart 20 %s\n" % rfile, ""), s)
+    r = run_ranks_local(3, s, script, tmp_path)
+    assert np.abs(r["x"] - o.x()).max() < 1e-9
+    assert np.abs(r["v"] - o.v()).max() < 1e-8
+    assert r["builds"][0] == o.neigh_builds()
+    assert os.path.exists(rfile + ".40") and os.path.exists(rfile + ".60")
+
+
 def test_rccl_bindings_on_one_rank():
     """The engine declares RCCL's entry points by hand (dlopen, no header): a size-1 communicator on the test GPU
     checks argument layouts and enum values through all-reduce(max), all-gather and a grouped send/recv to self."""
