@@ -53,37 +53,46 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
 // ---- exclusive scan of cell_count[0..m) into cell_start[0..m], two small kernels ----
 // (the counts are zeroed as they are read: the next binning pass - in the step kernel or in k_wrap_bin - finds a clean
 // array without a memset, which as a blit costs two launches, 11 us, between two step kernels)
+// (wavefront scans by lane shifts, 16 wave totals through LDS: two barriers per block instead of twenty)
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(v, off, 64); if (lane >= off) v += t; }
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(int m, int *__restrict__ in, int *__restrict__ out,
                                                            int *__restrict__ blocksum) {
-  __shared__ int s[SCAN_BLOCK];
+  __shared__ int wtot[SCAN_BLOCK / 64];
   int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   int v = 0;
   if (i < m) { v = in[i]; in[i] = 0; }
-  s[threadIdx.x] = v;
+  const int inc = wave_inclusive_scan(v);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 63) wtot[w] = inc;
   __syncthreads();
-  for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
-    int t = (threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
-    __syncthreads();
-    s[threadIdx.x] += t;
-    __syncthreads();
-  }
-  if (i < m) out[i] = s[threadIdx.x] - v;   // exclusive
-  if (threadIdx.x == SCAN_BLOCK - 1) blocksum[blockIdx.x] = s[threadIdx.x];
+  int before = 0;                                  // totals of the wavefronts in front of mine
+  for (int k = 0; k < w; k++) before += wtot[k];
+  if (i < m) out[i] = before + inc - v;            // exclusive
+  if (threadIdx.x == SCAN_BLOCK - 1) blocksum[blockIdx.x] = before + inc;
 }
 // second and last pass: every block sums the block totals in front of it itself (a few hundred L2-resident words; the
 // separate single-block scan of the totals cost a launch) and adds the offset to its slice
 __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(int m, int *__restrict__ out, const int *__restrict__ blocksum,
                                                          int total_slot_n) {
-  __shared__ int s[SCAN_BLOCK];
+  __shared__ int wtot[SCAN_BLOCK / 64];
   int part = 0;
   for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_BLOCK) part += blocksum[b];
-  s[threadIdx.x] = part;
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) wtot[threadIdx.x >> 6] = part;
   __syncthreads();
-  for (int off = SCAN_BLOCK / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
-    __syncthreads();
-  }
-  const int offset = s[0];
+  int offset = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_BLOCK / 64; k++) offset += wtot[k];
   int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   if (i < m) out[i] += offset;
   if (i == 0) out[m] = total_slot_n;
