@@ -691,6 +691,9 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
       if (++vi->second.which >= vi->second.values.size()) { variables.erase(name); var_info.erase(vi); jump_skip = true; }
       else variables[name] = vi->second.values[vi->second.which];
     }
+  } else if (cmd == "run_style") {
+    need(1);
+    if (arg[0] != "verlet") throw LammpsError("MI355X engine: run_style " + arg[0] + " is not supported (verlet only)");
   } else if (cmd == "label") {
     need(1);
   } else if (cmd == "jump") {

@@ -65,6 +65,9 @@ def test_errors_match_reference_messages(tmp_path):
         lmp.command("fix bad2 all ex_load 1000 1 1 1.12 2 prob 1.5 1")
     with pytest.raises(LammpsError, match="Illegal fix bond/break command"):
         lmp.command("fix bad2b all bond/break 1000 2 0.5 prob 1.5 1")
+    lmp.command("run_style verlet")
+    with pytest.raises(LammpsError, match="run_style respa is not supported"):
+        lmp.command("run_style respa 2 2")
     with pytest.raises(LammpsError, match="Unknown fix style"):
         lmp.command("fix bad3 all nvt temp 1 1 1")
     with pytest.raises(LammpsError, match="Fix langevin period must be > 0.0"):
