@@ -210,7 +210,8 @@ void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
 void launch_topo_snapshot(DeviceState &d);   // num_bond0 / bond_type0 / bond_atom0 := current bond tables
 void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
 // stock fix bond/create: `bondcount` (host, by tag, nt ints) goes up before the launch; bond_create_counts fetches it back
-void launch_bond_create(DeviceState &d, const ExLoadParams &p, int rng_slot, const int *bondcount, int nt);
+struct Comm;
+void launch_bond_create(DeviceState &d, const ExLoadParams &p, int rng_slot, const int *bondcount, int nt, Comm *comm);
 void bond_create_counts(DeviceState &d, int *bondcount, int nt);
 void launch_ex_unload(DeviceState &d, const ExUnloadParams &p, int rng_slot);
 void launch_extrusion(DeviceState &d, const ExtrusionParams &p, int rng_slot);

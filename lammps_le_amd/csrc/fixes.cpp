@@ -230,8 +230,8 @@ void FixExLoad::post_integrate() {
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
   ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction};
   if (stock) {
-    if (eng->world > 1) throw LammpsError("MI355X engine: fix bond/create is not available in decomposed runs");
-    launch_bond_create(d, p, slot, bondcount.data(), (int)bondcount.size());
+    if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // current positions by tag (ghost slots lag one step here)
+    launch_bond_create(d, p, slot, bondcount.data(), (int)bondcount.size(), eng->comm);
   } else {
     if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
     launch_ex_load(d, p, slot);

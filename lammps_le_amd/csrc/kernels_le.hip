@@ -17,6 +17,7 @@
 //  ex_unload farthest-wins partner over own bonds with the image frozen at the last reneighbor.
 //  special lists: rebuild_special_one / dedup exactly as fix_extrusion.cpp:1045-1135, O(events).
 #include "device.h"
+#include "comm.h"
 
 namespace lmp_le {
 
@@ -378,14 +379,16 @@ __global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams
                                                            const double4 *__restrict__ pos, const int *__restrict__ tag,
                                                            const int *__restrict__ neigh, const int *__restrict__ numneigh,
                                                            const int *__restrict__ bc, int *__restrict__ partner,
-                                                           int *__restrict__ haspartner) {
+                                                           int *__restrict__ haspartner, const double4 *__restrict__ xt) {
+  // xt != nullptr (decomposed): current positions by tag from the all-gather; a ghost's slot in `pos` still holds the
+  // previous step's position at this point of the step (the reference forward-communicates first, :368)
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
   const int t = tag[p];
   const int itype = tp.type_t[t];
   int best_tag = 0;
   if (itype == P.iatomtype || itype == P.jatomtype) {
-    const double4 ri = pos[p];
+    const double4 ri = xt ? xt[t] : pos[p];
     const int bci = bc[t];
     const int *sl = tp.special + (size_t)t * tp.ms;
     const int n1 = tp.nspecial[3 * (size_t)t];
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams
       if (!possible) continue;
       for (int q = 0; q < n1; q++) if (sl[q] == tj) possible = false;     // :455-458 no duplicate bond
       if (!possible) continue;
-      const double4 rj = pos[j];
+      const double4 rj = xt ? xt[tj] : pos[j];
       double dx = ri.x - rj.x, dy = ri.y - rj.y, dz = ri.z - rj.z;
       if (dx > box.half[0]) dx -= box.prd[0]; else if (dx < -box.half[0]) dx += box.prd[0];
       if (dy > box.half[1]) dy -= box.prd[1]; else if (dy < -box.half[1]) dy += box.prd[1];
@@ -417,19 +420,29 @@ __global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams
   partner[t] = best_tag;
   haspartner[t] = best_tag != 0;
 }
-void launch_bond_create(DeviceState &d, const ExLoadParams &P, int slot, const int *bondcount, int nt_host) {
+__global__ void k_nonzero(int n, const int *__restrict__ a, int *__restrict__ out) {
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) out[i] = a[i] != 0;
+}
+void launch_bond_create(DeviceState &d, const ExLoadParams &P, int slot, const int *bondcount, int nt_host, Comm *comm) {
   Topo tp = topo_of(d);
   int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
   hipStream_t st = d.stream;
   int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
-  if (nt_host != nt || d.n != T) throw LammpsError("fix bond/create: atom IDs must be 1..N on one rank");
+  if (nt_host != nt || (!d.dd && d.n != T)) throw LammpsError("fix bond/create: atom IDs must be 1..N");
   if (!d.neigh) throw LammpsError("fix bond/create needs a pair neighbor list");
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
   HIP_CHECK(hipMemcpyAsync(bc, bondcount, (size_t)nt * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemsetAsync(partner, 0, (size_t)nt * sizeof(int), st));
   HIP_CHECK(hipMemsetAsync(has, 0, (size_t)nt * sizeof(int), st));
   hipLaunchKernelGGL(k_bcreate_partner, dim3((d.n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, tp, P, d.box, d.n, d.npad, d.pos,
-                     d.tag, d.neigh, d.numneigh, bc, partner, has);
+                     d.tag, d.neigh, d.numneigh, bc, partner, has, d.dd ? d.xt : nullptr);
+  if (d.dd) {
+    // every rank picked partners for the beads it owns (its lists hold the ghosts within the pair shell); the table by
+    // tag is completed with a max-reduction (partner tags are > 0, unowned slots 0), the rest runs replicated as ex_load
+    comm->allreduce_int_max(st, partner, nt);
+    hipLaunchKernelGGL(k_nonzero, dim3(nb), dim3(BLOCK), 0, st, nt, partner, has);
+  }
   if (P.fraction < 1.0) {
     scan_ex(d, has, didx, nt, FLAG_NDRAW);
     launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);

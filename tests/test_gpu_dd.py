@@ -178,6 +178,30 @@ def test_script_commands_between_runs_when_decomposed(tmp_path):
     assert os.path.exists(rfile + ".40") and os.path.exists(rfile + ".60")
 
 
+def test_stock_bond_create_across_slabs(tmp_path):
+    """`fix bond/create` on three slabs: each rank picks partners for the beads it owns from its own lists (ghost
+    partners included, current positions from the all-gather), the partner table is completed by a max-reduction and
+    the rest runs replicated like ex_load; topology as on one rank."""
+    from test_gpu_le import melted
+    n = 20000
+    rng = np.random.RandomState(4)
+    types = np.where(rng.rand(n) < 0.3, 2, 1).astype(np.int32)
+    s = melted(n, nchains=2, seed=2, steps=400, types=types)
+    s["ntypes"], s["mass"] = 3, [1.0, 1.0, 1.0]
+    script = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0") \
+        .replace("comm_modify cutoff 5.0", "comm_modify cutoff 3.0") + (
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
+        "fix creating all bond/create 7 2 2 1.1 2 iparam 1 3 jparam 1 3 prob 0.6 8847\n"
+        "fix breaking all bond/break 9 2 1.3 prob 0.5 2211\nthermo 10\nrun 45\n")
+    o = run_oracle(script, s)
+    r = run_ranks_local(3, s, script, tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+    ns_o, sp_o = o.special_table()
+    assert special_sets(r["nspecial"], r["special"]) == special_sets(ns_o, sp_o)
+    assert o.fix_vector("creating")[1] > 50 and o.fix_vector("breaking")[1] > 0
+    assert np.abs(r["x"] - o.x()).max() < 1e-7
+
+
 def test_rccl_bindings_on_one_rank():
     """The engine declares RCCL's entry points by hand (dlopen, no header): a size-1 communicator on the test GPU
     checks argument layouts and enum values through all-reduce(max), all-gather and a grouped send/recv to self."""
