@@ -6,16 +6,29 @@ velocity-Verlet timestep of the whole system (pair lj/cut + bond fene + fix nve 
 USER-LE fixes on their firing steps, reneighboring included), inputs resident in HBM when timing starts.
 
 Default workload = BASELINE.json configs[3] at N=1 (the configuration the north-star target is quoted on):
-a 1M-bead single chain at melt density (strong scaling over N GPUs as z-slabs), barrier beads every 200, `extrusion 1000` / `ex_load 1000 prob 0.01` /
-`ex_unload 1000 prob 0.01` (the dense LE parameter set BASELINE.md measured the reference with), so that two
-firings of every LE fix fall inside the default 2000-step timed window.
+a 1M-bead single chain at melt density (strong scaling over N GPUs as z-slabs), barrier beads every 200,
+`extrusion 1000` / `ex_load 1000 prob 0.01` / `ex_unload 1000 prob 0.01` (the dense LE parameter set BASELINE.md
+measured the reference with).
+
+Order of a run (whatever K and W are, so that a 20-step line and a 2000-step line measure the same thing):
+  1. untimed PRE-ROLL to a state that has left the start lattice and carries extruders (default: to step 3010, i.e.
+     past three firings of every LE fix) — `pre_roll_steps` on the JSON line;
+  2. W untimed warm-up steps;
+  3. barrier + synchronize, `run K`, barrier + synchronize.  `value` = K / Loop time of that run, the metric exactly
+     as the reference prints it (src/finish.cpp:124-145: the timer starts after Verlet::setup, src/run.cpp:178-186),
+     MAX over ranks; the wall clock around the whole `run K` (setup included) is reported as `wall_s` / `value_wall`;
+  4. the three LE firings timed on their own (`le_firing`): the steps ...001-...010 of the next period (extrusion at
+     ...001, ex_unload at ...002, ex_load at ...003, each followed by the reneighboring it forces) against ten
+     ordinary steps, so a short window that holds no firing still reports what a firing costs;
+  5. only now is the state copied out for the CPU baseline (the copy idles the GPU; nothing timed follows it).
 
 Extra objects on the JSON line:
   roofline     — the fused step kernel k_step: algorithmic bytes (144*N + 4*F, F = stored full-list entries;
-                 DESIGN.md §3) / mean kernel duration from HIP events recorded on the launch
-                 stream inside the engine over the timed region, vs the 8 TB/s HBM3E peak.
+                 DESIGN.md §3) / mean kernel duration from HIP events recorded on the launch stream inside the
+                 engine over the timed region (every launch when K <= 64, every 16th otherwise), vs the 8 TB/s peak.
   cpu_baseline — the CPU oracle (oracle/le_oracle.c, a serial port of the reference path) on 1 host core, on a
-                 bounded sample (first steps of the same system from the same state); reported, not the target.
+                 bounded sample of the same system from the state (positions, velocities, bond topology with its
+                 extruders) the GPU run ended in; reported, not the target.
 """
 import argparse
 import json
@@ -31,15 +44,29 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
-    # name: (beads, chains, barrier_every, n1, nload, pload, tp)
-    "chain1m": (1000000, 1, 200, 1000, 1000, 0.01, 0.5),
-    "chains10x100k": (1000000, 10, 200, 1000, 1000, 0.01, 0.5),
-    "chain100k": (100000, 1, 0, 17500, 7000, 0.001, 1.0),     # README.md:17,33-34 parameters
-    "chain32k": (32000, 1, 0, 1000, 1000, 0.01, 1.0),
-    "chain250k": (250000, 1, 200, 1000, 1000, 0.01, 0.5),
-    "chain500k": (500000, 1, 200, 1000, 1000, 0.01, 0.5),
-    "chain8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5),        # per-GPU size of the 8 x 1M weak-scaling config, on one GPU
+    # name: (beads, chains, barrier_every, n1, nload, pload, tp, generator)
+    "chain1m": (1000000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),
+    "chains10x100k": (1000000, 10, 200, 1000, 1000, 0.01, 0.5, "lattice"),
+    "chain100k": (100000, 1, 0, 17500, 7000, 0.001, 1.0, "lattice"),     # README.md:17,33-34 parameters
+    "chain32k": (32000, 1, 0, 1000, 1000, 0.01, 1.0, "lattice"),
+    "chain250k": (250000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),
+    "chain500k": (500000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),
+    "chain8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),      # per-GPU size of the 8 x 1M weak-scaling config, on one GPU
+    # random-walk start (shape of the reference's tools/chain.f + def.chain: bond 0.97, rho* = 0.8442): tag order is NOT
+    # space order, which is what a melt looks like to every tag-indexed gather
+    "walk1m": (1000000, 1, 200, 1000, 1000, 0.01, 0.5, "walk"),
+    "walk100k": (100000, 1, 200, 1000, 1000, 0.01, 0.5, "walk"),
 }
+
+
+def bonds_by_tag(lmp):
+    """(type, lo, hi) rows of every stored bond, once, in ascending (lo, slot) order (vectorised bond_set)."""
+    nb, bt, ba = lmp.gather("num_bond"), lmp.gather("bond_type"), lmp.gather("bond_atom")
+    n, w = bt.shape
+    own = np.repeat(np.arange(1, n + 1, dtype=np.int64)[:, None], w, axis=1)
+    live = np.arange(w)[None, :] < nb[:, None]
+    keep = live & (own < ba)                      # newton_bond off: both ends store the bond, keep the lower end's copy
+    return np.stack([bt[keep], own[keep], ba[keep]], axis=1).astype(np.int32)
 
 
 def main():
@@ -48,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default="chain1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--pre-roll", type=int, default=-1,
+                    help="untimed steps before the warm-up (default: past three firings of every LE fix)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle sample length (0 = skip the CPU baseline)")
     args = ap.parse_args()
 
@@ -59,6 +88,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)"
+                         % (args.gpus, world, args.gpus))
     # rehearsal of the N > 1 path on a one-GPU box (every rank on device 0, file-mailbox transport instead of RCCL,
     # which refuses two ranks on one device): LAMMPS_LE_BENCH_SHM=1.  Never used for reported numbers.
     shm_rehearsal = world > 1 and os.environ.get("LAMMPS_LE_BENCH_SHM") == "1"
@@ -75,9 +107,13 @@ def main():
     from lammps_le_amd import lammps
     from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
 
-    nbeads, nchains, bar, n1, nload, pload, tp = WORKLOADS[args.workload]
+    nbeads, nchains, bar, n1, nload, pload, tp, gen = WORKLOADS[args.workload]
     # N > 1: the SAME system is decomposed into N z-slabs (strong scaling); every rank builds the identical input
-    sysd = lattice_chains(nbeads, nchains=nchains, seed=1, barrier_every=bar)
+    if gen == "walk":
+        from lammps_le_amd.synth import scrambled_chains
+        sysd = scrambled_chains(nbeads, nchains=nchains, seed=1, barrier_every=bar)
+    else:
+        sysd = lattice_chains(nbeads, nchains=nchains, seed=1, barrier_every=bar)
     ntypes = sysd["ntypes"]
     tmp = tempfile.mkdtemp(prefix="le_bench_")
     data = os.path.join(tmp, "data.r%d" % rank)
@@ -86,11 +122,17 @@ def main():
     script = CHAIN_INPUT.format(data=data, n1=n1, left=left, right=right, tp=tp, lr=lr, nload=nload, pload=pload)
 
     lmp = lammps(cmdargs=["-screen", "none"])
+    rccl_nranks = 1
     if world > 1 and shm_rehearsal:
         lmp.comm_init("shm", rank, world, session="bench%s" % os.environ.get("MASTER_PORT", "0"))
     elif world > 1:
         from lammps_le_amd import init_from_torch_distributed
         init_from_torch_distributed(lmp)     # engine's own RCCL communicator (unique id broadcast by torch)
+        # self-check of the first real multi-GPU run: the engine's communicator must span exactly N ranks
+        rccl_nranks = int(lmp.stat("comm_nranks"))
+        if rccl_nranks != world:
+            print("bench.py: engine communicator has %d ranks, expected %d" % (rccl_nranks, world), file=sys.stderr)
+            sys.exit(3)
     for ln in script.split("\n"):
         lmp.command(ln)
 
@@ -100,31 +142,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed warm-up of W steps: upload, melt from the lattice, first LE firings.  The state the CPU baseline starts
-    # from is copied out 50 steps before its end: the copy is ~0.1 s of host work during which the GPU idles and its
-    # clocks drop (the first 100 steps after such a pause were measured 2x slower); the last 50 warm-up steps bring
-    # them back before the timed region starts.
-    tail = 50 if args.warmup >= 100 else 0
-    lmp.command("run %d" % (args.warmup - tail))
-    if world == 1:
-        x_state, v_state = lmp.gather("x"), lmp.gather("v")
-    if tail:
-        lmp.command("run %d" % tail)
+    def max_over_ranks(val):
+        if world == 1:
+            return float(val)
+        t = torch.tensor([val], dtype=torch.float64, device="cpu" if shm_rehearsal else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    period = max(n1, nload)
+    # ---- 1. pre-roll (untimed): off the start lattice, extruders on the chain ----
+    pre = args.pre_roll if args.pre_roll >= 0 else 3 * period + 10
+    if pre > 0:
+        lmp.command("run %d" % pre)
+    # ---- 2. warm-up (untimed) ----
+    if args.warmup > 0:
+        lmp.command("run %d" % args.warmup)
+    # ---- 3. the timed region ----
     barrier()
     t0 = time.perf_counter()
     lmp.command("run %d" % args.steps)             # `run` = Verlet::setup + K steps, synchronised at the end
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if shm_rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- roofline of the dominant kernel (k_force: pair lj/cut + bonds, one launch per step) ----
+    wall = max_over_ranks(time.perf_counter() - t0)
+    loop = max_over_ranks(lmp.stat("loop_time"))   # the reference's Loop time: K steps, setup excluded
+    step_first = int(lmp.get_thermo("step")) - args.steps + 1
     kms = lmp.stat("pair_kernel_ms")
+    klaunches = int(lmp.stat("pair_kernel_launches"))
+    builds = int(lmp.stat("neigh_builds"))
     full_entries = lmp.stat("neigh_pairs")          # stored full-list entries (all ranks) = 2 * half pairs
     nbonds = lmp.get_thermo("bonds")
     nlocal = lmp.stat("nlocal")
+    sections = {k: round(lmp.stat("time_" + k), 6) for k in ("pair", "neigh", "comm", "modify", "output", "other")}
+
+    # ---- 4. what a firing of the three LE fixes costs (untimed for `value`) ----
+    le_firing = None
+    if period >= 100:
+        now = int(lmp.get_thermo("step"))
+        to_boundary = (period - now % period) % period
+        if to_boundary:
+            lmp.command("run %d" % to_boundary)
+        barrier()
+        lmp.command("run 10")                       # steps ...001 (extrusion), ...002 (ex_unload), ...003 (ex_load) + 7
+        fire_loop = max_over_ranks(lmp.stat("loop_time"))
+        fire_builds = int(lmp.stat("neigh_builds"))
+        lmp.command("run 30")                       # settle back to the ordinary rhythm
+        lmp.command("run 10")
+        plain_loop = max_over_ranks(lmp.stat("loop_time"))
+        plain_builds = int(lmp.stat("neigh_builds"))
+        extra_ms = 1e3 * (fire_loop - plain_loop)
+        le_firing = {"ms_per_period": round(extra_ms, 4), "period_steps": period,
+                     "ten_firing_steps_ms": round(1e3 * fire_loop, 4), "ten_plain_steps_ms": round(1e3 * plain_loop, 4),
+                     "neigh_builds": [fire_builds, plain_builds],
+                     "share_of_step_time": round(extra_ms / period / (1e3 * loop / args.steps), 5) if loop > 0 else None}
+    extruders = int(lmp.get_thermo("bonds") - (nbeads - nchains))
+
+    # ---- roofline of the dominant kernel (k_step: pair lj/cut + bonds + langevin + nve, one launch per step) ----
     # k_step moves, per owned bead: pos 32 r + pos' 32 w + v 24 r + 24 w + tag 4 + draws 12 + bond table 12 +
     # numneigh 4 = 144 B, plus 4 B per stored neighbor entry; this rank's share when decomposed
     alg_bytes = 144.0 * nlocal + 4.0 * full_entries * (nlocal / nbeads)
@@ -140,9 +211,9 @@ def main():
                 "achieved": round(achieved, 1),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kms, 5),
-                "launches_timed": int(lmp.stat("pair_kernel_launches"))}
+                "launches_timed": klaunches}
 
-    # ---- CPU baseline: the oracle on a bounded sample, rank 0 at N=1 only ----
+    # ---- 5. CPU baseline: the oracle on a bounded sample, rank 0 at N=1 only ----
     cpu = None
     cpu_steps = args.cpu_steps
     if cpu_steps < 0:
@@ -150,7 +221,9 @@ def main():
     if rank == 0 and world == 1 and cpu_steps > 0:
         from systems import OracleScript
         s2 = dict(sysd)
-        s2["x"], s2["v"] = x_state, v_state          # the state the timed GPU window started from
+        s2["x"], s2["v"], s2["image"] = lmp.gather("x"), lmp.gather("v"), lmp.gather("image")
+        s2["type"] = lmp.gather("type").astype(np.int32)
+        s2["bonds"] = bonds_by_tag(lmp)              # backbone + the extruders the GPU run has loaded
         osc = OracleScript(s2)
         for ln in script.split("\n"):
             if ln.startswith("thermo_style"):
@@ -158,22 +231,23 @@ def main():
             osc.line(ln)
         tc = time.perf_counter()
         osc.o.run(cpu_steps)
-        wall = time.perf_counter() - tc
+        cwall = time.perf_counter() - tc
         tm = osc.o.timers()
         cpu = {"value": round(cpu_steps / tm["total"], 3), "unit": "timesteps/s", "cores": 1, "kind": "port",
-               "sample": "%d steps of the same %d-bead system from the state near the end of the warm-up (setup excluded, as the "
-                         "reference's Loop time); wall incl. setup %.1f s" % (cpu_steps, nbeads, wall),
+               "sample": "%d steps of the same %d-bead system from the state the GPU run ended in (x, v, bond topology "
+                         "with %d extruders; setup excluded, as the reference's Loop time); wall incl. setup %.1f s"
+                         % (cpu_steps, nbeads, extruders, cwall),
                "split_pct": {k: round(100 * tm[k] / tm["total"], 1) for k in ("pair", "bond", "neigh", "modify")}}
 
     if rank == 0:
         out = {
             "metric": "MD timesteps/sec, bead-spring LJ+FENE chain with loop extrusion",
-            "value": round(args.steps / elapsed, 2),
+            "value": round(args.steps / loop, 2),
             "unit": "timesteps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 5), "higher_is_better": True,
+            "ms_per_step": round(1e3 * loop / args.steps, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d beads, %d chain(s), lj/cut 1.12 + fene + nve + langevin + extrusion %d / "
-                                   "ex_load %d prob %g / ex_unload %d prob %g" % (args.workload, nbeads, nchains, n1, nload,
+            "config": {"workload": "%s: %d beads, %d chain(s), %s start, lj/cut 1.12 + fene + nve + langevin + extrusion %d / "
+                                   "ex_load %d prob %g / ex_unload %d prob %g" % (args.workload, nbeads, nchains, gen, n1, nload,
                                                                                  pload, nload, pload),
                        "beads_total": nbeads,
                        "parallelism": "1 GPU" if world == 1 else
@@ -181,9 +255,13 @@ def main():
                        % (world, "a file mailbox on ONE shared GPU (rehearsal, not a result)" if shm_rehearsal else "RCCL")},
             "roofline": roofline, "cpu_baseline": cpu,
             # LJ units: the reference prints tau/day instead of ns/day (src/finish.cpp:124-145); timestep 0.005 tau
-            "tau_per_day": round(args.steps / elapsed * 0.005 * 86400.0, 1),
-            "engine_loop_time_s": round(lmp.stat("loop_time"), 5), "neigh_builds": int(lmp.stat("neigh_builds")),
-            "extruders": int(nbonds - (nbeads - nchains)), "fene_warnings": int(lmp.stat("fene_warnings")),
+            "tau_per_day": round(args.steps / loop * 0.005 * 86400.0, 1),
+            "timing": "value = steps / Loop time (setup excluded, src/finish.cpp:124-145), max over ranks",
+            "engine_loop_time_s": round(loop, 6), "wall_s": round(wall, 6), "value_wall": round(args.steps / wall, 2),
+            "pre_roll_steps": pre, "timed_steps": [step_first, step_first + args.steps - 1],
+            "neigh_builds": builds, "extruders": extruders, "le_firing": le_firing,
+            "loop_sections_s": sections, "rccl_nranks": rccl_nranks,
+            "fene_warnings": int(lmp.stat("fene_warnings")),
         }
         print(json.dumps(out))
     lmp.close()

@@ -251,7 +251,18 @@ double lammps_le_stat(void *handle, const char *name) {
   std::string k = name;
   if (k == "loop_time") return e->loop_time;
   if (k == "neigh_builds") return (double)e->neigh_builds;
-  if (k == "neigh_time") return e->timers[2];
+  if (k == "neigh_time" || k == "time_neigh") return e->timers[Engine::T_NEIGH];
+  if (k == "time_pair") return e->timers[Engine::T_PAIR];
+  if (k == "time_bond") return e->timers[Engine::T_BOND];
+  if (k == "time_comm") return e->timers[Engine::T_COMM];
+  if (k == "time_output") return e->timers[Engine::T_OUTPUT];
+  if (k == "time_modify") return e->timers[Engine::T_MODIFY];
+  if (k == "time_other") {
+    double all = 0.0;
+    for (int s = 0; s < Engine::T_NSECT; s++) all += e->timers[s];
+    return e->loop_time - all;
+  }
+  if (k == "comm_nranks") return e->comm ? (double)e->comm->nranks() : 1.0;
   if (k == "pair_kernel_ms") return e->kstat_ms;
   if (k == "pair_kernel_launches") return (double)e->kstat_n;
   if (k == "neigh_pairs") return e->stat_neigh_pairs();

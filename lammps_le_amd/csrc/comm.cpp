@@ -42,6 +42,8 @@ struct Rccl {
   int (*GetUniqueId)(ncclUniqueId_ *) = nullptr;
   int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId_, int) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommCount)(const ncclComm_t, int *) = nullptr;
+  int (*CommAbort)(ncclComm_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -59,7 +61,7 @@ struct Rccl {
     if (!h) throw LammpsError(std::string("cannot load librccl.so: ") + dlerror());
 #define SYM(f) *(void **)(&f) = dlsym(h, "nccl" #f); if (!f) throw LammpsError("librccl.so lacks nccl" #f)
     SYM(GetUniqueId); SYM(CommInitRank); SYM(CommDestroy); SYM(GroupStart); SYM(GroupEnd); SYM(Send); SYM(Recv);
-    SYM(AllReduce); SYM(AllGather); SYM(GetErrorString);
+    SYM(AllReduce); SYM(AllGather); SYM(GetErrorString); SYM(CommCount); SYM(CommAbort);
 #undef SYM
   }
 } rccl;
@@ -249,6 +251,14 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
     shm_sent.assign(world, 0); shm_rcvd.assign(world, 0);
     backend = SHM;
   } else throw LammpsError("unknown comm backend " + backend_name);
+}
+int Comm::nranks() {
+  if (backend == RCCL && rccl_comm) {
+    int c = 0;
+    NCCL_CHECK(rccl.CommCount((ncclComm_t)rccl_comm, &c));
+    return c;
+  }
+  return world;
 }
 void Comm::finalize() {
   if (backend == RCCL && rccl_comm) { rccl.CommDestroy((ncclComm_t)rccl_comm); rccl_comm = nullptr; }

@@ -16,6 +16,7 @@ struct Comm {
   hipStream_t main_stream = nullptr;   // every RCCL call is issued on the engine's stream: one total order per rank
   void init(const std::string &backend_name, int rank, int world, const void *unique_id, const std::string &session);
   void finalize();
+  int nranks();      // size of the communicator as the transport itself reports it (ncclCommCount for RCCL)
   // device buffers
   void exchange(hipStream_t st, const std::vector<Msg> &sends, const std::vector<Msg> &recvs);
   void allreduce_int_max(hipStream_t st, int *dev, int n);

@@ -379,7 +379,6 @@ static void check_device_error(Engine *e, DeviceState &d) {
 // the check (~25 us) is hidden behind that kernel instead of idling the GPU once per rebuild.
 void Engine::reneighbor(bool defer_check) {
   DeviceState &d = *dev;
-  double t0 = wall();
   // (read at every rebuild, not cached: the test that sets it shares its process with tests that must not see it)
   const char *ovf = getenv("LAMMPS_LE_TEST_OVERFLOW_AT");
   const long test_overflow_at = ovf ? atol(ovf) : -1;
@@ -401,7 +400,20 @@ void Engine::reneighbor(bool defer_check) {
   }
   ago = 0;
   neigh_builds++;
-  timers[2] += wall() - t0;
+}
+
+// Timer::stamp (src/timer.cpp:100-135): wall clock between stamps goes to a section; `timer sync` drains the device first
+void Engine::stamp() {
+  if (timer_level < 2) return;
+  if (timer_sync && dev && dev->stream) HIP_CHECK(hipStreamSynchronize(dev->stream));
+  timer_prev = wall();
+}
+void Engine::stamp(int which) {
+  if (timer_level < 2) return;
+  if (timer_sync && dev && dev->stream) HIP_CHECK(hipStreamSynchronize(dev->stream));
+  double now = wall();
+  timers[which] += now - timer_prev;
+  timer_prev = now;
 }
 
 bool Engine::finish_reneighbor() {
@@ -519,10 +531,9 @@ static int count_nve(Engine *e) {
 
 static bool timed_begin(Engine *e) {
   DeviceState &d = *e->dev;
-  // sample every 16th launch (uniform over the run)
-  static long counter = 0;
-  long c = counter++;
-  if (!e->kernel_timing || d.ev_used >= 4096 || (c & 15) != 0) return false;
+  // sample every ktime_every-th launch of this run (uniform over the run; every launch of a short run)
+  long c = e->ktime_counter++;
+  if (!e->kernel_timing || d.ev_used >= 4096 || (c % e->ktime_every) != 0) return false;
   if (d.ev0.size() <= d.ev_used) {
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
@@ -685,16 +696,25 @@ void Engine::iterate(long nsteps) {
     const bool restart_now = restart_every > 0 && ntimestep % restart_every == 0;
     const bool dump_now = (!dumps.empty() && dump_due(ntimestep)) || restart_now;   // needs the complete state of this step: unfused path
     TypeTables tt = make_tables(this, lg);
+    stamp();
     if (!pre_integrated) {
       bool will_check = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
       for (int k = 0; k < nnve; k++) launch_initial_integrate(d, tt, dt, triggersq, will_check && k == nnve - 1);
     }
     for (auto &f : fixes) if (f->has_post_integrate) f->post_integrate();
+    stamp(T_MODIFY);
     if (decide()) {
       const bool sort_due = sortfreq > 0 && ntimestep >= nextsort;
+      stamp();
       reneighbor(fusable && !eflag && !dump_now && !sort_due);
       if (sort_due) emulate_atom_sort();
-    } else halo_exchange();     // ghosts follow their owners (CommBrick::forward_comm)
+      stamp(T_NEIGH);
+    } else {
+      stamp();
+      halo_exchange();     // ghosts follow their owners (CommBrick::forward_comm)
+      stamp(T_COMM);
+    }
+    stamp();
     if (fusable && !eflag && !dump_now) {
       bool next = (it + 1 < nsteps);
       bool check_next = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
@@ -733,14 +753,17 @@ void Engine::iterate(long nsteps) {
       if (timed) d.ev_used++;
       if (lg) rng_langevin_consumed(d);
       pre_integrated = next;
+      stamp(T_PAIR);          // the fused kernel: pair + bond + post_force + final_integrate (+ next initial_integrate)
     } else {
       if (!finish_reneighbor()) regrow_lists();
       if (d.dd) dd_halo_wait(d);
       compute_forces(eflag);
+      stamp(T_PAIR);          // k_force: pair + bond in one pass
       if (lg) langevin_post_force(this, lg, nnve == 1);
       if (!(lg && nnve == 1))
         for (int k = 0; k < nnve; k++) launch_final_integrate(d, tt);
       pre_integrated = false;
+      stamp(T_MODIFY);
       if (eflag) {
         last_thermo = eval_thermo();
         thermo_log.push_back(last_thermo);
@@ -748,9 +771,42 @@ void Engine::iterate(long nsteps) {
       }
       if (dump_now) write_dumps(ntimestep);
       if (restart_now) write_periodic_restart(ntimestep);
+      if (eflag || dump_now || restart_now) stamp(T_OUTPUT);
     }
   }
+  stamp();
   HIP_CHECK(hipStreamSynchronize(d.stream));
+  stamp(T_PAIR);              // work still in flight when the host leaves the loop is the last step kernel
+}
+
+// "MPI task timing breakdown" of src/finish.cpp:318-370 (one task: min = avg = max, %varavg = 0).  Bond is part of the
+// Pair row here: pair and bond forces are ONE kernel (k_step / k_force), there is no boundary to stamp between them.
+void Engine::print_timing_breakdown(long nsteps) {
+  if (timer_level < 2 || nsteps <= 0) return;
+  const double tl = loop_time > 0.0 ? loop_time : 1.0;
+  std::string out = "\nMPI task timing breakdown:\nSection |  min time  |  avg time  |  max time  |%varavg| %total\n"
+                    "---------------------------------------------------------------\n";
+  char buf[160];
+  double all = 0.0;
+  auto row = [&](const char *label, int which) {
+    const double t = timers[which];
+    all += t;
+    snprintf(buf, sizeof buf, "%-8s| %-10.5g | %-10.5g | %-10.5g |%6.1f |%6.2f\n", label, t, t, t, 0.0, t / tl * 100.0);
+    out += buf;
+  };
+  row("Pair", T_PAIR);
+  if (atom_style != "atomic") row("Bond", T_BOND);
+  row("Neigh", T_NEIGH);
+  row("Comm", T_COMM);
+  row("Output", T_OUTPUT);
+  row("Modify", T_MODIFY);
+  const double other = loop_time - all;
+  snprintf(buf, sizeof buf, "Other   |            | %-10.4g |            |       |%6.2f\n", other, other / tl * 100.0);
+  out += buf;
+  if (!timer_sync)   // the reference's own words for its GPU build (src/finish.cpp:411-419)
+    out += "(host wall clock per section; the device runs asynchronously behind it - `timer sync` gives the device-accurate split)\n";
+  out += "\n";
+  say(out);
 }
 
 void Engine::run(long nsteps) {
@@ -768,9 +824,11 @@ void Engine::run(long nsteps) {
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
   host_current = false;
-  for (int k = 0; k < 8; k++) timers[k] = 0.0;
   setup();
+  for (int k = 0; k < 8; k++) timers[k] = 0.0;     // Timer::init() comes after setup (src/run.cpp:176-181)
   dev->ev_used = 0;
+  ktime_counter = 0;
+  ktime_every = nsteps <= 64 ? 1 : 16;
   double t0 = wall();
   iterate(nsteps);
   loop_time = wall() - t0;
@@ -792,8 +850,8 @@ void Engine::run(long nsteps) {
     else snprintf(buf, sizeof buf, "Performance: %.3f ns/day, %.3f timesteps/s\n", 86400.0 * sps * dt * 1e-6, sps);
     say(buf);
   }
-  snprintf(buf, sizeof buf, "Neigh   | %g s\nNeighbor list builds = %ld\nDangerous builds = %ld\n", timers[2], neigh_builds,
-           neigh_dangerous);
+  print_timing_breakdown(nsteps);
+  snprintf(buf, sizeof buf, "Neighbor list builds = %ld\nDangerous builds = %ld\n", neigh_builds, neigh_dangerous);
   say(buf);
   if (dev->flags_h[FLAG_FENE_WARN]) {
     snprintf(buf, sizeof buf, "FENE bond too long warnings: %d", dev->flags_h[FLAG_FENE_WARN]);

@@ -232,10 +232,22 @@ class Engine {
   double loop_time = 0.0;
   long neigh_builds = 0, neigh_dangerous = 0;
   int ago = 0;
+  // Timer sections of the loop (src/timer.h:25-28); wall clock between stamps as src/timer.cpp:100-135.  The GPU runs
+  // asynchronously behind the host, so without `timer sync` a section holds the time the HOST spent in it (waits for
+  // the device land where the host first needs a result); `timer sync` drains the stream at every stamp.
+  enum { T_PAIR = 0, T_BOND, T_NEIGH, T_COMM, T_OUTPUT, T_MODIFY, T_NSECT };
   double timers[8] = {0};
-  bool kernel_timing = false;  // LAMMPS_LE_KERNEL_TIMING=1: HIP events around every force-kernel launch
-  double kstat_ms = 0.0;       // mean force-kernel duration of the last run (ms)
+  int timer_level = 2;         // `timer off|loop|normal|full` (src/timer.cpp:230-300): 0 off, 1 loop, 2 normal, 3 full
+  bool timer_sync = false;     // `timer sync|nosync`
+  double timer_prev = 0.0;
+  void stamp();                // Timer::stamp()      : restart the section clock
+  void stamp(int which);       // Timer::stamp(which) : add the time since the previous stamp to a section
+  void print_timing_breakdown(long nsteps);   // src/finish.cpp:318-370
+  bool kernel_timing = false;  // LAMMPS_LE_KERNEL_TIMING=1: HIP events around sampled step-kernel launches
+  double kstat_ms = 0.0;       // mean step-kernel duration of the last run (ms)
   long kstat_n = 0;
+  long ktime_counter = 0;      // launches seen by the sampler in this run
+  int ktime_every = 16;        // sample every n-th launch (1 for runs of <= 64 steps)
   double stat_neigh_pairs();   // stored full-list entries of the current neighbor list
 
   // ---- topology on the host (read_data path) ----

@@ -755,7 +755,20 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
   } else if (cmd == "print") {
     need(1);
     say(substitute(arg[0]) + "\n");                              // src/input.cpp:1093
-  } else if (cmd == "timer" || cmd == "processors" || cmd == "package" ||
+  } else if (cmd == "timer") {
+    // src/timer.cpp:230-300 modify_params: off | loop | normal | full | sync | nosync (timeout / every: no wall-time limit here)
+    for (size_t k = 0; k < arg.size(); k++) {
+      const std::string &a = arg[k];
+      if (a == "off") timer_level = 0;
+      else if (a == "loop") timer_level = 1;
+      else if (a == "normal") timer_level = 2;
+      else if (a == "full") timer_level = 3;
+      else if (a == "sync") timer_sync = true;
+      else if (a == "nosync") timer_sync = false;
+      else if ((a == "timeout" || a == "every") && k + 1 < arg.size()) k++;
+      else throw LammpsError("Illegal timer command");
+    }
+  } else if (cmd == "processors" || cmd == "package" ||
              cmd == "suffix" || cmd == "group" || cmd == "velocity_zero") {
     if (cmd == "group" && !(arg.size() >= 1 && arg[0] == "all"))
       throw LammpsError("MI355X engine: only group all is supported");
