@@ -229,6 +229,9 @@ def main():
             if ln.startswith("thermo_style"):
                 continue
             osc.line(ln)
+        # same phase of the LE firing periods as the GPU run (a firing right after a firing moves extruder bonds that
+        # have not relaxed yet: an oracle restarted at step 0 aborts with `Bad FENE bond` at 1M beads)
+        osc.line("reset_timestep %d" % int(lmp.get_thermo("step")))
         tc = time.perf_counter()
         osc.o.run(cpu_steps)
         cwall = time.perf_counter() - tc

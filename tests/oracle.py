@@ -114,6 +114,9 @@ class Oracle:
     def atom_sort(self, freq):
         self.L.leo_atom_sort(self.h, C.c_int(freq))
 
+    def reset_timestep(self, step):
+        self.L.leo_reset_timestep(self.h, C.c_long(int(step)))
+
     def thermo_every(self, n):
         self.L.leo_thermo_every(self.h, C.c_int(n))
 

@@ -223,6 +223,8 @@ class OracleScript:
             o.timestep(float(a[0]))
         elif c == "thermo":
             o.thermo_every(int(a[0]))
+        elif c == "reset_timestep":
+            o.reset_timestep(int(a[0]))
         elif c == "run":
             o.run(int(a[0]))
         else:
