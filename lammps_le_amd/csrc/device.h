@@ -88,6 +88,7 @@ struct DeviceState {
   int *numneigh = nullptr;   // [npad]
   int *bpart = nullptr;      // [bpa][npad] (type << 26) | partner p ; -1 = none
   double *pairtab = nullptr; // 6 * nt*nt : cutsq lj1 lj2 lj3 lj4 offset
+  int sflag[4] = {1, 1, 1, 1};   // Engine::special_flag per level: 0 dropped from the list, 1 ordinary entry, 2 entry with level bits
   int pair_uniform = 0;      // every type pair has the same coefficients
   double pair_u[6] = {0, 0, 0, 0, 0, 0};
   double cutneigh = 0.0;
@@ -208,7 +209,8 @@ void le_rng_upload(DeviceState &d, int slot, const RanMarsInt &r);
 void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);
 // each returns after enqueueing; counters are read back by the caller through flags_h
 void launch_topo_snapshot(DeviceState &d);   // num_bond0 / bond_type0 / bond_atom0 := current bond tables
-void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot);
+struct Comm;
+void launch_ex_load(DeviceState &d, const ExLoadParams &p, int rng_slot, Comm *comm);
 // stock fix bond/create: `bondcount` (host, by tag, nt ints) goes up before the launch; bond_create_counts fetches it back
 struct Comm;
 void launch_bond_create(DeviceState &d, const ExLoadParams &p, int rng_slot, const int *bondcount, int nt, Comm *comm);

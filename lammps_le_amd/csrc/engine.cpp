@@ -178,6 +178,7 @@ void Engine::upload() {
       if (auto *l = dynamic_cast<FixLangevin *>(f.get())) l->dev_ready = false;
   }
   d.box = box;
+  for (int k = 1; k <= 3; k++) d.sflag[k] = special_flag(k);
   if (comm) comm->main_stream = d.stream;
   int n = natoms, np = d.npad;
   size_t nt = (size_t)n + 2;
@@ -258,7 +259,7 @@ void Engine::upload() {
       const int *sl = &special[(size_t)i * maxspecial];
       int n1 = nspecial[3 * (size_t)i], n2 = nspecial[3 * (size_t)i + 1], n3 = nspecial[3 * (size_t)i + 2];
       for (int k = 0; k < n3; k++)
-        if (sl[k] == t) { int l = k < n1 ? 1 : k < n2 ? 2 : 3; return special_lj[l] == 1.0 ? 0 : l; }
+        if (sl[k] == t) { int l = k < n1 ? 1 : k < n2 ? 2 : 3; return special_flag(l) == 1 ? 0 : l; }
       return 0;     // a level with weight 1 is the same as not special
     };
     int asym = 0;
@@ -267,7 +268,7 @@ void Engine::upload() {
       for (int k = 0; k < n3; k++) {
         int j = special[(size_t)i * maxspecial + k] - 1;
         int l = k < n1 ? 1 : k < n2 ? 2 : 3;
-        if (special_lj[l] == 1.0) continue;
+        if (special_flag(l) == 1) continue;
         if (j < 0 || j >= natoms || level(j, i + 1) != l) { asym = 1; break; }
       }
     }
@@ -816,6 +817,7 @@ void Engine::run(long nsteps) {
   init();
   double tr1 = wall();
   if (!dev_current || !dev || !dev->pos) upload();
+  for (int k = 1; k <= 3; k++) dev->sflag[k] = special_flag(k);
   double tr2 = wall();
   le_reneigh_step.assign(fixes.size(), -1);
   dev->le_snapshot = 0;

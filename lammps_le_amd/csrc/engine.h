@@ -179,6 +179,16 @@ class Engine {
   int sortfreq = 1000;
   long nextsort = 0;
   double special_lj[4] = {1.0, 0.0, 0.0, 0.0};
+  double special_coul[4] = {1.0, 0.0, 0.0, 0.0};   // no Coulomb on this path, but the pair list's special flags depend on it
+  // how the pair list treats a special level (src/neighbor.cpp:360-376 special_flag, src/npair.h:112-136 find_special):
+  // 0 = pair dropped from the list (lj and coul weight both 0), 1 = stored as an ordinary entry, 2 = stored with the level
+  // in its top bits.  The reference also takes 2 when lj == 1 but coul != 1; the factor such an entry carries is 1.0,
+  // so it is stored as an ordinary entry here (same list membership, same forces).
+  int special_flag(int level) const {
+    if (special_lj[level] == 0.0 && special_coul[level] == 0.0) return 0;
+    if (special_lj[level] == 1.0) return 1;
+    return 2;
+  }
   double comm_cutoff = 0.0;
   long ntimestep = 0, beginstep = 0, endstep = 0;
   int thermo_every = 0;

@@ -234,7 +234,7 @@ void FixExLoad::post_integrate() {
     launch_bond_create(d, p, slot, bondcount.data(), (int)bondcount.size(), eng->comm);
   } else {
     if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
-    launch_ex_load(d, p, slot);
+    launch_ex_load(d, p, slot, eng->comm);
   }
   d.topo_dirty = true;
   sync_flags(d);

@@ -340,23 +340,31 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
       } else throw LammpsError("Illegal atom_modify command");
     }
   } else if (cmd == "special_bonds") {
-    // src/force.cpp:748- set_special
+    // src/force.cpp:748-826 set_special: every command starts from the defaults (lj 0 0 0, coul 0 0 0)
     need(1);
+    const char *ill = "Illegal special_bonds command";
+    for (int k = 1; k <= 3; k++) special_lj[k] = special_coul[k] = 0.0;
+    auto set3 = [&](double *w, double a, double b, double c) { w[1] = a; w[2] = b; w[3] = c; };
     for (size_t i = 0; i < arg.size();) {
-      if (arg[i] == "fene") { special_lj[1] = 0.0; special_lj[2] = 1.0; special_lj[3] = 1.0; i++; }
-      else if (arg[i] == "lj" || arg[i] == "lj/coul") {
-        if (i + 4 > arg.size()) throw LammpsError("Illegal special_bonds command");
+      if (arg[i] == "amber") { set3(special_lj, 0.0, 0.0, 0.5); set3(special_coul, 0.0, 0.0, 5.0 / 6.0); i++; }
+      else if (arg[i] == "charmm") { set3(special_lj, 0.0, 0.0, 0.0); set3(special_coul, 0.0, 0.0, 0.0); i++; }
+      else if (arg[i] == "dreiding") { set3(special_lj, 0.0, 0.0, 1.0); set3(special_coul, 0.0, 0.0, 1.0); i++; }
+      else if (arg[i] == "fene") { set3(special_lj, 0.0, 1.0, 1.0); set3(special_coul, 0.0, 1.0, 1.0); i++; }
+      else if (arg[i] == "lj/coul" || arg[i] == "lj" || arg[i] == "coul") {
+        if (i + 4 > arg.size()) throw LammpsError(ill);
         for (int k = 1; k <= 3; k++) {
-          special_lj[k] = numeric(arg[i + k]);
-          if (special_lj[k] < 0.0 || special_lj[k] > 1.0) throw LammpsError("Illegal special_bonds command");
+          const double w = numeric(arg[i + k]);
+          if (arg[i] != "coul") special_lj[k] = w;
+          if (arg[i] != "lj") special_coul[k] = w;
         }
         i += 4;
-      } else if (arg[i] == "coul") { if (i + 4 > arg.size()) throw LammpsError("Illegal special_bonds command"); i += 4; }
-      else if (arg[i] == "charmm") { special_lj[1] = special_lj[2] = special_lj[3] = 0.0; i++; }
-      else if (arg[i] == "amber") { special_lj[1] = special_lj[2] = 0.0; special_lj[3] = 0.5; i++; }
-      else if (arg[i] == "angle" || arg[i] == "dihedral") { i += 2; }
-      else throw LammpsError("Illegal special_bonds command");
+      } else if (arg[i] == "angle" || arg[i] == "dihedral") {
+        if (i + 2 > arg.size() || (arg[i + 1] != "no" && arg[i + 1] != "yes")) throw LammpsError(ill);
+        i += 2;
+      } else throw LammpsError(ill);
     }
+    for (int k = 1; k <= 3; k++)
+      if (special_lj[k] < 0.0 || special_lj[k] > 1.0 || special_coul[k] < 0.0 || special_coul[k] > 1.0) throw LammpsError(ill);
     if (box_exist && natoms) { special_built = false; }
   } else if (cmd == "read_data") {
     need(1);
@@ -940,7 +948,9 @@ void Engine::read_data(const std::string &path) {
 // Special::build (src/special.cpp:55-): set semantics of onetwo/onethree/onefour + dedup + combine;
 // 1-3 / 1-4 are only built when their weights differ from 1.0 (:103-131)
 void Engine::build_special() {
-  bool do13 = !(special_lj[2] == 1.0 && special_lj[3] == 1.0), do14 = do13 && !(special_lj[3] == 1.0);
+  // src/special.cpp:97-131: the lists beyond a level are built unless both the lj and the coul weights there are 1.0
+  bool do13 = !(special_lj[2] == 1.0 && special_coul[2] == 1.0 && special_lj[3] == 1.0 && special_coul[3] == 1.0),
+       do14 = do13 && !(special_lj[3] == 1.0 && special_coul[3] == 1.0);
   std::vector<std::vector<int>> l12(natoms), l13(natoms), l14(natoms);
   auto has = [](const std::vector<int> &a, int val) { return std::find(a.begin(), a.end(), val) != a.end(); };
   for (int i = 0; i < natoms; i++)
@@ -1472,7 +1482,7 @@ struct Rd {
   void str(std::string &s) { uint64_t n; pod(n); if (n > (1u << 20)) throw LammpsError("Restart file is not a lammps_le_amd restart file"); s.resize(n); if (n && fread(&s[0], 1, n, fp) != n) throw LammpsError("Restart file is truncated"); }
   template <class T> void vec(std::vector<T> &v) { uint64_t n; pod(n); if (n > (1ull << 36)) throw LammpsError("Restart file is truncated"); v.resize(n); if (n && fread(v.data(), sizeof(T), n, fp) != n) throw LammpsError("Restart file is truncated"); }
 };
-const char RESTART_MAGIC[] = "LAMMPS_LE_AMD restart 1";
+const char RESTART_MAGIC[] = "LAMMPS_LE_AMD restart 2";
 template <class T> void blob_put(std::vector<unsigned char> &b, const T &v) { const unsigned char *p = (const unsigned char *)&v; b.insert(b.end(), p, p + sizeof(T)); }
 template <class T> void blob_get(const std::vector<unsigned char> &b, size_t &off, T &v) { if (off + sizeof(T) > b.size()) throw LammpsError("Restart file: bad fix state"); memcpy(&v, &b[off], sizeof(T)); off += sizeof(T); }
 }  // namespace
@@ -1513,7 +1523,7 @@ void Engine::write_restart(const std::string &path) {
   w.str(RESTART_MAGIC);
   w.str(units); w.str(atom_style);
   w.pod(dt); w.pod(skin); w.pod(neigh_every); w.pod(neigh_delay); w.pod(neigh_check); w.pod(newton_pair); w.pod(newton_bond);
-  w.pod(sortfreq); w.pod(nextsort); w.pod(special_lj); w.pod(comm_cutoff); w.pod(ntimestep); w.pod(box);
+  w.pod(sortfreq); w.pod(nextsort); w.pod(special_lj); w.pod(special_coul); w.pod(comm_cutoff); w.pod(ntimestep); w.pod(box);
   w.pod(natoms); w.pod(ntypes); w.pod(nbondtypes); w.pod(extra_bond); w.pod(extra_special); w.pod(bpa); w.pod(maxspecial);
   w.pod(nbonds); w.pod(special_built);
   w.vec(mass); w.vec(mass_set); w.vec(x); w.vec(v); w.vec(type); w.vec(image); w.vec(molecule); w.vec(num_bond);
@@ -1549,7 +1559,7 @@ void Engine::read_restart(const std::string &path) {
     if (magic != RESTART_MAGIC) throw LammpsError("Restart file is not a lammps_le_amd restart file");
     r.str(units); r.str(atom_style);
     r.pod(dt); r.pod(skin); r.pod(neigh_every); r.pod(neigh_delay); r.pod(neigh_check); r.pod(newton_pair); r.pod(newton_bond);
-    r.pod(sortfreq); r.pod(nextsort); r.pod(special_lj); r.pod(comm_cutoff); r.pod(ntimestep); r.pod(box);
+    r.pod(sortfreq); r.pod(nextsort); r.pod(special_lj); r.pod(special_coul); r.pod(comm_cutoff); r.pod(ntimestep); r.pod(box);
     r.pod(natoms); r.pod(ntypes); r.pod(nbondtypes); r.pod(extra_bond); r.pod(extra_special); r.pod(bpa); r.pod(maxspecial);
     r.pod(nbonds); r.pod(special_built);
     r.vec(mass); r.vec(mass_set); r.vec(x); r.vec(v); r.vec(type); r.vec(image); r.vec(molecule); r.vec(num_bond);

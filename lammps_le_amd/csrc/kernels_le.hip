@@ -248,11 +248,24 @@ void launch_topo_snapshot(DeviceState &d) {
 }
 
 // ========================================= ex_load ============================================
-// base(a): every test of the candidate scan that does not depend on earlier pairs (fix_ex_load.cpp:453-494)
+// base(a): every test of the candidate scan that does not depend on earlier pairs (fix_ex_load.cpp:453-494), AND the
+// fact that the scan visits the pair at all: it walks `list->firstneigh` (:427-451), an occasional list that NPairCopy
+// (src/npair_copy.cpp) aliases to the pair list of the last reneighbor.  (a, a+2) is an entry there only if it was within
+// the list cutoff at that build and its special level is not dropped (npair_half_bin_newtoff.cpp:103-112: weight 0 ->
+// no entry; e.g. `special_bonds lj 0 0 1` removes every 1-3 pair and ex_load then loads nothing).  The engine's full
+// list holds the same pairs in both directions; the entry is looked up in the list of bead a, the lower local index at
+// the canonical order, whose special list the reference consults (ASYM builds apply that rule to both directions).
+// LISTSRC: 0 = one rank, every bead and its list are here -> ballot straight into the bitmask; 1 = decomposed: only the
+// owner of bead a has its list, write 0/1 per pair for a max-reduction over the ranks (k_exload_bits packs it afterwards).
+struct PairListView {
+  int n_owned, npad;
+  const int *map, *neigh, *numneigh;
+};
+template <int LISTSRC>
 __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, const double4 *__restrict__ xt,
-                                                       const int *__restrict__ bc,
+                                                       const int *__restrict__ bc, PairListView V,
                                                        unsigned long long *__restrict__ bits,
-                                                       double *__restrict__ rsq_out) {
+                                                       double *__restrict__ rsq_out, int *__restrict__ base_i) {
   int a = blockIdx.x * BLOCK + threadIdx.x;   // pair a = (a, a+2); a = 0 is never valid
   bool base = false;
   if (a >= 1 && a + 2 <= tp.T) {
@@ -274,8 +287,24 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
         base = rsq < P.cutsq;
       }
     }
+    if (base) {                          // few pairs get here: walk bead a's list for a+2
+      base = false;
+      const int p = V.map[i], q = V.map[j];
+      if (p >= 0 && p < V.n_owned && q >= 0) {
+        const int nn = V.numneigh[p];
+        for (int k = 0; k < nn; k++)
+          if ((V.neigh[(size_t)k * V.npad + p] & NEIGH_MASK) == q) { base = true; break; }
+      }
+    }
   }
+  if (LISTSRC == 1) { if (a <= tp.T + 1) base_i[a] = base ? 1 : 0; return; }
   unsigned long long m = __ballot(base);
+  if ((threadIdx.x & 63) == 0) bits[a >> 6] = m;
+}
+__global__ __launch_bounds__(BLOCK) void k_exload_bits(int nt, const int *__restrict__ base_i,
+                                                       unsigned long long *__restrict__ bits) {
+  int a = blockIdx.x * BLOCK + threadIdx.x;
+  unsigned long long m = __ballot(a < nt && base_i[a] != 0);
   if ((threadIdx.x & 63) == 0) bits[a >> 6] = m;
 }
 __device__ __forceinline__ bool bit_at(const unsigned long long *bits, int a) { return (bits[a >> 6] >> (a & 63)) & 1ull; }
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_create(Topo tp, ExLoadParams P
   fin[t] = f;
 }
 
-void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot) {
+void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm) {
   Topo tp = topo_of(d);
   int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
   hipStream_t st = d.stream;
@@ -358,7 +387,16 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot) {
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
   hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 0, d.flags);
   int nbw = ((nt + 63) / 64 * 64 + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL(k_exload_base, dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, d.le_bits, d.le_d[0]);
+  if (!d.neigh || !d.numneigh) throw LammpsError("fix ex_load needs a pair neighbor list");
+  PairListView V{d.n, d.npad, d.map, d.neigh, d.numneigh};
+  if (d.dd) {
+    int *base_i = d.le_i[I_E];
+    hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
+    comm->allreduce_int_max(st, base_i, nt);       // the owner of bead a knows whether (a, a+2) is in its list
+    hipLaunchKernelGGL(k_exload_bits, dim3(nbw), dim3(BLOCK), 0, st, nt, base_i, d.le_bits);
+  } else {
+    hipLaunchKernelGGL((k_exload_base<0>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], (int *)nullptr);
+  }
   hipLaunchKernelGGL(k_exload_partner, dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], partner, has);
   if (P.fraction < 1.0) {
     scan_ex(d, has, didx, nt, FLAG_NDRAW);

@@ -595,8 +595,8 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.sl0 = sl[0]; A.sl1 = sl[1]; A.sl2 = sl[2]; A.sl3 = sl[3];
   A.uniform = d.pair_uniform; A.u_cutsq = d.pair_u[0]; A.u_lj1 = d.pair_u[1]; A.u_lj2 = d.pair_u[2];
   A.u_lj3 = d.pair_u[3]; A.u_lj4 = d.pair_u[4]; A.u_off = d.pair_u[5];
-  A.has_sb = 0;
-  for (int k = 1; k <= 3; k++) if (sl[k] != 0.0 && sl[k] != 1.0) A.has_sb = 1;
+  A.has_sb = 0;     // some list entries carry a special level whose factor is not 1 (incl. lj weight 0 kept for its coul weight)
+  for (int k = 1; k <= 3; k++) if (d.sflag[k] == 2) A.has_sb = 1;
   A.margin = d.cutneigh;
   static int lim = getenv("LAMMPS_LE_NN_LIMIT") ? atoi(getenv("LAMMPS_LE_NN_LIMIT")) : (1 << 30);
   A.nn_limit = lim;

@@ -502,8 +502,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   // even the unused extra kernel argument cost the build 32 us)
   hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.tag, d.map, BT, d.flags);
   if (has_pair) {
-    auto sflag = [](double w) { return w == 0.0 ? 0 : (w == 1.0 ? 1 : 2); };
-    int sf1 = sflag(sl[1]), sf2 = sflag(sl[2]), sf3 = sflag(sl[3]);
+    const int sf1 = d.sflag[1], sf2 = d.sflag[2], sf3 = d.sflag[3];   // Engine::special_flag (lj AND coul weights)
     double margin = sqrt(cutneighsq) * (1.0 + 1e-12);
     // FP32 test: a float coordinate is off by <= M * 2^-24 (M = largest |coordinate|), a separation component
     // (difference, periodic shift with a float box length) by e_d <= 8 * M * 2^-24, the squared distance of a pair

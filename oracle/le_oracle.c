@@ -54,7 +54,7 @@ struct leo {
   /* pair */
   int pair_on, shift, mix; double cut_global;
   double *eps, *sig, *cut, *lj1, *lj2, *lj3, *lj4, *offset, *cutsq; int *setflag;
-  double special_lj[4];
+  double special_lj[4], special_coul[4];   /* src/force.cpp:47-49: coul defaults 0 0 0 (no Coulomb here; only the list flags use it) */
   /* bonds */
   int *bstyle; double *bp0, *bp1, *bp2, *bp3;
   /* neighbor */
@@ -158,6 +158,7 @@ leo_t *leo_new(int natoms, int ntypes, int nbondtypes, int extra_bond, int extra
   s->bp0 = calloc(nb, sizeof(double)); s->bp1 = calloc(nb, sizeof(double));
   s->bp2 = calloc(nb, sizeof(double)); s->bp3 = calloc(nb, sizeof(double));
   s->special_lj[0] = 1.0; s->special_lj[1] = s->special_lj[2] = s->special_lj[3] = 0.0;
+  s->special_coul[0] = 1.0; s->special_coul[1] = s->special_coul[2] = s->special_coul[3] = 0.0;
   /* defaults: src/neighbor.cpp:87-89, src/atom.cpp:89-91, src/update.cpp (units lj) */
   s->every = 1; s->delay = 10; s->check = 1; s->sortfreq = 1000;
   s->thermo_every = 0;
@@ -243,10 +244,16 @@ static int append_unique(int *list, int n, int self, int val, const int *a, int 
   for (int k = 0; k < nb; k++) if (b[k] == val) return n;
   list[n] = val; return n + 1;
 }
+/* special_bonds ... coul c1 c2 c3 (src/force.cpp:748-826); call before leo_special_build */
+void leo_special_coul(leo_t *s, double c1, double c2, double c3) {
+  s->special_coul[0] = 1.0; s->special_coul[1] = c1; s->special_coul[2] = c2; s->special_coul[3] = c3;
+}
 void leo_special_build(leo_t *s, double w1, double w2, double w3) {
   int n = s->n;
   s->special_lj[0] = 1.0; s->special_lj[1] = w1; s->special_lj[2] = w2; s->special_lj[3] = w3;
-  int do13 = !(w2 == 1.0 && w3 == 1.0), do14 = do13 && !(w3 == 1.0);
+  const double *c = s->special_coul;
+  /* src/special.cpp:97-131: 1-3 (1-4) lists are built unless BOTH the lj and the coul weights of the levels beyond are 1.0 */
+  int do13 = !(w2 == 1.0 && c[2] == 1.0 && w3 == 1.0 && c[3] == 1.0), do14 = do13 && !(w3 == 1.0 && c[3] == 1.0);
   int cap = 4096;
   int *l12 = malloc(cap * sizeof(int)), *l13 = malloc(cap * sizeof(int)), *l14 = malloc(cap * sizeof(int));
   /* two passes: size then fill */
@@ -453,10 +460,10 @@ static inline int find_special(const leo_t *s, int i, int tagj) {
   for (int k = 0; k < n3; k++)
     if (list[k] == tagj) {
       int lev = (k < n1) ? 1 : (k < n2) ? 2 : 3;
-      double w = s->special_lj[lev];
-      if (w == 0.0) return -1;
-      if (w == 1.0) return 0;
-      return lev;
+      double w = s->special_lj[lev], c = s->special_coul[lev];
+      if (w == 0.0 && c == 0.0) return -1;      /* special_flag 0: pair dropped from the list */
+      if (w == 1.0 && c == 1.0) return 0;       /* special_flag 1: ordinary entry */
+      return lev;                               /* special_flag 2: entry carries the level, factor_lj = special_lj[lev] */
     }
   return 0;
 }
@@ -1000,6 +1007,20 @@ static int fire_extrusion(leo_t *s, leo_fix *fx) {
 }
 
 /* ===================== fix ex_load: src/USER-LE/fix_ex_load.cpp:329-655 ===================== */
+/* Is (i, j), i < j local and both owned, an entry of the pair list of the last reneighbor?  fix_ex_load.cpp:427-451 walks
+   list->firstneigh of an occasional list that NPairCopy (src/npair_copy.cpp) aliases to the pair list; the pair is stored
+   under the smaller local index (npair_half_bin_newtoff.cpp:90) unless find_special said "weight 0" (:103-112) or it was
+   farther than the list cutoff at build time.  The owned-owned entry is the unshifted one. */
+static int in_pair_list(const leo_t *s, int i, int j) {
+  if (!s->pair_on) return 0;
+  if (s->brute) {
+    for (long p = 0; p < s->npairs; p++)
+      if (s->pi_[p] == i && (s->pj[p] & 0x3FFFFFFF) == j && !s->pshift[3 * p] && !s->pshift[3 * p + 1] && !s->pshift[3 * p + 2]) return 1;
+    return 0;
+  }
+  for (int p = s->firstneigh[i]; p < s->firstneigh[i + 1]; p++) if ((s->pj[p] & 0x3FFFFFFF) == j) return 1;
+  return 0;
+}
 static int fire_ex_load(leo_t *s, leo_fix *fx) {
   int n = s->n; const int *tag = s->tag;
   int *partner = s->ia, *finalpartner = s->ib; double *distsq = s->da;
@@ -1034,9 +1055,10 @@ static int fire_ex_load(leo_t *s, leo_fix *fx) {
       for (int k = 0; k < s->nspecial[3 * i]; k++) if (sl[k] == tag[j]) possible = 0;
       if (!possible) continue;
       double rsq = d2raw(s, i, j);
-      /* the pair must also be in the neighbor list (raw distance within the list cutoff at build time);
-         with a valid list rsq < cutsq <= cut_pair^2 implies that */
       if (rsq >= fx->cutsq) continue;
+      /* the scan only ever sees pairs that ARE entries of the list (:437-441 loop over jlist).  Checked last here: every
+         test above is a `continue` without side effects, so their order relative to this one cannot change the result */
+      if (!in_pair_list(s, i, j)) continue;
       if (rsq < distsq[i]) { partner[i] = tag[j]; distsq[i] = rsq; }
       if (rsq < distsq[j]) { partner[j] = tag[i]; distsq[j] = rsq; }
     }

@@ -49,6 +49,10 @@ void   leo_set_atoms(leo_t *s, const int *tag, const int *type, const double *x,
 void   leo_set_bonds(leo_t *s, int nbonds, const int *btype, const int *a1, const int *a2);
 /* special_bonds lj w1 w2 w3 ; builds 1-2/1-3/1-4 lists (src/special.cpp:55-) */
 void   leo_special_build(leo_t *s, double w1, double w2, double w3);
+/* Coulomb weights of special_bonds (src/force.cpp:748-826; defaults 0 0 0).  No Coulomb on this path, but they decide
+   with the lj weights which special levels are dropped from / flagged in the pair list and which lists get built;
+   call BEFORE leo_special_build */
+void   leo_special_coul(leo_t *s, double c1, double c2, double c3);
 
 /* ---- force field ---- */
 /* pair_style lj/cut rc ; mix: 0 geometric, 1 arithmetic ; shift: pair_modify shift yes */

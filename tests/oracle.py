@@ -92,7 +92,9 @@ class Oracle:
         bt, a1, a2 = (np.ascontiguousarray(b[:, k]) for k in range(3))
         self.L.leo_set_bonds(self.h, C.c_int(len(b)), _ip(bt), _ip(a1), _ip(a2))
 
-    def special_bonds(self, w1, w2, w3):
+    def special_bonds(self, w1, w2, w3, coul=(0.0, 0.0, 0.0)):
+        """special_bonds lj w1 w2 w3 [coul c1 c2 c3]; `fene` = lj 0 1 1 coul 0 1 1 (src/force.cpp:748-826)."""
+        self.L.leo_special_coul(self.h, *[C.c_double(c) for c in coul])
         self.L.leo_special_build(self.h, C.c_double(w1), C.c_double(w2), C.c_double(w3))
 
     def pair_lj_cut(self, cut, shift=False, mix="geometric"):

@@ -103,6 +103,7 @@ class OracleScript:
         self.o = None
         self.units = "lj"
         self.special = (0.0, 0.0, 0.0)
+        self.special_coul = (0.0, 0.0, 0.0)
         self.pending = []
         self.bond_style = None
         self.hybrid = []
@@ -123,7 +124,7 @@ class OracleScript:
         tag = (np.asarray(order) + 1).astype(np.int32)
         o.atoms(tag, s["type"][order], x[order], s["v"][order], img[order])
         o.bonds(s["bonds"])
-        o.special_bonds(*self.special)
+        o.special_bonds(*self.special, coul=self.special_coul)
         self.o = o
 
     def line(self, text):
@@ -143,9 +144,23 @@ class OracleScript:
                 if o:
                     o.atom_sort(self.sort)
         elif c == "special_bonds":
-            self.special = (0.0, 1.0, 1.0) if a[0] == "fene" else tuple(float(v) for v in a[1:4])
+            # src/force.cpp:748-826: every command starts from lj 0 0 0 / coul 0 0 0
+            lj, coul, k = (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0
+            while k < len(a):
+                if a[k] == "fene":
+                    lj, coul, k = (0.0, 1.0, 1.0), (0.0, 1.0, 1.0), k + 1
+                elif a[k] in ("lj", "coul", "lj/coul"):
+                    w = tuple(float(v) for v in a[k + 1:k + 4])
+                    if a[k] != "coul":
+                        lj = w
+                    if a[k] != "lj":
+                        coul = w
+                    k += 4
+                else:
+                    raise ValueError("oracle script: special_bonds " + a[k])
+            self.special, self.special_coul = lj, coul
             if o:
-                o.special_bonds(*self.special)
+                o.special_bonds(*self.special, coul=self.special_coul)
         elif c == "read_data":
             self._make()
             if hasattr(self, "sort"):

@@ -31,7 +31,7 @@ def test_random_le_scenarios(tmp_path, seed):
                               rmax=rmax) + "run 45\n"
     try:
         o = run_oracle(script, s)
-    except RuntimeError as e:      # the reference itself aborts on this parameter set (Bad FENE bond): the product must too
+    except RuntimeError as e:      # the oracle aborts on this parameter set (Bad FENE bond): the product must too
         from lammps_le_amd import LammpsError
         with pytest.raises(LammpsError):
             run_product(script, s, tmp_path)
@@ -83,7 +83,7 @@ def test_random_le_scenarios_decomposed(tmp_path, seed):
     try:
         o = run_oracle(script, s)
     except RuntimeError:
-        pytest.skip("the reference itself aborts on this parameter set")
+        pytest.skip("the ORACLE aborts (Bad FENE bond) on this parameter set; the 1-rank sweep checks that the product aborts too")
     # FENE R0 = 5.0 keeps every extruder bond shorter than the 5.0 ghost shell, so bond partners are always reachable
     r = run_ranks_local(2, s, script, tmp_path)
     assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()

@@ -218,3 +218,24 @@ run 12
     o = run_oracle(script, s)
     p = run_product(script, s, tmp_path)
     compare(p, o, ("loop", "loading", "unloading"))
+
+
+@pytest.mark.parametrize("special,expect_loads", [("lj 0 0 1", False), ("lj 0 1 1", True), ("lj 0 0 1 coul 0 1 1", True)])
+def test_ex_load_sees_only_pairs_of_the_pair_list(tmp_path, special, expect_loads):
+    """ex_load's candidates are ENTRIES of the pair list (fix_ex_load.cpp:427-451 walks list->firstneigh, an NPairCopy
+    of the pair list).  `special_bonds lj 0 0 1`: the 1-3 level has lj = coul = 0 -> every (i, i+2) pair is dropped at the
+    build (npair_half_bin_newtoff.cpp:103-112) -> nothing is ever loaded.  With a non-zero coul weight on that level the
+    entries stay in the list (special_flag 2, factor_lj 0) and ex_load loads again, although the LJ forces are the same."""
+    n = 3000
+    s = melted(n)
+    script = CHAIN_SCRIPT.replace("special_bonds fene", "special_bonds " + special) + """fix 1 all nve
+fix 2 all langevin 1.0 1.0 1.0 904297
+fix loading all ex_load 10 1 1 1.12 2 prob 0.9 684474 iparam 1 1 jparam 1 1
+thermo 10
+run 24
+"""
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loading",))
+    loaded = o.fix_vector("loading")[1]
+    assert (loaded > 0) == expect_loads, loaded

@@ -349,3 +349,19 @@ def test_set_command(tmp_path):
     assert (lmp.gather("v").reshape(n, 3)[:, 2] == 0.25).all()
     with pytest.raises(LammpsError, match="set keyword charge is not supported"):
         lmp.command("set atom 1 charge 1.0")
+
+
+def test_oracle_ex_load_candidates_are_pair_list_entries():
+    """Oracle side of tests/test_gpu_le.py::test_ex_load_sees_only_pairs_of_the_pair_list (runs without a GPU)."""
+    from systems import CHAIN_SCRIPT, lattice_chain, run_oracle
+    s = lattice_chain(1500, seed=4)
+    o = run_oracle(CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 99\nrun 1200\n", s)
+    s["x"], s["v"], s["image"] = o.x(), o.v(), o.image()
+    tail = ("fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
+            "fix loading all ex_load 10 1 1 1.12 2 iparam 1 1 jparam 1 1\nrun 24\n")
+    loads = {}
+    for sp in ("fene", "lj 0 0 1", "lj 0 0 1 coul 0 1 1", "lj 1 1 1"):
+        o = run_oracle(CHAIN_SCRIPT.replace("special_bonds fene", "special_bonds " + sp) + tail, s)
+        loads[sp] = o.fix_vector("loading")[1]
+    assert loads["fene"] > 0 and loads["lj 1 1 1"] > 0 and loads["lj 0 0 1 coul 0 1 1"] > 0
+    assert loads["lj 0 0 1"] == 0      # 1-3 pairs are not in the list: nothing to scan
