@@ -107,7 +107,8 @@ def main():
     from lammps_le_amd import lammps
     from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
 
-    nbeads, nchains, bar, n1, nload, pload, tp, gen = WORKLOADS[args.workload]
+    nbeads, nchains, bar, n1, nload, pload, tp, gen = WORKLOADS[args.workload][:8]
+    punload = WORKLOADS[args.workload][8] if len(WORKLOADS[args.workload]) > 8 else pload
     # N > 1: the SAME system is decomposed into N z-slabs (strong scaling); every rank builds the identical input
     if gen == "walk":
         from lammps_le_amd.synth import scrambled_chains
@@ -119,7 +120,7 @@ def main():
     data = os.path.join(tmp, "data.r%d" % rank)
     write_data(data, sysd)
     left, right, lr = (2, 3, "4") if ntypes == 4 else (1, 1, "")
-    script = CHAIN_INPUT.format(data=data, n1=n1, left=left, right=right, tp=tp, lr=lr, nload=nload, pload=pload)
+    script = CHAIN_INPUT.format(data=data, n1=n1, left=left, right=right, tp=tp, lr=lr, nload=nload, pload=pload, punload=punload)
 
     lmp = lammps(cmdargs=["-screen", "none"])
     rccl_nranks = 1
@@ -251,7 +252,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d beads, %d chain(s), %s start, lj/cut 1.12 + fene + nve + langevin + extrusion %d / "
                                    "ex_load %d prob %g / ex_unload %d prob %g" % (args.workload, nbeads, nchains, gen, n1, nload,
-                                                                                 pload, nload, pload),
+                                                                                 pload, nload, punload),
                        "beads_total": nbeads,
                        "parallelism": "1 GPU" if world == 1 else
                        "%d z-slabs, one rank per GPU, halo + migration over %s, replicated extruder table"

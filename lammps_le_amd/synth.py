@@ -94,7 +94,7 @@ fix 1 all nve
 fix 2 all langevin 1.0 1.0 1.0 904297
 fix loop all extrusion {n1} 1 {left} {right} {tp} 2 {lr}
 fix loading all ex_load {nload} 1 1 1.12 2 prob {pload} 684474 iparam 1 1 jparam 1 1
-fix unloading all ex_unload {nload} 2 0.5 prob {pload} 456456
+fix unloading all ex_unload {nload} 2 0.5 prob {punload} 456456
 timestep 0.005
 thermo_style custom step temp epair emol press bonds f_loop[1] f_loading[2] f_unloading[2]
 """

@@ -19,7 +19,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 sysd = lattice_chains(nbeads, nchains=1, seed=1, barrier_every=200)
 data = os.path.join(tempfile.mkdtemp(prefix="le_ddl_"), "data")
 write_data(data, sysd)
-script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01)
+script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01, punload=0.01)
 session = uuid.uuid4().hex[:10]
 times, stats = [0.0] * world, [None] * world
 bar = threading.Barrier(world)

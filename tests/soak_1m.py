@@ -11,7 +11,7 @@ n = 1000000
 sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
 data = os.path.join(tempfile.mkdtemp(), "data")
 write_data(data, sysd)
-script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01)
+script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01, punload=0.01)
 lmp = lammps(cmdargs=["-screen", "none"])
 for ln in script.split("\n"):
     lmp.command(ln)

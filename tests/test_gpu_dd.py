@@ -232,7 +232,7 @@ def test_eight_slabs_with_the_bench_script(tmp_path):
     from systems import OracleScript
     n = 500000
     sysd = lattice_chains(n, nchains=1, seed=3, barrier_every=200)
-    script = CHAIN_INPUT.format(data="data.chain", n1=10, left=2, right=3, tp=0.5, lr="4", nload=10, pload=0.2) + "run 34\n"
+    script = CHAIN_INPUT.format(data="data.chain", n1=10, left=2, right=3, tp=0.5, lr="4", nload=10, pload=0.2, punload=0.2) + "run 34\n"
     osc = OracleScript(dict(sysd))
     for ln in script.split("\n"):
         if not ln.startswith("thermo_style"):

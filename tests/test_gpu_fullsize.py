@@ -18,7 +18,7 @@ def system(tmp_path_factory):
     sysd = lattice_chains(N, nchains=1, seed=1, barrier_every=200)
     data = str(tmp_path_factory.mktemp("full") / "data.chain1m")
     write_data(data, sysd)
-    script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01)
+    script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01, punload=0.01)
     return sysd, script
 
 
