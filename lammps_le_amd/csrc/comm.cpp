@@ -19,6 +19,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -44,6 +46,7 @@ struct Rccl {
   int (*CommDestroy)(ncclComm_t) = nullptr;
   int (*CommCount)(const ncclComm_t, int *) = nullptr;
   int (*CommAbort)(ncclComm_t) = nullptr;
+  int (*CommGetAsyncError)(ncclComm_t, int *) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -61,7 +64,7 @@ struct Rccl {
     if (!h) throw LammpsError(std::string("cannot load librccl.so: ") + dlerror());
 #define SYM(f) *(void **)(&f) = dlsym(h, "nccl" #f); if (!f) throw LammpsError("librccl.so lacks nccl" #f)
     SYM(GetUniqueId); SYM(CommInitRank); SYM(CommDestroy); SYM(GroupStart); SYM(GroupEnd); SYM(Send); SYM(Recv);
-    SYM(AllReduce); SYM(AllGather); SYM(GetErrorString); SYM(CommCount); SYM(CommAbort);
+    SYM(AllReduce); SYM(AllGather); SYM(GetErrorString); SYM(CommCount); SYM(CommAbort); SYM(CommGetAsyncError);
 #undef SYM
   }
 } rccl;
@@ -242,6 +245,7 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
     NCCL_CHECK(rccl.CommInitRank(&c, world, uid, rank));
     rccl_comm = c;
     backend = RCCL;
+    if (const char *t = getenv("LAMMPS_LE_COMM_TIMEOUT")) timeout_s = std::max(1.0, atof(t));
   } else if (backend_name == "local") {
     hub = hub_for(session);
     backend = LOCAL;
@@ -251,6 +255,34 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
     shm_sent.assign(world, 0); shm_rcvd.assign(world, 0);
     backend = SHM;
   } else throw LammpsError("unknown comm backend " + backend_name);
+}
+void Comm::abort() {
+  if (backend == RCCL && rccl_comm) { rccl.CommAbort((ncclComm_t)rccl_comm); rccl_comm = nullptr; backend = NONE; }
+}
+void Comm::wait_stream(hipStream_t st) {
+  if (backend != RCCL) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+  const auto t0 = std::chrono::steady_clock::now();
+  long it = 0;
+  for (;;) {
+    hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return;
+    if (q != hipErrorNotReady) HIP_CHECK(q);
+    if ((++it & 0x3FF) == 0) {
+      int aerr = 0;
+      if (rccl_comm && rccl.CommGetAsyncError((ncclComm_t)rccl_comm, &aerr) == 0 && aerr != 0) {
+        std::string msg = std::string("RCCL asynchronous error on rank ") + std::to_string(rank) + ": " + rccl.GetErrorString(aerr);
+        abort();
+        throw LammpsError(msg);
+      }
+      const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > timeout_s) {
+        abort();
+        throw LammpsError("rank " + std::to_string(rank) + ": no answer from the other ranks within " + std::to_string((int)timeout_s) +
+                          " s - another rank has probably stopped on an error (communicator aborted)");
+      }
+      if (waited > 0.001) usleep(20);      // long waits (a peer is late or gone): stop burning the core
+    }
+  }
 }
 int Comm::nranks() {
   if (backend == RCCL && rccl_comm) {
@@ -291,7 +323,7 @@ void Comm::allgather_host(const void *send, void *recv, size_t bytes) {
   HIP_CHECK(hipMemcpyAsync(bounce, send, bytes, hipMemcpyHostToDevice, main_stream));
   NCCL_CHECK(rccl.AllGather(bounce, (char *)bounce + bytes, bytes, ncclInt8, (ncclComm_t)rccl_comm, main_stream));
   HIP_CHECK(hipMemcpyAsync(recv, (char *)bounce + bytes, bytes * world, hipMemcpyDeviceToHost, main_stream));
-  HIP_CHECK(hipStreamSynchronize(main_stream));
+  wait_stream(main_stream);
 }
 void Comm::ensure_bounce(size_t bytes) {
   if (bytes <= bounce_bytes) return;
@@ -398,7 +430,7 @@ void Comm::exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &
   HIP_CHECK(hipStreamSynchronize(main_stream));    // the host send buffers are stack variables of the caller
   exchange(main_stream, ds, dr);
   for (size_t k = 0; k < recvs.size(); k++) HIP_CHECK(hipMemcpyAsync(recvs[k].dev, dr[k].dev, recvs[k].bytes, hipMemcpyDeviceToHost, main_stream));
-  HIP_CHECK(hipStreamSynchronize(main_stream));
+  wait_stream(main_stream);
 }
 void Comm::barrier() {
   int x = 1;

@@ -13,7 +13,16 @@ struct Msg { void *dev; size_t bytes; int peer; };
 struct Comm {
   enum Backend { NONE, RCCL, SHM, LOCAL } backend = NONE;
   int rank = 0, world = 1;
-  hipStream_t main_stream = nullptr;   // every RCCL call is issued on the engine's stream: one total order per rank
+  // RCCL calls are issued on the engine's stream (one total order per rank); the opt-in halo/compute overlap
+  // (LAMMPS_LE_OVERLAP) additionally issues the per-step halo on comm_stream, ordered against the main stream by events
+  hipStream_t main_stream = nullptr;
+  // A rank that stops on an error (its own LammpsError) leaves its peers inside a collective that can never complete.
+  // Every host-side wait of a decomposed RCCL run therefore goes through wait_stream(): it polls the stream and the
+  // communicator's asynchronous error state and, after timeout_s (LAMMPS_LE_COMM_TIMEOUT, default 120 s - what the test
+  // transports use), aborts the communicator and throws, so that every rank ends with an error instead of hanging.
+  double timeout_s = 120.0;
+  void wait_stream(hipStream_t st);
+  void abort();      // ncclCommAbort (no-op for the test transports); called by a rank that leaves a run with an error
   void init(const std::string &backend_name, int rank, int world, const void *unique_id, const std::string &session);
   void finalize();
   int nranks();      // size of the communicator as the transport itself reports it (ncclCommCount for RCCL)

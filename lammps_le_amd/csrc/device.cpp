@@ -1,4 +1,5 @@
 // device.cpp — HBM allocation for one engine instance (288 GB per MI355X: everything stays resident).
+#include "comm.h"
 #include "device.h"
 
 #include <algorithm>
@@ -145,6 +146,10 @@ __global__ void k_publish_flags(int *__restrict__ flags, int *__restrict__ host,
   __syncthreads();
   if (k == 0) __hip_atomic_store(&host[NFLAGS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+void stream_sync(DeviceState &d) {
+  if (d.comm_watch) d.comm_watch->wait_stream(d.stream);
+  else HIP_CHECK(hipStreamSynchronize(d.stream));
+}
 void publish_flags(DeviceState &d, unsigned reset) {
   const int seq = ++d.flags_seq;
   hipLaunchKernelGGL(k_publish_flags, dim3(1), dim3(64), 0, d.stream, d.flags, d.flags_h_dev, reset, seq);
@@ -166,7 +171,7 @@ void wait_flags(DeviceState &d) {
     }                                                                            // work (or a fault): block instead
     if (h[NFLAGS] == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }   // pairs with the release store
   }
-  HIP_CHECK(hipStreamSynchronize(d.stream));
+  stream_sync(d);
 }
 
 }  // namespace lmp_le

@@ -158,6 +158,7 @@ struct DeviceState {
   double4 *xht = nullptr;                               // [maxtag+2] xhold by tag (LE fixes)
   double *gather_send = nullptr, *gather_recv = nullptr;      // whole-system gathers
   size_t gather_cap = 0;
+  Comm *comm_watch = nullptr;     // decomposed runs: host waits on the stream go through Comm::wait_stream (time-out + abort)
   // ---- kernel timing (HIP events on the launch stream) ----
   std::vector<hipEvent_t> ev0, ev1;
   size_t ev_used = 0;
@@ -217,6 +218,7 @@ void launch_bond_create(DeviceState &d, const ExLoadParams &p, int rng_slot, con
 void bond_create_counts(DeviceState &d, int *bondcount, int nt);
 void launch_ex_unload(DeviceState &d, const ExUnloadParams &p, int rng_slot);
 void launch_extrusion(DeviceState &d, const ExtrusionParams &p, int rng_slot);
+void stream_sync(DeviceState &d);    // wait for d.stream; with ranks: bounded (Comm::wait_stream)
 void sync_flags(DeviceState &d, unsigned reset_mask = 0);   // copy flags to flags_h, zero the masked ones, wait
 void publish_flags(DeviceState &d, unsigned reset_mask = 0);   // the same without waiting ...
 void wait_flags(DeviceState &d);                               // ... and the wait for the last publish

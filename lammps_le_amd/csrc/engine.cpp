@@ -180,6 +180,7 @@ void Engine::upload() {
   d.box = box;
   for (int k = 1; k <= 3; k++) d.sflag[k] = special_flag(k);
   if (comm) comm->main_stream = d.stream;
+  d.comm_watch = (comm && world > 1) ? comm : nullptr;
   int n = natoms, np = d.npad;
   size_t nt = (size_t)n + 2;
   std::vector<double4> pos(np);
@@ -690,7 +691,11 @@ void Engine::iterate(long nsteps) {
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
   bool ident = (sortfreq == 0);
   bool pre_integrated = false;
-  const bool overlap = getenv("LAMMPS_LE_OVERLAP") != nullptr && atoi(getenv("LAMMPS_LE_OVERLAP")) != 0;
+  // halo/compute overlap issues the per-step halo on a second stream.  With RCCL that means two streams feeding ONE
+  // communicator (ordered by events, but never run on multi-GPU hardware): kept to the test transports unless
+  // LAMMPS_LE_OVERLAP_RCCL=1 says otherwise
+  bool overlap = getenv("LAMMPS_LE_OVERLAP") != nullptr && atoi(getenv("LAMMPS_LE_OVERLAP")) != 0;
+  if (overlap && comm && comm->backend == Comm::RCCL && !getenv("LAMMPS_LE_OVERLAP_RCCL")) overlap = false;
   for (long it = 0; it < nsteps; it++) {
     ntimestep++;
     bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
@@ -776,7 +781,7 @@ void Engine::iterate(long nsteps) {
     }
   }
   stamp();
-  HIP_CHECK(hipStreamSynchronize(d.stream));
+  stream_sync(d);
   stamp(T_PAIR);              // work still in flight when the host leaves the loop is the last step kernel
 }
 
@@ -826,14 +831,22 @@ void Engine::run(long nsteps) {
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
   host_current = false;
-  setup();
-  for (int k = 0; k < 8; k++) timers[k] = 0.0;     // Timer::init() comes after setup (src/run.cpp:176-181)
-  dev->ev_used = 0;
-  ktime_counter = 0;
-  ktime_every = nsteps <= 64 ? 1 : 16;
-  double t0 = wall();
-  iterate(nsteps);
-  loop_time = wall() - t0;
+  double t0 = 0.0;
+  try {
+    setup();
+    for (int k = 0; k < 8; k++) timers[k] = 0.0;     // Timer::init() comes after setup (src/run.cpp:176-181)
+    dev->ev_used = 0;
+    ktime_counter = 0;
+    ktime_every = nsteps <= 64 ? 1 : 16;
+    t0 = wall();
+    iterate(nsteps);
+    loop_time = wall() - t0;
+  } catch (...) {
+    // a rank that leaves the loop on an error must not keep its peers inside a collective: tear the communicator down
+    // (they end with "communicator aborted" or their own copy of the error; see Comm::wait_stream)
+    if (comm && world > 1) { try { comm->abort(); } catch (...) {} }
+    throw;
+  }
   if (trace) fprintf(stderr, "[run %ld] init %.2f ms, upload %.2f ms, setup %.2f ms, loop %.2f ms\n", nsteps, 1e3 * (tr1 - tr0), 1e3 * (tr2 - tr1), 1e3 * (t0 - tr2), 1e3 * loop_time);
   kstat_ms = 0.0; kstat_n = 0;
   for (size_t k = 0; k < dev->ev_used; k++) {

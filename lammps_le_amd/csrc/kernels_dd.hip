@@ -491,7 +491,7 @@ void dd_gather_all(DeviceState &d, Comm &comm, std::vector<double> &rows, int &s
   comm.allgather(d.stream, d.gather_send, d.gather_recv, (size_t)stride * GATH_W * sizeof(double));
   rows.resize((size_t)stride * comm.world * GATH_W);
   HIP_CHECK(hipMemcpyAsync(rows.data(), d.gather_recv, rows.size() * sizeof(double), hipMemcpyDeviceToHost, d.stream));
-  HIP_CHECK(hipStreamSynchronize(d.stream));
+  stream_sync(d);
   stride_out = stride;
 }
 

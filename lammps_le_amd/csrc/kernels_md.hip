@@ -698,7 +698,7 @@ void reduce_partials(DeviceState &d, double *out16) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
   HIP_CHECK(hipMemcpyAsync(d.partial_h, d.partial, (size_t)nb * 16 * sizeof(double), hipMemcpyDeviceToHost,
                            d.stream));
-  HIP_CHECK(hipStreamSynchronize(d.stream));
+  stream_sync(d);
   for (int k = 0; k < 16; k++) out16[k] = 0.0;
   for (int b = 0; b < nb; b++)
     for (int k = 0; k < 16; k++) out16[k] += d.partial_h[(size_t)b * 16 + k];
