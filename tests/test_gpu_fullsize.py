@@ -76,3 +76,70 @@ def test_run_is_bit_reproducible_and_topology_is_consistent(system):
         assert sorted(sp[i, :ns[i, 0]]) == sorted(int(ba[i, m]) for m in range(nb[i])), i + 1
     # fix counters: extrusion moves preserve the bond count; loads minus unloads = extruders present
     assert a.extract_fix("loading", 0, 1, 1) - a.extract_fix("unloading", 0, 1, 1) == len(ext)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the other two full-size configurations of BASELINE.json: 10 chains x 100k with barrier types (configs[2]) and the
+# 8M-bead system = the per-GPU size of the 8 x 1M weak-scaling run (configs[4]: dense load, prob 0.01, N1 = 1000)
+def _topology_invariants(lmp, n, nchains):
+    """Vectorised: storage symmetry, backbone intact inside every chain and absent across chain ends, one extruder
+    anchor per bead at most, 1-2 special block = bond partners, bond counter = backbone + extruders."""
+    nb, bt, ba = lmp.gather("num_bond"), lmp.gather("bond_type"), lmp.gather("bond_atom")
+    ns, sp = lmp.gather("nspecial"), lmp.gather("special")
+    w = bt.shape[1]
+    own = np.repeat(np.arange(1, n + 1, dtype=np.int64)[:, None], w, axis=1)
+    live = np.arange(w)[None, :] < nb[:, None]
+    t, i, j = bt[live].astype(np.int64), own[live], ba[live].astype(np.int64)
+    key = (t * (n + 1) + i) * (n + 1) + j
+    rkey = (t * (n + 1) + j) * (n + 1) + i
+    assert np.array_equal(np.sort(key), np.sort(rkey))                 # every bond stored by both ends, same type
+    per = n // nchains
+    a = np.arange(1, n, dtype=np.int64)                                # bond (a, a+1) exists iff a is not a chain's last bead
+    inside = (a % per != 0) | (a // per >= nchains)
+    have = np.isin((1 * (n + 1) + a) * (n + 1) + a + 1, key)
+    assert np.array_equal(have, inside)
+    e = t == 2
+    ends = np.concatenate([i[e & (i < j)], j[e & (i < j)]])
+    assert len(ends) == len(np.unique(ends))
+    next_ = int(e.sum()) // 2
+    assert int(lmp.get_thermo("bonds")) == int(inside.sum()) + next_
+    # 1-2 block of a sample of beads (every 997th and every anchor) = its bond partners
+    sample = np.unique(np.concatenate([np.arange(0, n, 997), ends - 1]))
+    for k in sample[:20000]:
+        assert sorted(sp[k, :ns[k, 0]]) == sorted(int(ba[k, m]) for m in range(nb[k])), k + 1
+    return next_
+
+
+def _full_size_case(tmp_path_factory, name, n, nchains, steps):
+    from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
+    sysd = lattice_chains(n, nchains=nchains, seed=1, barrier_every=200)
+    data = str(tmp_path_factory.mktemp(name) / ("data." + name))
+    write_data(data, sysd)
+    script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01, punload=0.01)
+    a, b = _open(script), _open(script)
+    a.command("run %d" % steps)
+    b.command("run %d" % steps)
+    for nm in ("x", "v", "image", "num_bond", "bond_type", "bond_atom", "nspecial"):
+        assert np.array_equal(a.gather(nm), b.gather(nm)), nm           # bit-reproducible
+    b.close()
+    x = a.gather("x")
+    assert np.isfinite(x).all()
+    assert abs(a.get_thermo("temp") - 1.0) < 0.05                       # the thermostat holds T* = 1
+    next_ = _topology_invariants(a, n, nchains)
+    assert a.extract_fix("loading", 0, 1, 1) - a.extract_fix("unloading", 0, 1, 1) == next_
+    assert a.stat("fene_warnings") == 0
+    return a, next_
+
+
+def test_chains10x100k_full_size(tmp_path_factory):
+    """BASELINE configs[2]: 1M beads in 10 chains with left / right / roadblock barrier beads, through the first firing
+    of every LE fix twice over (2004 steps)."""
+    a, next_ = _full_size_case(tmp_path_factory, "chains10x100k", 1000000, 10, 2004)
+    assert next_ > 20
+
+
+def test_chain8m_full_size(tmp_path_factory):
+    """BASELINE configs[4] at its per-GPU size: 8M beads, dense load (prob 0.01, N1 = 1000), one firing of every fix."""
+    a, next_ = _full_size_case(tmp_path_factory, "chain8m", 8000000, 1, 1004)
+    assert next_ > 100
+    assert a.stat("neigh_builds") > 50
