@@ -121,6 +121,7 @@ void dev_free(DeviceState &d) {
   for (int k = 0; k < 16; k++) dfree(d.le_i[k]);
   for (int k = 0; k < 2; k++) dfree(d.le_d[k]);
   dfree(d.le_bits); dfree(d.le_rng_state); dfree(d.le_draws); dfree(d.le_list); dfree(d.le_scan);
+  sort_scratch_free(d);
   if (d.stream) (void)hipStreamDestroy(d.stream);
   d.stream = nullptr;
 }

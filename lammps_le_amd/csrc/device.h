@@ -158,6 +158,7 @@ struct DeviceState {
   double4 *xht = nullptr;                               // [maxtag+2] xhold by tag (LE fixes)
   double *gather_send = nullptr, *gather_recv = nullptr;      // whole-system gathers
   size_t gather_cap = 0;
+  void *sort_scratch = nullptr;   // kernels_sort.hip: key / value / temp buffers of the Atom::sort emulation
   Comm *comm_watch = nullptr;     // decomposed runs: host waits on the stream go through Comm::wait_stream (time-out + abort)
   // ---- kernel timing (HIP events on the launch stream) ----
   std::vector<hipEvent_t> ev0, ev1;
@@ -186,6 +187,10 @@ void reduce_partials(DeviceState &d, double *out16);
 void launch_reneighbor(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
 void launch_sort_owned(DeviceState &d, int m_in = -1, int n_out = -1, const int *gone = nullptr);
 void launch_lists(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
+
+// Atom::sort emulation (kernels_sort.hip): crank[tag] := rank in the reference's sorted local order
+void launch_atom_sort(DeviceState &d, const int nb[3], const double binv[3]);
+void sort_scratch_free(DeviceState &d);
 
 // rng (kernels_rng.hip)
 void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms);

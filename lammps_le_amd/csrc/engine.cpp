@@ -348,6 +348,12 @@ void Engine::download() {
     }
   }
   for (int i = 0; i < n; i++) type[i] = ty[i + 1];
+  if (crank_on_device) {
+    std::vector<int> cr(nt);
+    HIP_CHECK(hipMemcpy(cr.data(), d.crank, nt * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) crank[i] = cr[i + 1];
+    crank_on_device = false;
+  }
   std::copy(nb.begin() + 1, nb.begin() + 1 + n, num_bond.begin());
   std::copy(bt.begin() + bpa, bt.begin() + bpa + (size_t)n * bpa, bond_type.begin());
   std::copy(ba.begin() + bpa, ba.begin() + bpa + (size_t)n * bpa, bond_atom.begin());
@@ -463,8 +469,6 @@ void Engine::emulate_atom_sort() {
   nextsort = (ntimestep / sortfreq) * sortfreq + sortfreq;
   double binsize = 0.5 * cutneighmax;
   if (binsize == 0.0) return;
-  host_current = false;
-  download();
   double bininv = 1.0 / binsize;
   int nb[3]; double binv[3];
   for (int d = 0; d < 3; d++) {
@@ -473,23 +477,10 @@ void Engine::emulate_atom_sort() {
     binv[d] = nb[d] / (box.hi[d] - box.lo[d]);
   }
   if ((long)nb[0] * nb[1] * nb[2] == 1) return;
-  std::vector<std::pair<long long, int>> key(natoms);   // (bin, old canonical index) -> tag-1
-  std::vector<int> bytag(natoms);
-  for (int i = 0; i < natoms; i++) {
-    int c[3];
-    for (int d = 0; d < 3; d++) {
-      c[d] = (int)((x[3 * i + d] - box.lo[d]) * binv[d]);
-      c[d] = std::min(std::max(c[d], 0), nb[d] - 1);
-    }
-    long long ibin = ((long long)c[2] * nb[1] + c[1]) * nb[0] + c[0];
-    key[i] = {ibin * (long long)natoms + crank[i], i};
-  }
-  std::sort(key.begin(), key.end());
-  for (int r = 0; r < natoms; r++) crank[key[r].second] = r;
-  std::vector<int> cr((size_t)natoms + 2, 0);
-  for (int i = 0; i < natoms; i++) cr[i + 1] = crank[i];
-  HIP_CHECK(hipMemcpyAsync(dev->crank, cr.data(), cr.size() * sizeof(int), hipMemcpyHostToDevice, dev->stream));
-  HIP_CHECK(hipStreamSynchronize(dev->stream));
+  // on the device (kernels_sort.hip): keys (bin, previous rank), radix sort, crank[tag] = new rank.  The host copy of
+  // `crank` is refreshed by download().
+  launch_atom_sort(*dev, nb, binv);
+  crank_on_device = true;
 }
 
 // ---------------------------------------------------------------------------------------------

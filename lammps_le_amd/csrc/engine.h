@@ -208,6 +208,7 @@ class Engine {
   std::vector<int> num_bond, bond_type, bond_atom; // [natoms], [natoms*bpa]
   std::vector<int> nspecial, special;              // [natoms*3], [natoms*maxspecial]
   std::vector<int> crank;                          // canonical (reference local) index of tag t-1
+  bool crank_on_device = false;                    // the device's crank[] is newer than this copy (Atom::sort emulation)
   bool special_built = false;
   bool host_current = true;    // host x/v/f/type/topology reflect the device state
   bool dev_current = false;    // device state reflects the host copies
