@@ -43,6 +43,61 @@ def lattice_chains(nbeads, nchains=1, density=0.85, seed=1, jitter=0.03, temp=1.
                 atom_style="bond")
 
 
+def _finish(x, n, nchains, barrier_every, box_edge, rng, temp):
+    v = rng.normal(0.0, np.sqrt(temp), size=(n, 3))
+    v -= v.mean(axis=0)
+    per = n // nchains
+    first = np.arange(n - 1)
+    keep = np.ones(n - 1, dtype=bool)
+    for c in range(1, nchains):
+        keep[c * per - 1] = False          # no bond across a chain boundary
+    a1 = first[keep] + 1
+    bonds = np.stack([np.ones_like(a1), a1, a1 + 1], axis=1).astype(np.int32)
+    typ = np.ones(n, dtype=np.int32)
+    ntypes = 1
+    k = np.arange(n)
+    if barrier_every > 0:
+        idx = np.arange(barrier_every, n - barrier_every, barrier_every)
+        typ[idx] = 2 + (np.arange(len(idx)) % 3)
+        ntypes = 4
+        ends = np.concatenate([[0], np.arange(1, nchains) * per - 1, np.arange(1, nchains) * per, [n - 1]])
+        typ[ends] = 1
+    mol = (np.minimum(k // per, nchains - 1) + 1).astype(np.int32)
+    return dict(box=np.array([[0.0, box_edge]] * 3), x=x, v=v, type=typ, mol=mol, image=np.zeros((n, 3), dtype=np.int32),
+                bonds=bonds, ntypes=ntypes, nbondtypes=2, mass=[1.0] * ntypes, extra_bond=1, extra_special=20,
+                atom_style="bond")
+
+
+def scrambled_chains(nbeads, nchains=1, density=0.85, seed=1, jitter=0.03, temp=1.0, barrier_every=0, block=10, sweeps=6):
+    """Overlap-free start whose chain order is NOT its memory order: a space-filling walk over the simple-cubic lattice
+    that is a random Hamiltonian path (backbite moves) inside every block of `block`^3 sites, blocks visited in
+    serpentine order (csrc/tools.cpp).  Same density, bond length and barrier typing as lattice_chains; locally the
+    walk turns at 77 % of its sites (the serpentine start: 1 %), so a cell's beads carry unrelated tags the way a melt's do.
+    The reference's own generator (tools/chain.f: phantom random walks) needs a soft push-off this engine has no style for."""
+    import ctypes as C
+    import os
+    rng = np.random.RandomState(seed)
+    n = int(nbeads)
+    a = (1.0 / density) ** (1.0 / 3.0)
+    L0 = int(np.ceil(n ** (1.0 / 3.0)))
+    # smallest lattice edge that is a multiple of an even block edge near the requested one
+    best = None
+    for b in (block, block - 2, block + 2, block - 4):
+        if b >= 4 and b % 2 == 0:
+            L = ((L0 + b - 1) // b) * b
+            if best is None or L < best[0]:
+                best = (L, b)
+    L, b = best
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblammps_le.so"))
+    xyz = np.zeros((L ** 3, 3), dtype=np.int32)
+    rc = lib.lammps_le_tool_scrambled_path(L, b, int(seed), int(sweeps), xyz.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("scrambled path generator failed (%d)" % rc)
+    x = (xyz[:n].astype(np.float64) + 0.5) * a
+    x += rng.uniform(-jitter, jitter, size=(n, 3))
+    return _finish(x, n, nchains, barrier_every, L * a, rng, temp)
+
+
 def write_data(path, s):
     """LAMMPS data file (atom_style bond) with %.17g coordinates; pandas C writer for speed."""
     import pandas as pd
