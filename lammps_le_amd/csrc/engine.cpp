@@ -465,6 +465,11 @@ bool Engine::decide() {
 
 // keep `crank` equal to the reference's local atom order: Atom::sort (src/atom.cpp:2003-2094) with
 // bins of 1/2 cutneighmax over the box (setup_sort_bins :2100-2208), stable within a bin
+bool Engine::local_order_is_tag_order() const {
+  if (sortfreq > 0 || crank_on_device) return false;
+  for (int i = 0; i < natoms; i++) if (crank[i] != i) return false;
+  return true;
+}
 void Engine::emulate_atom_sort() {
   nextsort = (ntimestep / sortfreq) * sortfreq + sortfreq;
   double binsize = 0.5 * cutneighmax;
@@ -567,7 +572,7 @@ static void langevin_draws(Engine *e, FixLangevin *lg) {
 static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
   langevin_draws(e, lg);
   TypeTables tt = make_tables(e, lg);
-  launch_langevin(*e->dev, tt, e->sortfreq == 0, fuse_final);
+  launch_langevin(*e->dev, tt, e->dev->ident_order, fuse_final);
   rng_langevin_consumed(*e->dev);
 }
 
@@ -680,7 +685,7 @@ void Engine::iterate(long nsteps) {
   int nnve = count_nve(this);
   double triggersq = 0.25 * skin * skin;
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
-  bool ident = (sortfreq == 0);
+  bool ident = d.ident_order;
   bool pre_integrated = false;
   // halo/compute overlap issues the per-step halo on a second stream.  With RCCL that means two streams feeding ONE
   // communicator (ordered by events, but never run on multi-GPU hardware): kept to the test transports unless
@@ -814,6 +819,7 @@ void Engine::run(long nsteps) {
   double tr1 = wall();
   if (!dev_current || !dev || !dev->pos) upload();
   for (int k = 1; k <= 3; k++) dev->sflag[k] = special_flag(k);
+  dev->ident_order = local_order_is_tag_order();
   double tr2 = wall();
   le_reneigh_step.assign(fixes.size(), -1);
   dev->le_snapshot = 0;

@@ -208,6 +208,9 @@ class Engine {
   std::vector<int> num_bond, bond_type, bond_atom; // [natoms], [natoms*bpa]
   std::vector<int> nspecial, special;              // [natoms*3], [natoms*maxspecial]
   std::vector<int> crank;                          // canonical (reference local) index of tag t-1
+  // the reference's local index of a bead is its ID - 1: true while no Atom::sort ran and the data file listed the atoms
+  // in ID order.  Then the order-sensitive kernels index by tag directly instead of through crank[].
+  bool local_order_is_tag_order() const;
   bool crank_on_device = false;                    // the device's crank[] is newer than this copy (Atom::sort emulation)
   bool special_built = false;
   bool host_current = true;    // host x/v/f/type/topology reflect the device state

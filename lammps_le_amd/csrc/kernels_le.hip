@@ -95,6 +95,30 @@ void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_fl
   hipLaunchKernelGGL(k_lscan_add, dim3(sb), dim3(SCAN_BLOCK), 0, d.stream, m, out, tmp, d.flags + total_flag);
 }
 
+// exclusive prefix count of flag[t] over the beads in the reference's LOCAL order (crank[t], 0-based): out[t] = number of
+// flagged beads with a smaller local index.  That is the order in which the LE fixes hand out RNG draws
+// (`for (i = 0; i < nlocal; i++) if (partner[i]) probability[i] = random->uniform()`, fix_ex_load.cpp:517-520) and in which
+// NTopoBondAll lists bonds.  With local index = ID - 1 (no Atom::sort, data file in ID order) it is the plain scan by tag.
+__global__ __launch_bounds__(BLOCK) void k_by_rank_scatter(int T, const int *__restrict__ crank, const int *__restrict__ flag,
+                                                           int *__restrict__ byrank) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t == 0 || t == T + 1) { if (t == 0) byrank[T] = byrank[T + 1] = 0; return; }
+  if (t <= T) byrank[crank[t]] = flag[t];
+}
+__global__ __launch_bounds__(BLOCK) void k_by_rank_gather(int T, const int *__restrict__ crank, const int *__restrict__ scanned,
+                                                          int *__restrict__ out) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > T + 1) return;
+  out[t] = (t >= 1 && t <= T) ? scanned[crank[t]] : 0;
+}
+static void scan_local_order(DeviceState &d, const int *flag, int *out, int total_flag, int *tmp_a, int *tmp_b) {
+  const int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
+  if (d.ident_order) { scan_exclusive(d, flag, out, nt, total_flag); return; }
+  hipLaunchKernelGGL(k_by_rank_scatter, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.crank, flag, tmp_a);
+  scan_exclusive(d, tmp_a, tmp_b, nt, total_flag);
+  hipLaunchKernelGGL(k_by_rank_gather, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.crank, tmp_b, out);
+}
+
 // ------------------------------------------------------------------------------------------
 // special-list / bond-table edits on one bead (device versions of the reference's in-place code)
 __device__ __forceinline__ void dev_delete_bond(const Topo &tp, int i, int partner) {   // fix_extrusion.cpp:656-668
@@ -260,6 +284,7 @@ void launch_topo_snapshot(DeviceState &d) {
 struct PairListView {
   int n_owned, npad;
   const int *map, *neigh, *numneigh;
+  const int *crank;      // nullptr: local index = ID - 1
 };
 template <int LISTSRC>
 __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, const double4 *__restrict__ xt,
@@ -277,10 +302,14 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
     } else if (itype == P.jatomtype && jtype == P.iatomtype) {
       if ((P.jmaxbond == 0 || bc[i] < P.jmaxbond) && (P.imaxbond == 0 || bc[j] < P.imaxbond)) possible = true;
     }
+    // the pair is stored under the end with the lower LOCAL index (npair_half_bin_newtoff.cpp:90); its special list
+    // and its neighbor list are the ones consulted (fix_ex_load.cpp:486-488)
+    const bool swap = V.crank && V.crank[j] < V.crank[i];
+    const int is = swap ? j : i, js = swap ? i : j;
     if (possible && tp.num_bond[i] == 2 && tp.num_bond[j] == 2 && tp.num_bond[mid] == 2) {
-      const int *sl = tp.special + (size_t)i * tp.ms;
-      int n1 = tp.nspecial[3 * (size_t)i];
-      for (int k = 0; k < n1; k++) if (sl[k] == j) possible = false;
+      const int *sl = tp.special + (size_t)is * tp.ms;
+      int n1 = tp.nspecial[3 * (size_t)is];
+      for (int k = 0; k < n1; k++) if (sl[k] == js) possible = false;
       if (possible) {
         double rsq = d2(xt[i], xt[j]);   // stored coordinates, no minimum image (ghost entries are skipped)
         rsq_out[a] = rsq;
@@ -289,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
     }
     if (base) {                          // few pairs get here: walk bead a's list for a+2
       base = false;
-      const int p = V.map[i], q = V.map[j];
+      const int p = V.map[is], q = V.map[js];
       if (p >= 0 && p < V.n_owned && q >= 0) {
         const int nn = V.numneigh[p];
         for (int k = 0; k < nn; k++)
@@ -305,6 +334,38 @@ __global__ __launch_bounds__(BLOCK) void k_exload_bits(int nt, const int *__rest
                                                        unsigned long long *__restrict__ bits) {
   int a = blockIdx.x * BLOCK + threadIdx.x;
   unsigned long long m = __ballot(a < nt && base_i[a] != 0);
+  if ((threadIdx.x & 63) == 0) bits[a >> 6] = m;
+}
+// Acceptance with a general visit order (local index != ID - 1, i.e. after an Atom::sort).  The scan visits pair a when it
+// reaches the storing atom, local index key(a) = min(crank[a], crank[a+2]); pair a is skipped if partner[a+1] was already
+// set, i.e. if pair a-1 or pair a+1 was ACCEPTED earlier in the scan.  That is the greedy maximal independent set of the
+// path graph of the base pairs in key order; it is resolved in rounds: an undecided pair whose undecided neighbours all
+// have larger keys is accepted, a pair next to an accepted one is rejected.  No round without progress can leave an
+// undecided pair (keys are distinct), so the loop ends; chains of dependent pairs are as short as runs of base pairs.
+// st: 0 undecided, 1 accepted, 2 rejected / not a base pair.
+__global__ __launch_bounds__(BLOCK) void k_exload_greedy_init(int nt, const int *__restrict__ base_i, int *__restrict__ st) {
+  int a = blockIdx.x * BLOCK + threadIdx.x;
+  if (a < nt) st[a] = base_i[a] ? 0 : 2;
+}
+__global__ __launch_bounds__(BLOCK) void k_exload_greedy_round(int T, const int *__restrict__ crank, int *__restrict__ st,
+                                                               int *__restrict__ changed) {
+  int a = blockIdx.x * BLOCK + threadIdx.x;
+  if (a < 1 || a + 2 > T || st[a] != 0) return;
+  const int ka = min(crank[a], crank[a + 2]);
+  bool blocked = false, wait = false;
+  for (int b = a - 1; b <= a + 1; b += 2) {
+    if (b < 1 || b + 2 > T) continue;
+    const int sb = st[b];
+    if (sb == 1) blocked = true;
+    else if (sb == 0 && min(crank[b], crank[b + 2]) < ka) wait = true;
+  }
+  if (blocked) { st[a] = 2; *changed = 1; }
+  else if (!wait) { st[a] = 1; *changed = 1; }
+}
+__global__ __launch_bounds__(BLOCK) void k_exload_accept_bits(int nt, const int *__restrict__ st,
+                                                              unsigned long long *__restrict__ bits) {
+  int a = blockIdx.x * BLOCK + threadIdx.x;
+  unsigned long long m = __ballot(a < nt && st[a] == 1);
   if ((threadIdx.x & 63) == 0) bits[a >> 6] = m;
 }
 __device__ __forceinline__ bool bit_at(const unsigned long long *bits, int a) { return (bits[a >> 6] >> (a & 63)) & 1ull; }
@@ -324,17 +385,23 @@ __device__ __forceinline__ bool accepted_at(const unsigned long long *__restrict
   }
   return (run & 1) == 0;
 }
+// DIRECT: `bits` already holds the accepted pairs (general visit order); else it holds base(a) and acceptance is the
+// parity rule of the ID-order scan.  crank (DIRECT only) orders the two pairs a bead belongs to: the one visited first
+// keeps the bead on an exact distance tie (strict `<` in fix_ex_load.cpp:496-503).
+template <bool DIRECT>
 __global__ __launch_bounds__(BLOCK) void k_exload_partner(int T, const unsigned long long *__restrict__ bits,
-                                                          const double *__restrict__ rsq, int *__restrict__ partner,
-                                                          int *__restrict__ haspartner) {
+                                                          const double *__restrict__ rsq, const int *__restrict__ crank,
+                                                          int *__restrict__ partner, int *__restrict__ haspartner) {
   int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > T + 1) return;
   int p = 0;
   if (t >= 1 && t <= T) {
-    bool lo = (t >= 3) && accepted_at(bits, t - 2);   // pair (t-2, t), visited first
-    bool hi = (t + 2 <= T) && accepted_at(bits, t);   // pair (t, t+2)
+    bool lo = (t >= 3) && (DIRECT ? bit_at(bits, t - 2) : accepted_at(bits, t - 2));   // pair (t-2, t)
+    bool hi = (t + 2 <= T) && (DIRECT ? bit_at(bits, t) : accepted_at(bits, t));       // pair (t, t+2)
+    bool lo_first = true;                                                              // ID order: pair t-2 comes first
+    if (DIRECT && lo && hi) lo_first = min(crank[t - 2], crank[t]) < min(crank[t], crank[t + 2]);
     if (lo) p = t - 2;
-    if (hi && (!lo || rsq[t] < rsq[t - 2])) p = t + 2;
+    if (hi && (!lo || (lo_first ? rsq[t] < rsq[t - 2] : !(rsq[t - 2] < rsq[t])))) p = t + 2;
   }
   partner[t] = p;
   haspartner[t] = p != 0;
@@ -388,18 +455,34 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
   hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 0, d.flags);
   int nbw = ((nt + 63) / 64 * 64 + BLOCK - 1) / BLOCK;
   if (!d.neigh || !d.numneigh) throw LammpsError("fix ex_load needs a pair neighbor list");
-  PairListView V{d.n, d.npad, d.map, d.neigh, d.numneigh};
+  PairListView V{d.n, d.npad, d.map, d.neigh, d.numneigh, d.ident_order ? nullptr : d.crank};
+  int *tmp_a = d.le_i[I_F], *tmp_b = d.le_i[I_G];
   if (d.dd) {
     int *base_i = d.le_i[I_E];
     hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
     comm->allreduce_int_max(st, base_i, nt);       // the owner of bead a knows whether (a, a+2) is in its list
     hipLaunchKernelGGL(k_exload_bits, dim3(nbw), dim3(BLOCK), 0, st, nt, base_i, d.le_bits);
-  } else {
+    hipLaunchKernelGGL((k_exload_partner<false>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
+  } else if (d.ident_order) {
     hipLaunchKernelGGL((k_exload_base<0>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], (int *)nullptr);
+    hipLaunchKernelGGL((k_exload_partner<false>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
+  } else {
+    // local order != ID order (Atom::sort ran): greedy acceptance in visit order, resolved in rounds
+    int *base_i = d.le_i[I_E], *state = tmp_a;
+    hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
+    hipLaunchKernelGGL(k_exload_greedy_init, dim3(nb), dim3(BLOCK), 0, st, nt, base_i, state);
+    for (int batch = 0; batch < 4096; batch++) {
+      HIP_CHECK(hipMemsetAsync(d.flags + FLAG_AUX, 0, sizeof(int), st));
+      for (int r = 0; r < 8; r++)
+        hipLaunchKernelGGL(k_exload_greedy_round, dim3(nb), dim3(BLOCK), 0, st, T, d.crank, state, d.flags + FLAG_AUX);
+      sync_flags(d);
+      if (!d.flags_h[FLAG_AUX]) break;
+    }
+    hipLaunchKernelGGL(k_exload_accept_bits, dim3(nbw), dim3(BLOCK), 0, st, nt, state, d.le_bits);
+    hipLaunchKernelGGL((k_exload_partner<true>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
   }
-  hipLaunchKernelGGL(k_exload_partner, dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], partner, has);
   if (P.fraction < 1.0) {
-    scan_ex(d, has, didx, nt, FLAG_NDRAW);
+    scan_local_order(d, has, didx, FLAG_NDRAW, tmp_a, tmp_b);
     launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
   }
   hipLaunchKernelGGL(k_exload_create, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, bc, fin, d.pos,
@@ -482,7 +565,7 @@ void launch_bond_create(DeviceState &d, const ExLoadParams &P, int slot, const i
     hipLaunchKernelGGL(k_nonzero, dim3(nb), dim3(BLOCK), 0, st, nt, partner, has);
   }
   if (P.fraction < 1.0) {
-    scan_ex(d, has, didx, nt, FLAG_NDRAW);
+    scan_local_order(d, has, didx, FLAG_NDRAW, d.le_i[I_F], d.le_i[I_G]);
     launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
   }
   hipLaunchKernelGGL(k_exload_create, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, bc, fin, d.pos,
@@ -560,7 +643,7 @@ void launch_ex_unload(DeviceState &d, const ExUnloadParams &P, int slot) {
   hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 0, d.flags);
   hipLaunchKernelGGL(k_exunload_partner, dim3(nb), dim3(BLOCK), 0, st, tp, P, d.box, d.xt, d.xht, partner, has);
   if (P.fraction < 1.0) {
-    scan_ex(d, has, didx, nt, FLAG_NDRAW);
+    scan_local_order(d, has, didx, FLAG_NDRAW, d.le_i[I_F], d.le_i[I_G]);
     launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
   }
   hipLaunchKernelGGL(k_exunload_break, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, fin, d.flags);
@@ -574,7 +657,8 @@ enum { CASE_NONE = 0, CASE_BOTH = 1, CASE_LEFT = 2, CASE_RIGHT = 3 };
 // which beads head a bond-list entry of type btype (ntopo_bond_all.cpp:52-73 with newton_bond off):
 // from t if t < partner (local index = ID-1), or from both ends if the bond straddled a face at the last build
 __global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box box, const double4 *__restrict__ xht,
-                                                        int *__restrict__ lflag, int *__restrict__ lpart) {
+                                                        const int *__restrict__ crank, int *__restrict__ lflag,
+                                                        int *__restrict__ lpart) {
   int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > tp.T + 1) return;
   int fl = 0, u = 0;
@@ -586,7 +670,9 @@ __global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box 
       double4 hi = xht[t], hj = xht[u];
       double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
       bool straddle = fabs(h0) > box.half[0] || fabs(h1) > box.half[1] || fabs(h2) > box.half[2];
-      fl = (straddle || t < u) ? 1 : 0;
+      // listed from the end with the lower LOCAL index (`newton_bond || i < atom1`, ntopo_bond_all.cpp:66); crank == nullptr: ID order
+      const bool first = crank ? crank[t] < crank[u] : t < u;
+      fl = (straddle || first) ? 1 : 0;
     }
   }
   lflag[t] = fl;
@@ -776,8 +862,9 @@ void launch_extrusion(DeviceState &d, const ExtrusionParams &P, int slot) {
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));
   for (int *a : {ndraw, ev_cnt, to_add, tr0, fin_rm, fin_add}) HIP_CHECK(hipMemsetAsync(a, 0, (size_t)nt * sizeof(int), st));
   hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 1, d.flags);
-  hipLaunchKernelGGL(k_ext_listflag, dim3(nb), dim3(BLOCK), 0, st, tp, P.btype, d.box, d.xht, lflag, lpart);
-  scan_ex(d, lflag, lidx, nt, FLAG_NLIST);
+  hipLaunchKernelGGL(k_ext_listflag, dim3(nb), dim3(BLOCK), 0, st, tp, P.btype, d.box, d.xht,
+                     d.ident_order ? (const int *)nullptr : d.crank, lflag, lpart);
+  scan_local_order(d, lflag, lidx, FLAG_NLIST, tr1, kcase);       // listing index = position in the bond list (tr1 / kcase: free until later)
   hipLaunchKernelGGL(k_ext_prepare, dim3(nb), dim3(BLOCK), 0, st, tp, P, lflag, lidx, lpart, bc, list_l, list_r, list_f,
                      ndraw);
   scan_ex(d, ndraw, doff, nt, FLAG_NDRAW);    // ndraw is zero beyond the number of listings

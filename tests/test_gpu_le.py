@@ -239,3 +239,32 @@ run 24
     compare(p, o, ("loading",))
     loaded = o.fix_vector("loading")[1]
     assert (loaded > 0) == expect_loads, loaded
+
+
+@pytest.mark.parametrize("sortfreq,tp", [(1000, 0.5), (7, 0.5), (3, 0.0), (5, 1.0)])
+def test_le_cycle_under_atom_sort(tmp_path, sortfreq, tp):
+    """with the reference's default `atom_modify sort N` the local index is no longer ID - 1, and everything
+    order-dependent in the LE fixes follows the SORTED order: which end lists an extruder bond and in which order the
+    listings are visited (barrier draws, closest-wins ties), the greedy `partner[mid]` rule of the ex_load scan, which
+    bead gets which draw.  The oracle permutes its arrays like Atom::sort does and loops over local indices; the engine
+    keeps the arrays and carries the local index (crank) instead.  Topology must still be bit-exact."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 11))
+    script = le_script(tp=tp, n1=4, nl=5, nu=6).replace("atom_modify sort 0 0", "atom_modify sort %d 0" % sortfreq) + "run 64\n"
+    o = run_oracle(script, s)
+    assert (o.local_order() != np.arange(1, n + 1)).any()          # the oracle really is in a sorted order
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    assert len([b for b in o.bond_set() if b[0] == 2]) > 5
+
+
+def test_data_file_order_is_the_local_order(tmp_path):
+    """Without Atom::sort the reference's local order is the order of the data file's Atoms section (1 rank), not the ID
+    order: a shuffled file must give every bead the draws of ITS file position."""
+    n = 2000
+    s = melted(n)
+    s["file_order"] = np.random.RandomState(5).permutation(n)
+    script = le_script(left=1, right=1, lr="") + "run 40\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
