@@ -88,6 +88,9 @@ struct DeviceState {
   int *numneigh = nullptr;   // [npad]
   int *bpart = nullptr;      // [bpa][npad] (type << 26) | partner p ; -1 = none
   double *pairtab = nullptr; // 6 * nt*nt : cutsq lj1 lj2 lj3 lj4 offset
+  int newton_pair = 0;           // `newton on [off]`: which end stores a pair in the reference's half list (ex_load's visit order)
+  int ref_nbin[3] = {1, 1, 1};   // the reference's neighbor bins (cutneighmax / 2 fitted to the box, nbin_standard.cpp:53-186)
+  double ref_bininv[3] = {1, 1, 1};
   bool ident_order = true;       // the reference's local index of a bead = its ID - 1 (no Atom::sort, data file in ID order)
   int sflag[4] = {1, 1, 1, 1};   // Engine::special_flag per level: 0 dropped from the list, 1 ordinary entry, 2 entry with level bits
   int pair_uniform = 0;      // every type pair has the same coefficients

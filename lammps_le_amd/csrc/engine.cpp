@@ -820,6 +820,14 @@ void Engine::run(long nsteps) {
   if (!dev_current || !dev || !dev->pos) upload();
   for (int k = 1; k <= 3; k++) dev->sflag[k] = special_flag(k);
   dev->ident_order = local_order_is_tag_order();
+  dev->newton_pair = newton_pair ? 1 : 0;
+  for (int k = 0; k < 3; k++) {
+    const double binsize_optimal = cutneighmax > 0.0 ? 0.5 * cutneighmax : box.prd[0];
+    int nb = (int)(box.prd[k] * (1.0 / binsize_optimal));
+    if (nb == 0) nb = 1;
+    dev->ref_nbin[k] = nb;
+    dev->ref_bininv[k] = 1.0 / (box.prd[k] / nb);
+  }
   double tr2 = wall();
   le_reneigh_step.assign(fixes.size(), -1);
   dev->le_snapshot = 0;

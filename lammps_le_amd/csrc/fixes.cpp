@@ -14,6 +14,15 @@ static void need_all(const std::vector<std::string> &arg) {
   if (arg[1] != "all") throw LammpsError("MI355X engine: fix group must be 'all' (got " + arg[1] + ")");
 }
 
+// The LE fixes count on every bond being stored with BOTH of its atoms (`num_bond == 2` for a free backbone bead,
+// fix_ex_load.cpp:481-483; bondcount per owned end, fix_extrusion.cpp:281-295).  With newton_bond on the reference stores a
+// bond once, those tests never pass and nothing is ever loaded; this engine always stores both copies, so it would NOT
+// reproduce that run: refuse instead of silently differing.
+static void need_newton_bond_off(Engine *e, const std::string &style) {
+  if (e->newton_bond)
+    throw LammpsError("fix " + style + " needs newton_bond off (`newton off` or `newton on off`): with newton_bond on the "
+                      "reference stores each bond on one atom only and the fix's bond counts never match");
+}
 // fix ID group nve  (src/fix_nve.cpp:33-45)
 FixNVE::FixNVE(Engine *e, const std::vector<std::string> &arg) {
   eng = e; id = arg[0]; group = arg[1]; style = arg[2];
@@ -62,6 +71,7 @@ FixExtrusion::FixExtrusion(Engine *e, const std::vector<std::string> &arg) {
   if (e->atom_style == "atomic") throw LammpsError("Cannot use fix extrusion with non-molecular systems");
   if (ctcf_lr == ctcf_left || ctcf_lr == ctcf_right)
     throw LammpsError("MI355X engine: bidirectional CTCF type must differ from the left/right CTCF types");
+  need_newton_bond_off(e, style);
   rng.seed(12345);   // hard-coded 12345 + me (:98-99)
   e->say("Attention! maxspecial = " + std::to_string(e->maxspecial) + "\n");
   force_reneighbor = true;
@@ -116,6 +126,7 @@ FixExLoad::FixExLoad(Engine *e, const std::vector<std::string> &arg) {
     } else throw LammpsError(ill);
   }
   if (e->atom_style == "atomic") throw LammpsError("Cannot use fix " + style + " with non-molecular systems");
+  need_newton_bond_off(e, style);
   if (iatomtype == jatomtype && (imaxbond != jmaxbond || inewtype != jnewtype))
     throw LammpsError("Inconsistent iparam/jparam values in fix " + style + " command");
   rng.seed(seed);
@@ -169,6 +180,7 @@ FixExUnload::FixExUnload(Engine *e, const std::vector<std::string> &arg) {
       iarg += 3;
     } else throw LammpsError(ill);
   }
+  need_newton_bond_off(e, style);
   rng.seed(seed);
   force_reneighbor = true;
   has_post_integrate = true;

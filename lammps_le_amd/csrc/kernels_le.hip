@@ -285,7 +285,34 @@ struct PairListView {
   int n_owned, npad;
   const int *map, *neigh, *numneigh;
   const int *crank;      // nullptr: local index = ID - 1
+  // newton_pair on (`newton on off`): the reference's half/bin/newton list stores an owned-owned pair under the atom whose
+  // neighbor bin comes first in (z, y, x) order, the lower local index inside one bin (npair_half_bin_newton.cpp:84-149,
+  // nstencil_half_bin_3d_newton.cpp); bins of cutneighmax / 2 fitted to the box (nbin_standard.cpp:53-186), positions =
+  // those of the last build (xht)
+  int newton;
+  double lo[3], bininv[3];
+  int nbin[3];
+  const double4 *xht;
 };
+__device__ __forceinline__ int local_index(const PairListView &V, int t) { return V.crank ? V.crank[t] : t - 1; }
+// true: bead i is the storing end of the pair (i, j)
+__device__ __forceinline__ bool stores_pair(const PairListView &V, int i, int j) {
+  if (V.newton) {
+    const double4 a = V.xht[i], b = V.xht[j];
+    const double pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z};
+#pragma unroll
+    for (int d = 2; d >= 0; d--) {
+      const int ba = min((int)((pa[d] - V.lo[d]) * V.bininv[d]), V.nbin[d] - 1);
+      const int bb = min((int)((pb[d] - V.lo[d]) * V.bininv[d]), V.nbin[d] - 1);
+      if (ba != bb) return ba < bb;
+    }
+  }
+  return local_index(V, i) < local_index(V, j);
+}
+// position of pair a = (a, a+2) in the scan: the local index of its storing end
+__device__ __forceinline__ int visit_key(const PairListView &V, int a) {
+  return stores_pair(V, a, a + 2) ? local_index(V, a) : local_index(V, a + 2);
+}
 template <int LISTSRC>
 __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, const double4 *__restrict__ xt,
                                                        const int *__restrict__ bc, PairListView V,
@@ -304,7 +331,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
     }
     // the pair is stored under the end with the lower LOCAL index (npair_half_bin_newtoff.cpp:90); its special list
     // and its neighbor list are the ones consulted (fix_ex_load.cpp:486-488)
-    const bool swap = V.crank && V.crank[j] < V.crank[i];
+    const bool swap = (V.crank || V.newton) && !stores_pair(V, i, j);
     const int is = swap ? j : i, js = swap ? i : j;
     if (possible && tp.num_bond[i] == 2 && tp.num_bond[j] == 2 && tp.num_bond[mid] == 2) {
       const int *sl = tp.special + (size_t)is * tp.ms;
@@ -347,17 +374,21 @@ __global__ __launch_bounds__(BLOCK) void k_exload_greedy_init(int nt, const int 
   int a = blockIdx.x * BLOCK + threadIdx.x;
   if (a < nt) st[a] = base_i[a] ? 0 : 2;
 }
-__global__ __launch_bounds__(BLOCK) void k_exload_greedy_round(int T, const int *__restrict__ crank, int *__restrict__ st,
+__global__ __launch_bounds__(BLOCK) void k_exload_keys(int T, PairListView V, int *__restrict__ key) {
+  int a = blockIdx.x * BLOCK + threadIdx.x;
+  if (a <= T + 1) key[a] = (a >= 1 && a + 2 <= T) ? visit_key(V, a) : 0;
+}
+__global__ __launch_bounds__(BLOCK) void k_exload_greedy_round(int T, const int *__restrict__ key, int *__restrict__ st,
                                                                int *__restrict__ changed) {
   int a = blockIdx.x * BLOCK + threadIdx.x;
   if (a < 1 || a + 2 > T || st[a] != 0) return;
-  const int ka = min(crank[a], crank[a + 2]);
+  const int ka = key[a];
   bool blocked = false, wait = false;
   for (int b = a - 1; b <= a + 1; b += 2) {
     if (b < 1 || b + 2 > T) continue;
     const int sb = st[b];
     if (sb == 1) blocked = true;
-    else if (sb == 0 && min(crank[b], crank[b + 2]) < ka) wait = true;
+    else if (sb == 0 && key[b] < ka) wait = true;
   }
   if (blocked) { st[a] = 2; *changed = 1; }
   else if (!wait) { st[a] = 1; *changed = 1; }
@@ -390,7 +421,7 @@ __device__ __forceinline__ bool accepted_at(const unsigned long long *__restrict
 // keeps the bead on an exact distance tie (strict `<` in fix_ex_load.cpp:496-503).
 template <bool DIRECT>
 __global__ __launch_bounds__(BLOCK) void k_exload_partner(int T, const unsigned long long *__restrict__ bits,
-                                                          const double *__restrict__ rsq, const int *__restrict__ crank,
+                                                          const double *__restrict__ rsq, const int *__restrict__ key,
                                                           int *__restrict__ partner, int *__restrict__ haspartner) {
   int t = blockIdx.x * BLOCK + threadIdx.x;
   if (t > T + 1) return;
@@ -399,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_partner(int T, const unsigned 
     bool lo = (t >= 3) && (DIRECT ? bit_at(bits, t - 2) : accepted_at(bits, t - 2));   // pair (t-2, t)
     bool hi = (t + 2 <= T) && (DIRECT ? bit_at(bits, t) : accepted_at(bits, t));       // pair (t, t+2)
     bool lo_first = true;                                                              // ID order: pair t-2 comes first
-    if (DIRECT && lo && hi) lo_first = min(crank[t - 2], crank[t]) < min(crank[t], crank[t + 2]);
+    if (DIRECT && lo && hi) lo_first = key[t - 2] < key[t];
     if (lo) p = t - 2;
     if (hi && (!lo || (lo_first ? rsq[t] < rsq[t - 2] : !(rsq[t - 2] < rsq[t])))) p = t + 2;
   }
@@ -455,7 +486,9 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
   hipLaunchKernelGGL(k_le_gather, dim3(nb), dim3(BLOCK), 0, st, tp, d.pos, d.xhold, d.map, d.dd ? 0 : 1, d.xt, d.xht, P.btype, bc, 0, d.flags);
   int nbw = ((nt + 63) / 64 * 64 + BLOCK - 1) / BLOCK;
   if (!d.neigh || !d.numneigh) throw LammpsError("fix ex_load needs a pair neighbor list");
-  PairListView V{d.n, d.npad, d.map, d.neigh, d.numneigh, d.ident_order ? nullptr : d.crank};
+  PairListView V{d.n, d.npad, d.map, d.neigh, d.numneigh, d.ident_order ? nullptr : d.crank, d.newton_pair,
+                 {d.box.lo[0], d.box.lo[1], d.box.lo[2]}, {d.ref_bininv[0], d.ref_bininv[1], d.ref_bininv[2]},
+                 {d.ref_nbin[0], d.ref_nbin[1], d.ref_nbin[2]}, d.xht};
   int *tmp_a = d.le_i[I_F], *tmp_b = d.le_i[I_G];
   if (d.dd) {
     int *base_i = d.le_i[I_E];
@@ -463,23 +496,25 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
     comm->allreduce_int_max(st, base_i, nt);       // the owner of bead a knows whether (a, a+2) is in its list
     hipLaunchKernelGGL(k_exload_bits, dim3(nbw), dim3(BLOCK), 0, st, nt, base_i, d.le_bits);
     hipLaunchKernelGGL((k_exload_partner<false>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
-  } else if (d.ident_order) {
+  } else if (d.ident_order && !d.newton_pair) {
     hipLaunchKernelGGL((k_exload_base<0>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], (int *)nullptr);
     hipLaunchKernelGGL((k_exload_partner<false>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
   } else {
-    // local order != ID order (Atom::sort ran): greedy acceptance in visit order, resolved in rounds
-    int *base_i = d.le_i[I_E], *state = tmp_a;
+    // visit order != ID order (Atom::sort ran, unordered data file, or newton_pair on): greedy acceptance in visit
+    // order, resolved in rounds
+    int *base_i = d.le_i[I_E], *state = tmp_a, *key = tmp_b;
+    hipLaunchKernelGGL(k_exload_keys, dim3(nb), dim3(BLOCK), 0, st, T, V, key);
     hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
     hipLaunchKernelGGL(k_exload_greedy_init, dim3(nb), dim3(BLOCK), 0, st, nt, base_i, state);
     for (int batch = 0; batch < 4096; batch++) {
       HIP_CHECK(hipMemsetAsync(d.flags + FLAG_AUX, 0, sizeof(int), st));
       for (int r = 0; r < 8; r++)
-        hipLaunchKernelGGL(k_exload_greedy_round, dim3(nb), dim3(BLOCK), 0, st, T, d.crank, state, d.flags + FLAG_AUX);
+        hipLaunchKernelGGL(k_exload_greedy_round, dim3(nb), dim3(BLOCK), 0, st, T, key, state, d.flags + FLAG_AUX);
       sync_flags(d);
       if (!d.flags_h[FLAG_AUX]) break;
     }
     hipLaunchKernelGGL(k_exload_accept_bits, dim3(nbw), dim3(BLOCK), 0, st, nt, state, d.le_bits);
-    hipLaunchKernelGGL((k_exload_partner<true>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
+    hipLaunchKernelGGL((k_exload_partner<true>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], key, partner, has);
   }
   if (P.fraction < 1.0) {
     scan_local_order(d, has, didx, FLAG_NDRAW, tmp_a, tmp_b);

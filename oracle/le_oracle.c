@@ -59,6 +59,7 @@ struct leo {
   int *bstyle; double *bp0, *bp1, *bp2, *bp3;
   /* neighbor */
   double skin, cutneighmax, triggersq; int every, delay, check, ago;
+  int newton_pair;        /* `newton on|off [bond]`: who stores an owned-owned pair (half/bin/newton vs newtoff); bonds are always newton off */
   long nbuilds, ndanger;
   int brute;              /* image-enumerating path for small boxes */
   long npairs, maxpairs;
@@ -342,6 +343,7 @@ void leo_neighbor(leo_t *s, double skin, int every, int delay, int check) {
   if (check >= 0) s->check = check;
 }
 void leo_atom_sort(leo_t *s, int sortfreq) { s->sortfreq = sortfreq; }
+void leo_newton_pair(leo_t *s, int on) { s->newton_pair = on; }
 void leo_reset_timestep(leo_t *s, long step) { s->ntimestep = step; }
 void leo_thermo_every(leo_t *s, int n) { s->thermo_every = n; }
 
@@ -499,7 +501,30 @@ static void build_bondlist(leo_t *s) {
       }
     }
 }
-/* src/neighbor.cpp:2022-2101 build: xhold, half list (all owned, i<j), topology */
+/* Which end of an owned-owned pair stores it in the half list (positions = those of the build, s->xhold).
+   newton_pair off, npair_half_bin_newtoff.cpp:90: the lower local index.
+   newton_pair on,  npair_half_bin_newton.cpp:84-149: atoms of one bin -> the one earlier in the bin's list (= lower local
+   index, bins are filled in reverse order: nbin_standard.cpp:192-232); different bins -> the pair is found from the atom
+   whose bin precedes the other's in (z, y, x) order, because the stencil holds only the "upper half" offsets
+   (nstencil_half_bin_3d_newton.cpp: k > 0 || j > 0 || (j == 0 && i > 0)).  Bins: nbin_standard.cpp:53-186 with
+   binsize_optimal = cutneighmax / 2, coord2bin of an owned atom src/nbin.cpp:120-152. */
+static void ref_bin(const leo_t *s, const double *x, int *b) {
+  double binsizeinv = 1.0 / (0.5 * s->cutneighmax);
+  for (int d = 0; d < 3; d++) {
+    int nb = (int)(s->prd[d] * binsizeinv); if (nb == 0) nb = 1;
+    double bininv = 1.0 / (s->prd[d] / nb);
+    int i = (int)((x[d] - s->lo[d]) * bininv); if (i > nb - 1) i = nb - 1;
+    b[d] = i;
+  }
+}
+static int stores_pair(const leo_t *s, int i, int j) {          /* 1: i is the storing end of (i, j) */
+  if (!s->newton_pair) return i < j;
+  int bi[3], bj[3];
+  ref_bin(s, s->xhold + 3 * i, bi); ref_bin(s, s->xhold + 3 * j, bj);
+  for (int d = 2; d >= 0; d--) if (bi[d] != bj[d]) return bi[d] < bj[d];
+  return i < j;
+}
+/* src/neighbor.cpp:2022-2101 build: xhold, half list (all owned; stored under the end stores_pair names), topology */
 static void neigh_build(leo_t *s) {
   int n = s->n;
   s->ago = 0; s->nbuilds++;
@@ -561,7 +586,7 @@ static void neigh_build(leo_t *s) {
       int c = (az * nc[1] + ay) * nc[0] + ax;
       for (int p = head[c]; p < head[c + 1]; p++) {
         int j = order[p];
-        if (j <= i) continue;
+        if (j == i || !stores_pair(s, i, j)) continue;
         double d[3] = { xi - s->x[3 * j], yi - s->x[3 * j + 1], zi - s->x[3 * j + 2] };
         signed char sh[3]; minimg(s, d, sh);
         double rsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
@@ -1033,8 +1058,8 @@ static int fire_ex_load(leo_t *s, leo_fix *fx) {
   for (int i = 0; i < n; i++) {
     int cand[2], ncand = 0;
     int j1 = map_(s, tag[i] - 2), j2 = map_(s, tag[i] + 2);
-    if (j1 > i) cand[ncand++] = j1;
-    if (j2 > i) cand[ncand++] = j2;
+    if (j1 >= 0 && stores_pair(s, i, j1)) cand[ncand++] = j1;      /* the pairs the scan meets in i's list */
+    if (j2 >= 0 && stores_pair(s, i, j2)) cand[ncand++] = j2;
     if (ncand == 2 && cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
     for (int c = 0; c < ncand; c++) {
       int j = cand[c];

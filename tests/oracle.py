@@ -113,6 +113,9 @@ class Oracle:
     def neighbor(self, skin=-1.0, every=0, delay=-1, check=-1):
         self.L.leo_neighbor(self.h, C.c_double(skin), C.c_int(every), C.c_int(delay), C.c_int(check))
 
+    def newton_pair(self, on):
+        self.L.leo_newton_pair(self.h, C.c_int(1 if on else 0))
+
     def atom_sort(self, freq):
         self.L.leo_atom_sort(self.h, C.c_int(freq))
 

@@ -136,7 +136,11 @@ class OracleScript:
         o = self.o
         if c == "units":
             self.units = a[0]
-        elif c in ("atom_style", "newton", "comm_modify", "boundary", "thermo_style", "thermo_modify", "echo", "log"):
+        elif c == "newton":
+            self.newton_pair = a[0] == "on"          # `newton pair [bond]`; bonds are always stored on both atoms here
+            if o:
+                o.newton_pair(self.newton_pair)
+        elif c in ("atom_style", "comm_modify", "boundary", "thermo_style", "thermo_modify", "echo", "log"):
             pass
         elif c == "atom_modify":
             if a[0] == "sort":
@@ -165,6 +169,8 @@ class OracleScript:
             self._make()
             if hasattr(self, "sort"):
                 self.o.atom_sort(self.sort)
+            if hasattr(self, "newton_pair"):
+                self.o.newton_pair(self.newton_pair)
         elif c == "neighbor":
             o.neighbor(skin=float(a[0]))
         elif c == "neigh_modify":

@@ -268,3 +268,29 @@ def test_data_file_order_is_the_local_order(tmp_path):
     o = run_oracle(script, s)
     p = run_product(script, s, tmp_path)
     compare(p, o, ("loop", "loading", "unloading"))
+
+
+@pytest.mark.parametrize("sort", ["0 0", "9 0"])
+def test_ex_load_visit_order_with_newton_pair_on(tmp_path, sort):
+    """`newton on off` (pair on, bond off): the reference's half/bin/newton list stores an owned-owned pair under the atom
+    whose neighbor bin comes first in (z, y, x) order (the lower local index inside a bin), so the ex_load scan meets the
+    (i, i+2) pairs in an order set by bin geometry - and its `partner[mid]` rule depends on that order."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 17))
+    script = le_script(n1=4, nl=5, nu=6, lprob="prob 0.8 684474").replace("newton off", "newton on off") \
+        .replace("atom_modify sort 0 0", "atom_modify sort " + sort) + "run 48\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    # and the order really matters: the same run with the newton-off order differs (without Atom::sort; right after a
+    # sort the local order IS the bin order - the sort bins are the neighbor bins - and the two rules coincide)
+    if sort == "0 0":
+        o2 = run_oracle(script.replace("newton on off", "newton off"), s)
+        assert o2.bond_set() != o.bond_set()
+
+
+def test_le_fixes_refuse_newton_bond_on(tmp_path):
+    from lammps_le_amd import LammpsError
+    s = melted(3000)
+    with pytest.raises(LammpsError, match="newton_bond off"):
+        run_product(le_script(left=1, right=1, lr="").replace("newton off", "newton on") + "run 1\n", s, tmp_path)
