@@ -43,19 +43,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# LE parameter set of the default workloads: extrusion every 1000 steps, ex_load prob 0.002, ex_unload prob 0.05.
+# Round 1 used the "dense" set 0.01 / 0.01 (the one BASELINE.md timed the reference with over 2-4k steps): it loads
+# 1 % of ~0.35 N candidate pairs per firing and unloads 1 % of the extruders, i.e. it heads for extruders on a third of
+# the beads; loops then grow faster than the melt relaxes, extruder bonds over-stretch and BOTH engines end in the
+# reference's `Bad FENE bond` (oracle at 100k beads: 200 warnings by step 100k; product at 1M: abort before step 80k;
+# tests/soak_onset.py replays the first warning of a 250k-bead product run in the oracle: same bond, same mechanism).
+# The set below saturates near 0.4 % loaded beads and was run for 300 000 steps at 1M beads (2 warnings, no abort) and
+# 120 000 steps in the oracle at 100k beads (0 warnings): tests/soak_1m.py, tests/soak_compare.py.
 WORKLOADS = {
-    # name: (beads, chains, barrier_every, n1, nload, pload, tp, generator)
-    "chain1m": (1000000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),
-    "chains10x100k": (1000000, 10, 200, 1000, 1000, 0.01, 0.5, "lattice"),
-    "chain100k": (100000, 1, 0, 17500, 7000, 0.001, 1.0, "lattice"),     # README.md:17,33-34 parameters
-    "chain32k": (32000, 1, 0, 1000, 1000, 0.01, 1.0, "lattice"),
-    "chain250k": (250000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),
-    "chain500k": (500000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),
-    "chain8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice"),      # per-GPU size of the 8 x 1M weak-scaling config, on one GPU
-    # random-walk start (shape of the reference's tools/chain.f + def.chain: bond 0.97, rho* = 0.8442): tag order is NOT
-    # space order, which is what a melt looks like to every tag-indexed gather
-    "walk1m": (1000000, 1, 200, 1000, 1000, 0.01, 0.5, "walk"),
-    "walk100k": (100000, 1, 200, 1000, 1000, 0.01, 0.5, "walk"),
+    # name: (beads, chains, barrier_every, n1, nload, pload, tp, generator, punload)
+    "chain1m": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "lattice", 0.05),
+    "chains10x100k": (1000000, 10, 200, 1000, 1000, 0.002, 0.5, "lattice", 0.05),
+    "chain100k": (100000, 1, 0, 17500, 7000, 0.001, 1.0, "lattice", 0.001),     # README.md:17,33-34 parameters
+    "chain32k": (32000, 1, 0, 1000, 1000, 0.002, 1.0, "lattice", 0.05),
+    "chain250k": (250000, 1, 200, 1000, 1000, 0.002, 0.5, "lattice", 0.05),
+    "chain500k": (500000, 1, 200, 1000, 1000, 0.002, 0.5, "lattice", 0.05),
+    # BASELINE configs[4] names its load: dense (prob 0.01, N1 = 1000); the per-GPU size of the 8 x 1M weak-scaling run
+    "chain8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice", 0.01),
+    "chain1m_dense": (1000000, 1, 200, 1000, 1000, 0.01, 0.5, "lattice", 0.01),  # round-1 default, for comparison
+    # scrambled start (lammps_le_amd.synth.scrambled_chains): chain order is NOT memory order, which is what a melt looks
+    # like to every tag-indexed gather (the serpentine lattice start flatters them)
+    "walk1m": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
+    "walk100k": (100000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
 }
 
 

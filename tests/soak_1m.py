@@ -11,13 +11,16 @@ n = 1000000
 sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
 data = os.path.join(tempfile.mkdtemp(), "data")
 write_data(data, sysd)
-script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01, punload=0.01)
+pload = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
+punload = float(sys.argv[2]) if len(sys.argv) > 2 else pload
+blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=pload, punload=punload)
 lmp = lammps(cmdargs=["-screen", "none"])
 for ln in script.split("\n"):
     lmp.command(ln)
 lmp.command("thermo 20000")
 t0 = time.time()
-for k in range(5):
+for k in range(blocks):
     try:
         lmp.command("run 20000")
     except Exception as e:
