@@ -5,16 +5,34 @@
 
 namespace lmp_le {
 
-// cell of a (wrapped) position.  z cells are counted from zlo_ext (the bottom of this rank's slab + ghost shell;
-// = box.lo[2] on one rank) with a periodic wrap, so owned and ghost beads of a slab land in one local grid.
-__device__ __forceinline__ int cell_index(const double4 &r, const Box &box, int ncx, int ncy, int ncz, double cix,
-                                          double ciy, double ciz, double zlo_ext) {
+// Numbering of the (y, z) rows of cells.  A row's x-cells are always consecutive cell ids (the list build and the cell
+// sort rely on one contiguous bead range per row); the ROWS are numbered in tiles of ROW_TILE x ROW_TILE instead of plain
+// z-major order, so that the beads a group of concurrently running workgroups needs - their own rows and the rows +-1 in
+// y and z - are a compact ~10 x 10 bundle of rows (1.3 MB of positions at 8M beads) instead of three whole z-layers
+// (5.5 MB at 8M beads, more than an XCD's 4 MB L2).  tile = 0: plain z-major numbering (decomposed runs: the slab code
+// relies on ghosts from below / above forming the first / last cell layers).
+constexpr int ROW_TILE = 8;
+__device__ __forceinline__ int row_id(int ay, int az, int ncy, int ncz, int tile) {
+  if (tile == 0) return az * ncy + ay;
+  const int ty = ay / tile, tz = az / tile;
+  const int hy = min(tile, ncy - ty * tile), hz = min(tile, ncz - tz * tile);
+  return tz * tile * ncy + ty * tile * hz + (az - tz * tile) * hy + (ay - ty * tile);
+}
+// cell coordinates of a (wrapped) position.  z cells are counted from zlo_ext (the bottom of this rank's slab + ghost
+// shell; = box.lo[2] on one rank) with a periodic wrap, so owned and ghost beads of a slab land in one local grid.
+__device__ __forceinline__ void cell_coords(const double4 &r, const Box &box, int ncx, int ncy, int ncz, double cix,
+                                            double ciy, double ciz, double zlo_ext, int &cx, int &cy, int &cz) {
   double zrel = r.z - zlo_ext;
   if (zrel < 0.0) zrel += box.prd[2];
   if (zrel >= box.prd[2]) zrel -= box.prd[2];
-  int cx = (int)((r.x - box.lo[0]) * cix), cy = (int)((r.y - box.lo[1]) * ciy), cz = (int)(zrel * ciz);
+  cx = (int)((r.x - box.lo[0]) * cix); cy = (int)((r.y - box.lo[1]) * ciy); cz = (int)(zrel * ciz);
   cx = min(max(cx, 0), ncx - 1); cy = min(max(cy, 0), ncy - 1); cz = min(max(cz, 0), ncz - 1);
-  return (cz * ncy + cy) * ncx + cx;
+}
+__device__ __forceinline__ int cell_index(const double4 &r, const Box &box, int ncx, int ncy, int ncz, double cix,
+                                          double ciy, double ciz, double zlo_ext, int tile) {
+  int cx, cy, cz;
+  cell_coords(r, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext, cx, cy, cz);
+  return row_id(cy, cz, ncy, ncz, tile) * ncx + cx;
 }
 
 // Domain::pbc for one coordinate triple (src/domain.cpp:528-645, orthogonal box): wrapped copy + image deltas

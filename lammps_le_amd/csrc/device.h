@@ -80,6 +80,7 @@ struct DeviceState {
   bool topo_dirty = true;          // bond tables changed since the snapshot was taken
   // ---- cells / neighbor list ----
   int ncell[3] = {0, 0, 0}, ncells = 0;
+  int row_tile = 0;          // (y, z) rows of cells numbered in tiles of this edge (bin_inl.h row_id); 0 = z-major (decomposed runs)
   double cellinv[3] = {0, 0, 0};
   int *cell_of = nullptr, *cell_count = nullptr, *cell_start = nullptr, *cell_fill = nullptr;
   int *scan_tmp = nullptr, *perm = nullptr;

@@ -169,7 +169,7 @@ struct ForceArgs {
   // inside the cell and the cell counts, i.e. everything k_wrap_bin would produce except Domain::pbc itself (k_permute)
   const float4 *holdf;   // float copy of xhold (= posf of the last build; nullptr: use xhold only)
   double hold_band;
-  int bin, ncx, ncy, ncz;
+  int bin, ncx, ncy, ncz, rtile;
   double cix, ciy, ciz, zlo_ext;
   int *cell_of, *cell_count, *cell_rank;
   // decomposed runs: border beads also write their new position into the halo send buffer (no pack launch per step)
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
         if (isfinite(w.x) && isfinite(w.y) && isfinite(w.z)) {
           int dix, diy, diz;
           wrap_into_box(w, box, dix, diy, diz);
-          cell = cell_index(w, box, A.ncx, A.ncy, A.ncz, A.cix, A.ciy, A.ciz, A.zlo_ext);
+          cell = cell_index(w, box, A.ncx, A.ncy, A.ncz, A.cix, A.ciy, A.ciz, A.zlo_ext, A.rtile);
         } else flags[FLAG_ERROR] = ERR_NONFINITE;
         A.cell_of[p] = cell;
         A.cell_rank[p] = count_into_cell<LPB>(cell, A.cell_count);
@@ -613,7 +613,7 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
     A.holdf = (d.posf && !d.dd) ? d.posf : nullptr;
     A.hold_band = 4.0 * (2.0 * 1.7320508 * dmax * e + 3.0 * e * e);
   }
-  A.bin = 0; A.ncx = d.ncell[0]; A.ncy = d.ncell[1]; A.ncz = d.ncell[2];
+  A.bin = 0; A.ncx = d.ncell[0]; A.ncy = d.ncell[1]; A.ncz = d.ncell[2]; A.rtile = d.row_tile;
   A.cix = d.cellinv[0]; A.ciy = d.cellinv[1]; A.ciz = d.cellinv[2]; A.zlo_ext = d.zlo_ext;
   A.cell_of = d.cell_of; A.cell_count = d.cell_count; A.cell_rank = d.tag_tmp;
   return A;

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
                                                     double ciz, double zlo_ext, int *__restrict__ cell_of,
                                                     int *__restrict__ cell_count, int *__restrict__ rank,
                                                     int *__restrict__ flags, const int *__restrict__ gone,
-                                                    int sentinel) {
+                                                    int sentinel, int rtile) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
   double4 r = pos[p];
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(BLOCK) void k_wrap_bin(int n, double4 *__restrict__
   if (diy) img[npad + p] += diy;
   if (diz) img[2 * npad + p] += diz;
   pos[p] = r;
-  int cell = cell_index(r, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
+  int cell = cell_index(r, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext, rtile);
   // decomposed runs: a bead that has just migrated to another slab is binned into a sentinel cell behind all real
   // cells, so the sort that follows also compacts the array (no separate keep/scan/scatter pass)
   if (gone && gone[p]) cell = sentinel;
@@ -283,8 +283,11 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
   double4 ri = pos[active ? s : 0];
-  int cself = cell_index(ri, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext);
-  int cx = cself % ncx, cy = (cself / ncx) % ncy, cz = cself / (ncx * ncy);
+  // `dd`: 0 = one GPU, rows numbered in tiles (bin_inl.h row_id); 1 = decomposed, z-major rows; 2 = one GPU, z-major rows
+  const int rtile = (dd == 0) ? ROW_TILE : 0;
+  dd = (dd == 1) ? 1 : 0;
+  int cx, cy, cz;
+  cell_coords(ri, box, ncx, ncy, ncz, cix, ciy, ciz, zlo_ext, cx, cy, cz);
   // special entries whose level carries a weight != 1 (for `special_bonds fene` the 1-2 partners only): translated
   // to physical indices once, compared as integers in the loop
   int n1 = 0, n2 = 0, kmax = 0, nrel = 0;
@@ -353,7 +356,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
     else { if (az < 0) az += ncz; else if (az >= ncz) az -= ncz; }
     az = min(max(az, 0), ncz - 1);
     if (ay < 0) ay += ncy; else if (ay >= ncy) ay -= ncy;
-    return (az * ncy + ay) * ncx;
+    return row_id(ay, az, ncy, ncz, rtile) * ncx;
   };
   {
     int vb[9], ve[9];
@@ -472,7 +475,7 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
     if (d.cell_count_dirty) HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(nc + 1) * sizeof(int), st));   // bins nobody consumed
     hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, m_in, d.pos, d.img, d.npad, d.box, d.ncell[0],
                        d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of,
-                       d.cell_count, d.tag_tmp, d.flags, gone, d.ncells);
+                       d.cell_count, d.tag_tmp, d.flags, gone, d.ncells, d.row_tile);
   }
   int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_count, d.cell_start, d.scan_tmp);
@@ -502,7 +505,8 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   // even the unused extra kernel argument cost the build 32 us)
   hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.tag, d.map, BT, d.flags);
   if (has_pair) {
-    const int sf1 = d.sflag[1], sf2 = d.sflag[2], sf3 = d.sflag[3];   // Engine::special_flag (lj AND coul weights)
+    const int sf1 = d.sflag[1], sf2 = d.sflag[2], sf3 = d.sflag[3];
+    const int ddcode = d.dd ? 1 : (d.row_tile ? 0 : 2);     // see build_body   // Engine::special_flag (lj AND coul weights)
     double margin = sqrt(cutneighsq) * (1.0 + 1e-12);
     // FP32 test: a float coordinate is off by <= M * 2^-24 (M = largest |coordinate|), a separation component
     // (difference, periodic shift with a float box length) by e_d <= 8 * M * 2^-24, the squared distance of a pair
@@ -515,7 +519,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
     if (getenv("LAMMPS_LE_BUILD_FP64")) bandf = 1e30f;     // diagnostic: every candidate takes the FP64 test
 #define BUILD(NOSP, AS)                                                                                            \
   hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
-                     d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
+                     d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
                      sf2, sf3, d.neigh, d.numneigh, d.flags, 0)
     if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
@@ -524,7 +528,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
 #undef BUILD
     if (const char *dg = getenv("LAMMPS_LE_DIAG_BUILD")) {   // diagnostics: extra launch, entry stores off, scratch counters
       hipLaunchKernelGGL((k_build_neigh_diag<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
-                         d.cell_start, d.gcell_start, d.dd, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],
+                         d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],
                          d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,
                          sf2, sf3, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
     }

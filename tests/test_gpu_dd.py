@@ -245,3 +245,49 @@ def test_eight_slabs_with_the_bench_script(tmp_path):
         assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1]
     assert np.abs(r["x"] - o.x()).max() < 1e-7 and (r["image"] == o.image()).all()
     assert r["builds"][0] == o.neigh_builds() and r["neigh_pairs"][0] == 2 * o.neigh_pairs()
+
+
+def test_overlap_two_ranks_one_million_beads(tmp_path, monkeypatch):
+    """Regression at the shape of the round-1 crash record (gpurun_out/prof_ov2.log: SIGSEGV inside hipMemcpyAsync <-
+    local_exchange <- dd_halo on comm_stream, 2 ranks, 1M beads, halo/compute overlap on, while that mode was being
+    written).  Two in-process ranks, overlap on, 400 steps incl. ~40 collective rebuilds and the first LE firings would
+    not: the run must finish, both ranks must hold the same gathered state, and it must be the 1-rank run's topology."""
+    import threading
+    from lammps_le_amd import lammps
+    from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
+    monkeypatch.setenv("LAMMPS_LE_OVERLAP", "1")
+    n, world = 1000000, 2
+    sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
+    data = os.path.join(str(tmp_path), "data.1m")
+    write_data(data, sysd)
+    script = CHAIN_INPUT.format(data=data, n1=100, left=2, right=3, tp=0.5, lr="4", nload=100, pload=0.01, punload=0.05)
+    session = uuid.uuid4().hex[:12]
+    out, errs = [None] * (world + 1), []
+
+    def work(rank, nranks):
+        try:
+            lmp = lammps(cmdargs=["-screen", "none"])
+            if nranks > 1:
+                lmp.comm_init("local", rank, nranks, session=session)
+            for ln in script.split("\n"):
+                lmp.command(ln)
+            lmp.command("run 400")
+            out[rank if nranks > 1 else world] = (lmp.gather("x"), lmp.gather("num_bond"), lmp.gather("bond_atom"),
+                                                  lmp.get_thermo("bonds"))
+            lmp.close()
+        except Exception as e:
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r, world)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    work(0, 1)                                   # the same script on one rank
+    assert not errs, errs
+    a, b, one = out[0], out[1], out[world]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+    assert a[3] == one[3] > n - 1                # extruders were loaded, and as many as on one rank
+    assert np.array_equal(a[1], one[1]) and np.array_equal(a[2], one[2])      # bit-exact topology
+    assert np.abs(a[0] - one[0]).max() < 1e-6
