@@ -319,7 +319,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   // positions were wrapped into the box just before this kernel: interior = farther than cutneigh from all faces
   bool interior = ri.x > box.lo[0] + margin && ri.x < box.hi[0] - margin && ri.y > box.lo[1] + margin &&
                   ri.y < box.hi[1] - margin && ri.z > box.lo[2] + margin && ri.z < box.hi[2] - margin;
-  bool all_in = __all(interior || !active) && !dd;
+  bool all_in = __all(interior || !active);      // (decomposed runs too: ghosts are unshifted copies, only beads near a BOX face meet images)
   // Row-segment staging.  The 64 beads of a wavefront are consecutive in cell order, so for one (dy,dz) offset
   // their candidate ranges are overlapping windows of ONE short index interval [B,E) (~64 + one window).  The
   // wavefront copies that interval's float4 positions into LDS with coalesced loads and every lane then walks its
@@ -378,7 +378,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
     mb = s_rng[0][r][threadIdx.x]; me = s_rng[1][r][threadIdx.x];
     // interval of the wavefront: ranges grow with the lane index, so [first lane's begin, last lane's end)
     B = __shfl(mb, 0, 64); E = __shfl(me, last, 64);
-    fits = !dd && E - B <= STAGE_CAP && __all(me <= mb || (mb >= B && me <= E));
+    fits = E - B <= STAGE_CAP && __all(me <= mb || (mb >= B && me <= E));
   };
   int mb, me, B, E;
   bool fits;
