@@ -295,7 +295,20 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   int spi[SPMAX], spc[SPMAX];
 #pragma unroll
   for (int k = 0; k < SPMAX; k++) { spi[k] = -1; spc[k] = 0; }
-  if (!NOSPECIAL && active && !(diag & 4)) {
+  if (!NOSPECIAL && active && !(diag & 4) && nspecial == nullptr) {
+    // `special_bonds fene`-like flags (only the 1-2 level is dropped) with symmetric special lists: the excluded beads are
+    // the bond partners, and k_bond_table has just written their physical indices, coalesced, into bpart (handed in
+    // through `special`, row count through `ms`) - no walk through the tag-indexed special tables (5 scattered reads per bead)
+    int m = 0;
+    for (int k = 0; k < ms; k++) {
+      const int e = special[(size_t)k * npad + s];
+      if (e < 0) continue;
+#pragma unroll
+      for (int j = 0; j < SPMAX; j++) if (j == m) { spi[j] = e & BOND_IDX_MASK; spc[j] = -1; }
+      m++;
+    }
+    nrel = m;
+  } else if (!NOSPECIAL && active && !(diag & 4)) {
     int t = tag[s];
     // (tag-indexed tables, one or two lines per bead out of 100 MB, read once per rebuild: kept out of the caches)
     n1 = __builtin_nontemporal_load(&nspecial[3 * (size_t)t]); n2 = __builtin_nontemporal_load(&nspecial[3 * (size_t)t + 1]);
@@ -524,7 +537,16 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
                      sf2, sf3, d.neigh, d.numneigh, d.flags, 0)
     if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
     else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
-    else BUILD(false, false);
+    else if (sf1 == 0 && sf2 == 1 && sf3 == 1 && d.bpa >= 1 && d.bpa <= SPMAX && !getenv("LAMMPS_LE_NO_BPART_EXCL")) {
+      // exclusions = bond partners: read them from the bond-partner table (see build_body)
+#define BUILD_BP()                                                                                                  \
+  hipLaunchKernelGGL((k_build_neigh<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
+                     d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
+                     d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, (const int *)nullptr, (const int *)d.bpart, d.bpa, sf1,  \
+                     sf2, sf3, d.neigh, d.numneigh, d.flags, 0)
+      BUILD_BP();
+#undef BUILD_BP
+    } else BUILD(false, false);
 #undef BUILD
     if (const char *dg = getenv("LAMMPS_LE_DIAG_BUILD")) {   // diagnostics: extra launch, entry stores off, scratch counters
       hipLaunchKernelGGL((k_build_neigh_diag<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
