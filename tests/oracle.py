@@ -10,11 +10,13 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "liboracle.so")
+_SO = os.environ.get("ORACLE_SO") or os.path.join(_ROOT, "oracle", "liboracle.so")   # ORACLE_SO: e.g. the ASan/UBSan build (oracle/Makefile `asan`)
 
 
 def build():
     src = os.path.join(_ROOT, "oracle", "le_oracle.c")
+    if os.environ.get("ORACLE_SO"):
+        return _SO
     if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", os.path.join(_ROOT, "oracle")])
     return _SO

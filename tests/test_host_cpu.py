@@ -365,3 +365,37 @@ def test_oracle_ex_load_candidates_are_pair_list_entries():
         loads[sp] = o.fix_vector("loading")[1]
     assert loads["fene"] > 0 and loads["lj 1 1 1"] > 0 and loads["lj 0 0 1 coul 0 1 1"] > 0
     assert loads["lj 0 0 1"] == 0      # 1-3 pairs are not in the list: nothing to scan
+
+
+@pytest.mark.parametrize("order", ["newton off\natom_modify sort 0 0", "newton off\natom_modify sort 7 0", "newton on off\natom_modify sort 0 0"])
+def test_oracle_le_cycle_invariants(order):
+    """The oracle alone through extrusion / ex_load / ex_unload cycles in the three visit orders it restates (ID order,
+    Atom::sort order, half/bin/newton storing order): structural invariants of the topology it leaves behind.  Also the
+    workload for the sanitizer build (`make -C oracle asan`, see oracle/Makefile)."""
+    from systems import CHAIN_SCRIPT, lattice_chain, run_oracle
+    n = 2000
+    s = lattice_chain(n, seed=6)
+    o = run_oracle(CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 77\nrun 1000\n", s)
+    s["x"], s["v"], s["image"] = o.x(), o.v(), o.image()
+    script = CHAIN_SCRIPT.replace("newton off\natom_modify sort 0 0", order) \
+        .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0") + """fix 1 all nve
+fix 2 all langevin 1.0 1.0 1.0 904297
+fix loop all extrusion 4 1 1 1 1.0 2
+fix loading all ex_load 5 1 1 1.12 2 prob 0.5 684474 iparam 1 1 jparam 1 1
+fix unloading all ex_unload 6 2 0.5 prob 0.3 456456
+run 120
+"""
+    assert order.split("\n")[0] in script and order.split("\n")[1] in script
+    o = run_oracle(script, s)
+    nb, bt, ba = o.bond_table()
+    ns, sp = o.special_table()
+    half = {(int(bt[i, m]), i + 1, int(ba[i, m])) for i in range(n) for m in range(nb[i])}
+    assert all((t, j, i) in half for (t, i, j) in half)                     # stored by both ends
+    assert all((1, i, i + 1) in half for i in range(1, n))                  # backbone intact
+    ext = [(i, j) for (t, i, j) in half if t == 2 and i < j]
+    ends = [e for p in ext for e in p]
+    assert len(ext) > 3 and len(ends) == len(set(ends))                     # one anchor per bead at most
+    assert o.nbonds() == n - 1 + len(ext)
+    assert o.fix_vector("loading")[1] - o.fix_vector("unloading")[1] == len(ext)
+    for i in range(n):                                                      # 1-2 block = bond partners
+        assert sorted(sp[i, :ns[i, 0]]) == sorted(int(ba[i, m]) for m in range(nb[i])), i + 1
