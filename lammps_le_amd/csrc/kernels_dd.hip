@@ -17,6 +17,7 @@ namespace lmp_le {
 constexpr int BLOCK = 256;
 constexpr int MIG_W = 12;    // doubles per migrating bead: x y z type vx vy vz tag ix iy iz pad
 constexpr int GATH_W = 14;   // doubles per bead in whole-system gathers: tag x y z type vx vy vz fx fy fz ix iy iz
+constexpr int GATH_LE_W = 8; // ... of the LE fixes' firing-step gather: tag x y z type xhold[3]
 
 void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);   // kernels_le.hip
 void dd_halo_wait(DeviceState &d);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_dd_gather_pack(int n, int npad, int s
                                                           const int *__restrict__ img, int mode, double *__restrict__ out) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= stride) return;
-  double *b = out + (size_t)p * GATH_W;
+  double *b = out + (size_t)p * (mode == 0 ? GATH_LE_W : GATH_W);
   if (p >= n) { b[0] = 0.0; return; }
   double4 r = pos[p];
   b[0] = (double)tag[p]; b[1] = r.x; b[2] = r.y; b[3] = r.z; b[4] = r.w;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(BLOCK) void k_dd_scatter_xt(long total, const doubl
                                                          double4 *__restrict__ xht) {
   long i = (long)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= total) return;
-  const double *b = in + (size_t)i * GATH_W;
+  const double *b = in + (size_t)i * GATH_LE_W;
   int t = (int)b[0];
   if (t <= 0) return;
   xt[t] = make_double4(b[1], b[2], b[3], b[4]);
@@ -284,11 +285,12 @@ __global__ __launch_bounds__(BLOCK) void k_dd_scatter_xt(long total, const doubl
 // =============================================================================================
 static void ensure_gather(DeviceState &d, size_t doubles_per_rank, int world) {
   size_t need = doubles_per_rank * (size_t)(world + 1);
-  if (need <= d.gather_cap) return;
-  if (d.gather_send) (void)hipFree(d.gather_send);
-  HIP_CHECK(hipMalloc(&d.gather_send, need * sizeof(double)));
-  d.gather_recv = d.gather_send + doubles_per_rank;
-  d.gather_cap = need;
+  if (need > d.gather_cap) {
+    if (d.gather_send) (void)hipFree(d.gather_send);
+    HIP_CHECK(hipMalloc(&d.gather_send, need * sizeof(double)));
+    d.gather_cap = need;
+  }
+  d.gather_recv = d.gather_send + doubles_per_rank;      // (per call: the two gathers differ in their row width)
 }
 
 void dd_alloc(DeviceState &d, int world) {
@@ -471,10 +473,10 @@ void dd_gather_positions(DeviceState &d, Comm &comm) {
   dd_halo_wait(d);
   long maxn = comm.allreduce_host_max(d.n);
   int stride = (int)maxn;
-  ensure_gather(d, (size_t)stride * GATH_W, comm.world);
+  ensure_gather(d, (size_t)stride * GATH_LE_W, comm.world);
   hipLaunchKernelGGL(k_dd_gather_pack, dim3((stride + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.n, d.npad, stride,
                      d.pos, d.xhold, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2], d.tag, d.img, 0, d.gather_send);
-  comm.allgather(d.stream, d.gather_send, d.gather_recv, (size_t)stride * GATH_W * sizeof(double));
+  comm.allgather(d.stream, d.gather_send, d.gather_recv, (size_t)stride * GATH_LE_W * sizeof(double));
   long total = (long)stride * comm.world;
   hipLaunchKernelGGL(k_dd_scatter_xt, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, total,
                      d.gather_recv, d.xt, d.xht);
