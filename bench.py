@@ -23,7 +23,7 @@ Order of a run (whatever K and W are, so that a 20-step line and a 2000-step lin
   5. only now is the state copied out for the CPU baseline (the copy idles the GPU; nothing timed follows it).
 
 Extra objects on the JSON line:
-  roofline     — the fused step kernel k_step: algorithmic bytes (144*N + 4*F, F = stored full-list entries;
+  roofline     — the fused step kernel k_step: algorithmic bytes (132*N + 4*(F + 2*B), F = stored full-list entries, B = bonds;
                  DESIGN.md §3) / mean kernel duration from HIP events recorded on the launch stream inside the
                  engine over the timed region (every launch when K <= 64, every 16th otherwise), vs the 8 TB/s peak.
   cpu_baseline — the CPU oracle (oracle/le_oracle.c, a serial port of the reference path) on 1 host core, on a
@@ -207,9 +207,10 @@ def main():
     extruders = int(lmp.get_thermo("bonds") - (nbeads - nchains))
 
     # ---- roofline of the dominant kernel (k_step: pair lj/cut + bonds + langevin + nve, one launch per step) ----
-    # k_step moves, per owned bead: pos 32 r + pos' 32 w + v 24 r + 24 w + tag 4 + draws 12 + bond table 12 +
-    # numneigh 4 = 144 B, plus 4 B per stored neighbor entry; this rank's share when decomposed
-    alg_bytes = 144.0 * nlocal + 4.0 * full_entries * (nlocal / nbeads)
+    # k_step moves, per owned bead: pos 32 r + pos' 32 w + v 24 r + 24 w + tag 4 + draws 12 + numneigh 4 = 132 B, plus
+    # 4 B per list entry: the stored neighbor entries and the bead's bonds, which open its list (one entry per bond end:
+    # 2 per bond) - DESIGN.md §3; this rank's share when decomposed
+    alg_bytes = 132.0 * nlocal + 4.0 * (full_entries + 2.0 * nbonds) * (nlocal / nbeads)
     achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -550,7 +550,7 @@ double Engine::stat_neigh_pairs() {
   HIP_CHECK(hipMemcpy(nn.data(), dev->numneigh, (size_t)dev->n * sizeof(int), hipMemcpyDeviceToHost));
   nn[dev->n] = 0;
   double s = 0.0;
-  for (int v : nn) s += v;
+  for (int v : nn) s += (v & NN_COUNT_MASK) - (v >> NN_BOND_SHIFT);     // pair entries (a bead's bonds open its list)
   if (world > 1) s = comm->allreduce_host_sum(s);
   return s;
 }

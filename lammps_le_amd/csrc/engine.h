@@ -26,6 +26,10 @@ constexpr int NEIGH_SB_SHIFT = 30; // special-bond bits, as src/lmptype.h:61-62
 constexpr int NEIGH_MASK = 0x3FFFFFFF;
 constexpr int BOND_TYPE_SHIFT = 26; // bond partner table: (type << 26) | partner index
 constexpr int BOND_IDX_MASK = (1 << BOND_TYPE_SHIFT) - 1;
+// numneigh word of a bead: list entries in the low 16 bits (bonds + pairs), of which the first (word >> 16) are bond
+// entries in the bond-partner table's encoding (kernels_md.hip pair_loop)
+constexpr int NN_BOND_SHIFT = 16;
+constexpr int NN_COUNT_MASK = (1 << NN_BOND_SHIFT) - 1;
 
 // ---------------------------------------------------------------------------------------------
 // RanMars in exact integer arithmetic (src/random_mars.cpp:29-95; every value is k * 2^-24)

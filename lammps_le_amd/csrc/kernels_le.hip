@@ -347,8 +347,8 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
       base = false;
       const int p = V.map[is], q = V.map[js];
       if (p >= 0 && p < V.n_owned && q >= 0) {
-        const int nn = V.numneigh[p];
-        for (int k = 0; k < nn; k++)
+        const int w = V.numneigh[p], nn = w & NN_COUNT_MASK;       // (the bead's bond entries come first: skipped)
+        for (int k = w >> NN_BOND_SHIFT; k < nn; k++)
           if ((V.neigh[(size_t)k * V.npad + p] & NEIGH_MASK) == q) { base = true; break; }
       }
     }
@@ -548,9 +548,9 @@ __global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams
     const int bci = bc[t];
     const int *sl = tp.special + (size_t)t * tp.ms;
     const int n1 = tp.nspecial[3 * (size_t)t];
-    const int nn = numneigh[p];
+    const int w = numneigh[p], nn = w & NN_COUNT_MASK;             // (the bead's bond entries come first: skipped)
     double best = 1.0e20;
-    for (int k = 0; k < nn; k++) {
+    for (int k = w >> NN_BOND_SHIFT; k < nn; k++) {
       const int j = neigh[(size_t)k * npad + p] & NEIGH_MASK;
       const int tj = tag[j];
       const int jtype = tp.type_t[tj];

@@ -17,12 +17,17 @@
 namespace lmp_le {
 
 constexpr int BLOCK = 256;
-constexpr int BOND_AHEAD = 3;             // bond slots whose partner loads are issued ahead of the neighbor loop
 // the throughput variant of k_step is bound by (resident wavefronts) / (lifetime of one wavefront): occupancy was
 // varied on purpose with unused LDS and 16 -> 12 -> 8 waves per CU cost x1.22 and x1.79.  Asking the compiler for five
 // waves per SIMD makes it fit 92 VGPRs without scratch (it takes 126 when left alone).
+#ifndef LATE_OWN_LOADS
+#define LATE_OWN_LOADS 0
+#endif
+#ifndef STEP_STAGE_W
+#define STEP_STAGE_W 4
+#endif
 #ifndef STEP_WAVES_PER_SIMD
-#define STEP_WAVES_PER_SIMD 5
+#define STEP_WAVES_PER_SIMD 4
 #endif
 constexpr int AHEAD_MAX_BEADS = 64000;   // k_step: partner / first-stage loads issued ahead of their use up to this size
 constexpr int LPB4_MAX_BEADS = 50000;   // k_step: four lanes per bead up to this many (owned) beads, see k_step
@@ -162,7 +167,6 @@ struct ForceArgs {
   int has_sb;            // some special weight is neither 0 nor 1 -> list entries carry special bits
   double margin;         // beads farther than this from every box face need no minimum image
   int maxrow;            // highest list row a lane may touch before it knows its count: (maxneigh - 1 - sub) / LPB >= this
-  int bprow;             // last row of the bond-partner table (max(bpa, 1) - 1)
   int nn_limit;          // diagnostics only (LAMMPS_LE_NN_LIMIT): cap on neighbors visited per bead
   int diag;              // diagnostics only (LAMMPS_LE_DIAG_STEP): extra launch with parts off, see launch_step
   // a launch that tests the skin/2 displacement (a rebuild may follow) also bins the new positions: cell, arrival order
@@ -258,9 +262,8 @@ __device__ __forceinline__ void pair_term(const ForceArgs &A, const Box &box, co
 // walks (every level costs a trip to the memory-side cache: each kernel starts with a cold L2), so the chain is kept
 // at own data -> partners' positions -> next list stage.
 struct BeadPre {
-  int nall;                // list length
+  int nall;                // list length word: entries | bond entries << NN_BOND_SHIFT (device.h)
   int j0, j1, j2, j3;      // first list stage (rows below maxneigh always exist; masked once the length is known)
-  int eb[BOND_AHEAD];      // first bond slots (rows clamped to the table; masked by the bond count)
 };
 template <bool HAS_PAIR, int LPB, bool AHEAD>
 __device__ __forceinline__ BeadPre bead_preload(const ForceArgs &A, int p, int sub) {
@@ -268,8 +271,6 @@ __device__ __forceinline__ BeadPre bead_preload(const ForceArgs &A, int p, int s
   if (!AHEAD) {            // throughput-bound sizes: loads stay where they are consumed (measured faster at 1M beads)
     L.nall = HAS_PAIR ? A.numneigh[p] : 0;
     L.j0 = L.j1 = L.j2 = L.j3 = p;
-#pragma unroll
-    for (int u = 0; u < BOND_AHEAD; u++) L.eb[u] = -1;
     return L;
   }
   if (HAS_PAIR) {
@@ -280,42 +281,125 @@ __device__ __forceinline__ BeadPre bead_preload(const ForceArgs &A, int p, int s
   } else {
     L.nall = 0; L.j0 = L.j1 = L.j2 = L.j3 = p;
   }
-#pragma unroll
-  for (int u = 0; u < BOND_AHEAD; u++) L.eb[u] = A.bpart[(size_t)min(sub + u * LPB, A.bprow) * A.npad + p];
   return L;
 }
 
-// LPB = lanes per bead: lane `sub` of a bead's LPB lanes takes list entries sub, sub + LPB, ... (see k_step)
+// one bond term seen from bead p (BondFENE::compute / BondHarmonic::compute; every bond is evaluated from both ends).
+// `eb` = (bond type << BOND_TYPE_SHIFT) | partner's index, rj = the partner's position.
+template <bool EFLAG>
+__device__ __forceinline__ void bond_term(const Box &box, const double *__restrict__ s_bt, int p, const double4 &ri,
+                                          int eb, const double4 &rj, double &fxi, double &fyi, double &fzi,
+                                          double (&e)[14], int *__restrict__ flags) {
+  const int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
+  const double *row = s_bt + type * BT_W;
+  const int style = (int)row[0];
+  if (style == 0) return;
+  const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
+  const double px = box.prd[0], py = box.prd[1], pz = box.prd[2];
+  double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
+  if (delx > hx) delx -= px; else if (delx < -hx) delx += px;
+  if (dely > hy) dely -= py; else if (dely < -hy) dely += py;
+  if (delz > hz) delz -= pz; else if (delz < -hz) delz += pz;
+  double rsq = delx * delx + dely * dely + delz * delz;
+  double fbond, ebond = 0.0;
+  if (style == 1) {
+    // BondFENE::compute with its four divisions done as products with reciprocals (each <= 1 ulp from the quotient)
+    const double K = row[1], inv_r0sq = row[2];
+    double rlogarg = 1.0 - rsq * inv_r0sq;
+    double sr6 = 0.0;
+    if (rlogarg < 0.1) {
+      // each bond is visited from both ends: count the warning once (lower index)
+      if (p < q) atomicAdd(&flags[FLAG_FENE_WARN], 1);
+      if (rlogarg <= -3.0) flags[FLAG_ERROR] = ERR_BAD_FENE;
+      rlogarg = 0.1;
+    }
+    fbond = -K * rcp_nr(rlogarg);
+    if (rsq < row[5]) {
+      const double rinv = rcp_nr(rsq);
+      double sr2 = row[4] * rinv;
+      sr6 = sr2 * sr2 * sr2;
+      fbond += row[3] * sr6 * (sr6 - 0.5) * rinv;
+    }
+    if (EFLAG) {
+      ebond = -0.5 * K * row[6] * log(rlogarg);
+      if (rsq < row[5]) ebond += 4.0 * row[7] * sr6 * (sr6 - 1.0) + row[7];
+    }
+  } else {
+    double r = sqrt(rsq);
+    double dr = r - row[2];
+    double rk = row[1] * dr;
+    fbond = (r > 0.0) ? -2.0 * rk / r : 0.0;
+    if (EFLAG) ebond = rk * dr;
+  }
+  fxi += delx * fbond; fyi += dely * fbond; fzi += delz * fbond;
+  if (EFLAG) {
+    e[1] += 0.5 * ebond;
+    e[8] += 0.5 * delx * delx * fbond; e[9] += 0.5 * dely * dely * fbond; e[10] += 0.5 * delz * delz * fbond;
+    e[11] += 0.5 * delx * dely * fbond; e[12] += 0.5 * delx * delz * fbond; e[13] += 0.5 * dely * delz * fbond;
+  }
+}
+
+// LPB = lanes per bead: lane `sub` of a bead's LPB lanes takes list entries sub, sub + LPB, ... (see k_step).
+// The first `nb` entries of a bead's list are its BONDS ((type << BOND_TYPE_SHIFT) | partner, written by the list build
+// from the bond-partner table), the pair entries follow: a bonded partner's position travels through the same pipelined
+// gathers as the pair partners', instead of a chain of dependent loads (table entry -> position, one bond after the
+// other) behind the pair loop.  Stages that hold a bond entry in some lane (the first one; the second for a wavefront
+// with an extruder anchor) run the mixed body, all later ones the plain pair body.
 template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB, int LPB, bool AHEAD, bool DIAGP = false>
-__device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, const double *__restrict__ s_tab, int p,
-                                          int sub, const BeadPre &L, int nall, const double4 &ri, double &fxi,
-                                          double &fyi, double &fzi, double (&e)[14]) {
+__device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, const double *__restrict__ s_tab,
+                                          const double *__restrict__ s_bt, int p, int sub, const BeadPre &L, int nall,
+                                          int nb, const double4 &ri, double &fxi, double &fyi, double &fzi,
+                                          double (&e)[14], int *__restrict__ flags) {
+  // software pipeline, W neighbors per stage: while the W position gathers of the current stage are in flight the
+  // (coalesced) index loads of the next stage are issued, so a stage costs one exposed round trip.  Lists are
+  // consumed in groups of W; slots past the end are predicated off (index = own bead, cached).
+  constexpr int W = AHEAD ? 4 : STEP_STAGE_W;
   const int itype = (int)ri.w;
   const size_t npad = (size_t)LPB * A.npad;                                             // stride between a lane's entries
   const int *col = A.neigh + p + (size_t)sub * A.npad;
-  // software pipeline, 4 neighbors per stage: while the four position gathers of the current stage are in
-  // flight the (coalesced) index loads of the next stage are issued, so a stage costs one exposed round trip.
-  // Lists are consumed in groups of 4; slots past the end are predicated off (index = own bead, cached).
   const int nn = (LPB == 1) ? nall : (nall > sub ? (nall - sub + LPB - 1) / LPB : 0);   // entries of this lane
-  int j0, j1, j2, j3;
-  if (AHEAD) { j0 = (0 < nn) ? L.j0 : p; j1 = (1 < nn) ? L.j1 : p; j2 = (2 < nn) ? L.j2 : p; j3 = (3 < nn) ? L.j3 : p; }
-  else { j0 = (0 < nn) ? col[0] : p; j1 = (1 < nn) ? col[npad] : p; j2 = (2 < nn) ? col[2 * npad] : p; j3 = (3 < nn) ? col[3 * npad] : p; }
-  for (int k = 0; k < nn; k += 4) {
+  const bool bonds_on = !(DIAGP && (A.diag & 1));
+  int j[W];
+  if (AHEAD) { j[0] = (0 < nn) ? L.j0 : p; j[1] = (1 < nn) ? L.j1 : p; j[2] = (2 < nn) ? L.j2 : p; j[3] = (3 < nn) ? L.j3 : p; }
+  else {
+#pragma unroll
+    for (int u = 0; u < W; u++) j[u] = (u < nn) ? col[u * npad] : p;
+  }
+  for (int k = 0; k < nn; k += W) {
     if (DIAGP && (A.diag & 8)) {          // diagnostics: same arithmetic, gathers replaced by coalesced loads
-      j0 = min(p + k + 1, A.n - 1); j1 = min(p + k + 2, A.n - 1); j2 = min(p + k + 3, A.n - 1); j3 = min(p + k + 4, A.n - 1);
+#pragma unroll
+      for (int u = 0; u < W; u++) j[u] = min(p + k + u + 1, A.n - 1);
     }
-    double4 r0 = A.pos[j0 & NEIGH_MASK], r1 = A.pos[j1 & NEIGH_MASK], r2 = A.pos[j2 & NEIGH_MASK],
-            r3 = A.pos[j3 & NEIGH_MASK];
-    const int c0 = j0, c1 = j1, c2 = j2, c3 = j3;
-    const int kn = k + 4;
-    j0 = (kn < nn) ? col[(size_t)kn * npad] : p;
-    j1 = (kn + 1 < nn) ? col[(size_t)(kn + 1) * npad] : p;
-    j2 = (kn + 2 < nn) ? col[(size_t)(kn + 2) * npad] : p;
-    j3 = (kn + 3 < nn) ? col[(size_t)(kn + 3) * npad] : p;
-    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c0, r0, true, fxi, fyi, fzi, e);
-    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c1, r1, k + 1 < nn, fxi, fyi, fzi, e);
-    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c2, r2, k + 2 < nn, fxi, fyi, fzi, e);
-    pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c3, r3, k + 3 < nn, fxi, fyi, fzi, e);
+    const int g0 = k * LPB + sub;                                                       // list row of this lane's slot 0
+    const bool mixed = __any(g0 < nb);                                                  // (bond entries come first)
+    double4 r[W];
+    int c[W];
+    if (mixed) {
+#pragma unroll
+      for (int u = 0; u < W; u++) r[u] = A.pos[j[u] & (g0 + u * LPB < nb ? BOND_IDX_MASK : NEIGH_MASK)];
+    } else {
+#pragma unroll
+      for (int u = 0; u < W; u++) r[u] = A.pos[j[u] & NEIGH_MASK];
+    }
+    const int kn = k + W;
+#pragma unroll
+    for (int u = 0; u < W; u++) { c[u] = j[u]; j[u] = (kn + u < nn) ? col[(size_t)(kn + u) * npad] : p; }
+    if (mixed) {
+      // rolled over the slots (one copy of each body in the code; unrolled, the two bodies per slot cost ~20 registers)
+#pragma unroll 1
+      for (int u = 0; u < W; u++) {
+        int cu = c[0];
+        double4 ru = r[0];
+#pragma unroll
+        for (int w = 1; w < W; w++) if (u == w) { cu = c[w]; ru = r[w]; }
+        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, cu, ru, fxi, fyi, fzi, e, flags); }
+        else pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, cu, ru, k + u < nn, fxi, fyi, fzi, e);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < W; u++)
+        pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c[u], r[u], k + u < nn, fxi, fyi, fzi, e);
+    }
   }
 }
 
@@ -324,96 +408,33 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
                                            const double *__restrict__ s_tab, const double *__restrict__ s_bt, int p,
                                            int sub, const BeadPre &L, const double4 &ri, double &fxi, double &fyi,
                                            double &fzi, double (&e)[14], int *__restrict__ flags) {
-  const int npad = A.npad;
-  const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
-  const double px = box.prd[0], py = box.prd[1], pz = box.prd[2];
-  const int nbond = (DIAG && (A.diag & 1)) ? 0 : A.bpa;
-  const int nall = (DIAG && (A.diag & 2)) ? 0 : min(L.nall, A.nn_limit);
-  // bonded partners of the first BOND_AHEAD slots: positions requested together with the first list stage
-  int eb_a[BOND_AHEAD];
-  double4 rb_a[BOND_AHEAD];
-  if (AHEAD) {
-#pragma unroll
-    for (int u = 0; u < BOND_AHEAD; u++) {
-      eb_a[u] = (sub + u * LPB < nbond) ? L.eb[u] : -1;
-      rb_a[u] = A.pos[eb_a[u] >= 0 ? (eb_a[u] & BOND_IDX_MASK) : p];
-    }
-  }
   if (HAS_PAIR) {
+    const int nall = (DIAG && (A.diag & 2)) ? 0 : min(L.nall & NN_COUNT_MASK, A.nn_limit);
+    const int nb = min(L.nall >> NN_BOND_SHIFT, nall);
     // wave-uniform choice: a wavefront whose 64 beads all sit deeper than `margin` inside the box skips
-    // the minimum-image arithmetic (cell order makes most wavefronts interior)
+    // the minimum-image arithmetic of the pair terms (cell order makes most wavefronts interior)
     const double m = A.margin;
     bool interior = ri.x > box.lo[0] + m && ri.x < box.hi[0] - m && ri.y > box.lo[1] + m && ri.y < box.hi[1] - m &&
                     ri.z > box.lo[2] + m && ri.z < box.hi[2] - m;
     bool all_in = __all(interior);
+#define LE_LOOP(MI, UN, SB) pair_loop<EFLAG, MI, UN, SB, LPB, AHEAD, DIAG>(A, box, s_tab, s_bt, p, sub, L, nall, nb, ri, fxi, fyi, fzi, e, flags)
     if (A.uniform && !A.has_sb) {
-      if (all_in) pair_loop<EFLAG, false, true, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
-      else pair_loop<EFLAG, true, true, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
+      if (all_in) LE_LOOP(false, true, false); else LE_LOOP(true, true, false);
     } else if (!A.has_sb) {
-      if (all_in) pair_loop<EFLAG, false, false, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
-      else pair_loop<EFLAG, true, false, false, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
+      if (all_in) LE_LOOP(false, false, false); else LE_LOOP(true, false, false);
     } else {
-      pair_loop<EFLAG, true, false, true, LPB, AHEAD, DIAG>(A, box, s_tab, p, sub, L, nall, ri, fxi, fyi, fzi, e);
+      LE_LOOP(true, false, true);
     }
+#undef LE_LOOP
+    return;
   }
-  for (int u = 0, m = sub; m < nbond; m += LPB, u++) {
-    int eb;
-    double4 rj;
-    if (AHEAD && u < BOND_AHEAD) {
-      // (static indexing keeps the prefetched values in registers)
-      eb = eb_a[0]; rj = rb_a[0];
-#pragma unroll
-      for (int w = 1; w < BOND_AHEAD; w++) if (u == w) { eb = eb_a[w]; rj = rb_a[w]; }
-    } else {
-      eb = A.bpart[(size_t)m * npad + p];
-      rj = A.pos[eb >= 0 ? (eb & BOND_IDX_MASK) : p];
-    }
+  // no pair style (no list): the bonds come straight from the bond-partner table
+  const int nbond = (DIAG && (A.diag & 1)) ? 0 : A.bpa;
+  for (int m = sub; m < nbond; m += LPB) {
+    const int eb = A.bpart[(size_t)m * A.npad + p];
     if (eb < 0) continue;
-    int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
-    const double *row = s_bt + type * BT_W;
-    const int style = (int)row[0];
-    if (style == 0) continue;
-    double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
-    if (delx > hx) delx -= px; else if (delx < -hx) delx += px;
-    if (dely > hy) dely -= py; else if (dely < -hy) dely += py;
-    if (delz > hz) delz -= pz; else if (delz < -hz) delz += pz;
-    double rsq = delx * delx + dely * dely + delz * delz;
-    double fbond, ebond = 0.0;
-    if (style == 1) {
-      // BondFENE::compute with its four divisions done as products with reciprocals (each <= 1 ulp from the quotient)
-      const double K = row[1], inv_r0sq = row[2];
-      double rlogarg = 1.0 - rsq * inv_r0sq;
-      double sr6 = 0.0;
-      if (rlogarg < 0.1) {
-        // each bond is visited from both ends: count the warning once (lower index)
-        if (p < q) atomicAdd(&flags[FLAG_FENE_WARN], 1);
-        if (rlogarg <= -3.0) flags[FLAG_ERROR] = ERR_BAD_FENE;
-        rlogarg = 0.1;
-      }
-      fbond = -K * rcp_nr(rlogarg);
-      if (rsq < row[5]) {
-        const double rinv = rcp_nr(rsq);
-        double sr2 = row[4] * rinv;
-        sr6 = sr2 * sr2 * sr2;
-        fbond += row[3] * sr6 * (sr6 - 0.5) * rinv;
-      }
-      if (EFLAG) {
-        ebond = -0.5 * K * row[6] * log(rlogarg);
-        if (rsq < row[5]) ebond += 4.0 * row[7] * sr6 * (sr6 - 1.0) + row[7];
-      }
-    } else {
-      double r = sqrt(rsq);
-      double dr = r - row[2];
-      double rk = row[1] * dr;
-      fbond = (r > 0.0) ? -2.0 * rk / r : 0.0;
-      if (EFLAG) ebond = rk * dr;
-    }
-    fxi += delx * fbond; fyi += dely * fbond; fzi += delz * fbond;
-    if (EFLAG) {
-      e[1] += 0.5 * ebond;
-      e[8] += 0.5 * delx * delx * fbond; e[9] += 0.5 * dely * dely * fbond; e[10] += 0.5 * delz * delz * fbond;
-      e[11] += 0.5 * delx * dely * fbond; e[12] += 0.5 * delx * delz * fbond; e[13] += 0.5 * dely * delz * fbond;
-    }
+    const double4 rj = A.pos[eb & BOND_IDX_MASK];
+    bond_term<EFLAG>(box, s_bt, p, ri, eb, rj, fxi, fyi, fzi, e, flags);
   }
 }
 
@@ -478,22 +499,35 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
   // check behind this kernel); store nothing, it will rebuild and launch again
   // ---- level 0: all loads addressed by p, issued back to back before any of them is used ----
   double4 ri = A.pos[p];
-  double a = vx[p], b = vy[p], c = vz[p];
+  // throughput shape: velocity and draws are only needed behind the neighbor loop; fetching them there keeps ten
+  // registers free across the loop (5 wavefronts per SIMD without spills)
+  constexpr bool LATE = !AHEAD && LATE_OWN_LOADS;
+  double a = 0.0, b = 0.0, c = 0.0;
+  if (!LATE) { a = vx[p]; b = vy[p]; c = vz[p]; }
   int t = 0;
-  if (LANGEVIN) t = tag[p];
+  if (LANGEVIN && !LATE) t = tag[p];
   const BeadPre L = bead_preload<HAS_PAIR, LPB, AHEAD>(A, p, sub);
   double4 hold = ri;
   if (AHEAD && NEXT && check) hold = xhold[p];
-  const int poisoned = flags[FLAG_NEIGH_OVERFLOW];
+  int poisoned = LATE ? 0 : flags[FLAG_NEIGH_OVERFLOW];
   // ---- level 1: the draws (by canonical rank), then - inside bead_force - the partners' positions ----
   uint32_t d0 = 0, d1 = 0, d2 = 0;
-  if (LANGEVIN && !(DIAG && (A.diag & 4))) {
+  if (!LATE && LANGEVIN && !(DIAG && (A.diag & 4))) {
     int rank = IDENT ? (t - 1) : crank[t];
     d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
   }
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
   double e[14];
   bead_force<false, HAS_PAIR, LPB, DIAG, AHEAD>(A, bt, box, s_tab, s_bt, p, sub, L, ri, f0, f1, f2, e, flags);
+  if (LATE) {
+    a = vx[p]; b = vy[p]; c = vz[p];
+    poisoned = flags[FLAG_NEIGH_OVERFLOW];
+    if (LANGEVIN) t = tag[p];
+    if (LANGEVIN && !(DIAG && (A.diag & 4))) {
+      int rank = IDENT ? (t - 1) : crank[t];
+      d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
+    }
+  }
   if (LPB > 1) {
 #pragma unroll
     for (int o = 1; o < LPB; o <<= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); }
@@ -601,7 +635,6 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   static int lim = getenv("LAMMPS_LE_NN_LIMIT") ? atoi(getenv("LAMMPS_LE_NN_LIMIT")) : (1 << 30);
   A.nn_limit = lim;
   A.maxrow = d.maxneigh - 1;
-  A.bprow = std::max(d.bpa, 1) - 1;
   A.diag = 0;
   A.sendslot = nullptr; A.sendbuf = nullptr; A.nsend0 = 0;
   {

@@ -278,7 +278,8 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
                                                        Box box, double cutneighsq, double margin,
                                                        const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
-                                                       int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
+                                                       int sf3, const int *__restrict__ bondtab, int bpa,
+                                                       int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags, int diag) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
@@ -347,8 +348,18 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   if (actmask == 0ull) return;
   if (diag & 8) { if (active) numneigh[s] = 0; return; }                       // lanes past the end of an otherwise live wavefront stay as helpers
   const int last = 63 - __clzll((long long)actmask);
-  int cnt = 0;
   const int maxneigh_w = (diag & 1) ? 0 : maxneigh;   // diagnostics: bit 0 = no entry stores, bit 1 = no candidate loops
+  // the bead's bonds open its list: (type, partner index) words of the bond-partner table k_bond_table has just written,
+  // compacted; the step kernel evaluates them inside its pipelined neighbor loop (kernels_md.hip pair_loop)
+  int cnt = 0;
+  if (active)
+    for (int k = 0; k < bpa; k++) {
+      const int e = bondtab[(size_t)k * npad + s];
+      if (e < 0) continue;
+      if (cnt < maxneigh_w) neigh[(size_t)cnt * npad + s] = e;
+      cnt++;
+    }
+  const int nbond = cnt;
   int x0 = cx - CELL_XSPLIT, x1 = cx + CELL_XSPLIT;   // x-cell range (>= cutneigh each way), may stick out of [0, ncx)
 #define RANGE_T(B, E, STG, SB)                                                                                    \
   do {                                                                                                            \
@@ -435,7 +446,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
 #undef RANGE
 #undef RANGE_T
   if (!active) return;
-  numneigh[s] = min(cnt, maxneigh);
+  numneigh[s] = min(cnt, maxneigh) | (min(nbond, maxneigh) << NN_BOND_SHIFT);
   // The longest list is only needed when a list did not fit (the host then grows the table to it).  Recording it
   // unconditionally - one atomicMax per wavefront on ONE address - serialises 15.6k read-modify-writes in a single
   // L2 channel: 170 us of a 255 us kernel at 1M beads.
@@ -452,9 +463,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
                                                        Box box, double cutneighsq, double margin,
                                                        const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
-                                                       int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
+                                                       int sf3, const int *__restrict__ bondtab, int bpa,
+                                                       int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags, int diag) {
-  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag);
+  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, neigh, numneigh, flags, diag);
 }
 // same body under a second name: LAMMPS_LE_DIAG_BUILD re-runs the build into scratch outputs with parts switched
 // off, so that a profile of a physically unchanged run shows what each part costs
@@ -468,9 +480,10 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh_diag(int n, int npad, int
                                                        Box box, double cutneighsq, double margin,
                                                        const int *__restrict__ nspecial,
                                                        const int *__restrict__ special, int ms, int sf1, int sf2,
-                                                       int sf3, int *__restrict__ neigh, int *__restrict__ numneigh,
+                                                       int sf3, const int *__restrict__ bondtab, int bpa,
+                                                       int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags, int diag) {
-  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, neigh, numneigh, flags, diag);
+  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, neigh, numneigh, flags, diag);
 }
 
 // phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
@@ -534,7 +547,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
-                     sf2, sf3, d.neigh, d.numneigh, d.flags, 0)
+                     sf2, sf3, d.bpart, d.bpa, d.neigh, d.numneigh, d.flags, 0)
     if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
     else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
     else if (sf1 == 0 && sf2 == 1 && sf3 == 1 && d.bpa >= 1 && d.bpa <= SPMAX && !getenv("LAMMPS_LE_NO_BPART_EXCL")) {
@@ -543,7 +556,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   hipLaunchKernelGGL((k_build_neigh<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, (const int *)nullptr, (const int *)d.bpart, d.bpa, sf1,  \
-                     sf2, sf3, d.neigh, d.numneigh, d.flags, 0)
+                     sf2, sf3, d.bpart, d.bpa, d.neigh, d.numneigh, d.flags, 0)
       BUILD_BP();
 #undef BUILD_BP
     } else BUILD(false, false);
@@ -552,7 +565,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
       hipLaunchKernelGGL((k_build_neigh_diag<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
                          d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],
                          d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,
-                         sf2, sf3, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
+                         sf2, sf3, d.bpart, d.bpa, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
     }
   }
 }
