@@ -23,6 +23,9 @@ constexpr int BLOCK = 256;
 #ifndef LATE_OWN_LOADS
 #define LATE_OWN_LOADS 0
 #endif
+#ifndef STEP_IDX_AHEAD
+#define STEP_IDX_AHEAD 1
+#endif
 #ifndef STEP_STAGE_W
 #define STEP_STAGE_W 4
 #endif
@@ -365,6 +368,13 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
 #pragma unroll
     for (int u = 0; u < W; u++) j[u] = (u < nn) ? col[u * npad] : p;
   }
+#if STEP_IDX_AHEAD == 2
+  // the indices run TWO stages ahead of the gathers (4 registers): a stage then waits for its gathers only, the index
+  // rows - streamed from HBM, the longest latency of the loop - have a whole stage more to arrive
+  int jn[W];
+#pragma unroll
+  for (int u = 0; u < W; u++) jn[u] = (W + u < nn) ? col[(size_t)(W + u) * npad] : p;
+#endif
   for (int k = 0; k < nn; k += W) {
     if (DIAGP && (A.diag & 8)) {          // diagnostics: same arithmetic, gathers replaced by coalesced loads
 #pragma unroll
@@ -381,9 +391,15 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
 #pragma unroll
       for (int u = 0; u < W; u++) r[u] = A.pos[j[u] & NEIGH_MASK];
     }
+#if STEP_IDX_AHEAD == 2
+    const int kn = k + 2 * W;
+#pragma unroll
+    for (int u = 0; u < W; u++) { c[u] = j[u]; j[u] = jn[u]; jn[u] = (kn + u < nn) ? col[(size_t)(kn + u) * npad] : p; }
+#else
     const int kn = k + W;
 #pragma unroll
     for (int u = 0; u < W; u++) { c[u] = j[u]; j[u] = (kn + u < nn) ? col[(size_t)(kn + u) * npad] : p; }
+#endif
     if (mixed) {
       // rolled over the slots (one copy of each body in the code; unrolled, the two bodies per slot cost ~20 registers)
 #pragma unroll 1
