@@ -12,11 +12,14 @@ namespace lmp_le {
 // (5.5 MB at 8M beads, more than an XCD's 4 MB L2).  tile = 0: plain z-major numbering (decomposed runs: the slab code
 // relies on ghosts from below / above forming the first / last cell layers).
 constexpr int ROW_TILE = 8;
+// (`tile` is 0 or ROW_TILE: the tiled branch divides by the compile-time constant - shifts; an integer division by a
+// run-time value is ~40 instructions, and the list build numbers 18 rows per bead)
 __device__ __forceinline__ int row_id(int ay, int az, int ncy, int ncz, int tile) {
   if (tile == 0) return az * ncy + ay;
-  const int ty = ay / tile, tz = az / tile;
-  const int hy = min(tile, ncy - ty * tile), hz = min(tile, ncz - tz * tile);
-  return tz * tile * ncy + ty * tile * hz + (az - tz * tile) * hy + (ay - ty * tile);
+  static_assert((ROW_TILE & (ROW_TILE - 1)) == 0, "ROW_TILE must be a power of two");
+  const int ty = (int)((unsigned)ay / (unsigned)ROW_TILE), tz = (int)((unsigned)az / (unsigned)ROW_TILE);
+  const int hy = min(ROW_TILE, ncy - ty * ROW_TILE), hz = min(ROW_TILE, ncz - tz * ROW_TILE);
+  return tz * ROW_TILE * ncy + ty * ROW_TILE * hz + (az - tz * ROW_TILE) * hy + (ay - ty * ROW_TILE);
 }
 // cell coordinates of a (wrapped) position.  z cells are counted from zlo_ext (the bottom of this rank's slab + ghost
 // shell; = box.lo[2] on one rank) with a periodic wrap, so owned and ghost beads of a slab land in one local grid.

@@ -179,20 +179,28 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, const int
 // physical indices (the bead's own special list is translated through map[] once), the minimum image is
 // branch-free and skipped by wavefronts that are wholly interior.  Entries come out in (row segment, index)
 // order, which depends only on the sorted positions -> deterministic.
+#ifndef BUILD_WAVES_PER_SIMD
+#define BUILD_WAVES_PER_SIMD 5
+#endif
+#ifndef BUILD_ILP
+#define BUILD_ILP 2
+#endif
 constexpr int STAGE_CAP = 192;   // float4 slots of one wavefront's staged row interval (2.5 KB)
 constexpr int SPMAX = 4;   // special entries THAT MATTER (weight != 1) translated to indices and kept in registers
+static_assert(SPMAX == 4, "neigh_range compares against spi[0..3]");
 
 // The distance test runs in FP32 on a float4 copy of the positions (half the bytes through the texture-address
 // path and a quarter of the FP64 issue cycles) and is DECISIVE outside an error band around cutneigh^2; inside the
 // band (a fraction ~1e-4 of the candidates) the FP64 test is repeated on the double positions, so the accepted set is
 // exactly the FP64 one.  (A variant that used FP32 only to reject, confirming every survivor in FP64, was slower:
 // some lane of a wavefront survives in almost every iteration, so both paths executed.)
-template <bool NOSPECIAL, bool MINIMG, bool ASYM, bool STAGED>
+template <bool NOSPECIAL, bool MINIMG, bool ASYM, bool STAGED, bool FRAC>
 __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const float4 *__restrict__ posf,
                                             float cutf, const double4 *__restrict__ pos,
                                             const int *__restrict__ tag, const Box &box, double cutneighsq, int n1,
                                             int n2, int kmax, int nrel, const int (&spi)[SPMAX],
-                                            const int (&spc)[SPMAX], const int *__restrict__ slist,
+                                            const int (&spc)[SPMAX],
+                                            const int *__restrict__ slist,
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
                                             int *__restrict__ neigh, const int *__restrict__ all_nspecial,
                                             const int *__restrict__ all_special, int ms_, int &cnt, float bandf,
@@ -202,7 +210,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
   const float px = (float)box.prd[0], py = (float)box.prd[1], pz = (float)box.prd[2];
   const float ipx = (float)box.iprd[0], ipy = (float)box.iprd[1], ipz = (float)box.iprd[2];
   const float cut_hi = cutf + bandf, cut_lo = cutf - bandf;
-  for (int q = b; q < e; q++) {
+  auto dist2 = [&](int q) {
     const float4 rf = STAGED ? stg[q - stg_base] : posf[q];
     float dxf = rix - rf.x, dyf = riy - rf.y, dzf = riz - rf.z;
     if (MINIMG) {
@@ -210,10 +218,17 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
       dyf -= py * __builtin_rintf(dyf * ipy);
       dzf -= pz * __builtin_rintf(dzf * ipz);
     }
-    float rsqf = dxf * dxf + dyf * dyf + dzf * dzf;
-    if (rsqf > cut_hi) continue;                // the common case costs one compare
-    bool reject = false;
-    if (rsqf >= cut_lo) {                       // inside the FP32 error band: repeat the test in FP64
+    return dxf * dxf + dyf * dyf + dzf * dzf;
+  };
+  // The loop body is straight-line, predicated code: a wavefront executes every statement of it for every candidate slot
+  // anyway (some lane survives the distance test in almost every trip), so what counts is the length of the one path, and
+  // nested `continue`s cost mask bookkeeping on top.  Only the rare cases branch: the FP64 re-test inside the error band,
+  // beads with more relevant special entries than fit in registers, the asymmetric-special-list variant.
+  int *out = neigh + (size_t)cnt * npad + s;     // running store address (one 64-bit add per stored entry)
+  for (int q = b; q < e; q++) {
+    const float rsqf = dist2(q);
+    bool keep = !(rsqf > cut_hi) && q != s;
+    if (keep && rsqf >= cut_lo) {               // inside the FP32 error band: repeat the test in FP64
       double4 rj = pos[q];
       double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
       if (MINIMG) {
@@ -222,53 +237,59 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
         delz -= box.prd[2] * __builtin_rint(delz * box.iprd[2]);
       }
       double rsq = delx * delx + dely * dely + delz * delz;
-      reject = rsq > cutneighsq;
+      keep = !(rsq > cutneighsq);
     }
-    if (reject || q == s) continue;
     int entry = q;
     bool own_list = true;
     if (!NOSPECIAL && ASYM) {
       // half-list semantics of the reference: the pair is stored under the lower local index (= lower ID at the
       // canonical order), so ITS special list decides (npair_half_bin_newtoff.cpp:90-108)
-      int ts = tag[s], tq = tag[q];
-      if (tq < ts) {
-        own_list = false;
-        const int *ql = all_special + (size_t)tq * ms_;
-        int q1 = all_nspecial[3 * (size_t)tq], q2 = all_nspecial[3 * (size_t)tq + 1], q3 = all_nspecial[3 * (size_t)tq + 2];
-        int which = 0;
-        for (int k = 0; k < q3; k++)
-          if (ql[k] == ts) { which = (k < q1) ? 1 : (k < q2) ? 2 : 3; break; }
-        if (which) {
-          int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
-          if (sf == 0) continue;
-          if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
+      if (keep) {
+        int ts = tag[s], tq = tag[q];
+        if (tq < ts) {
+          own_list = false;
+          const int *ql = all_special + (size_t)tq * ms_;
+          int q1 = all_nspecial[3 * (size_t)tq], q2 = all_nspecial[3 * (size_t)tq + 1], q3 = all_nspecial[3 * (size_t)tq + 2];
+          int which = 0;
+          for (int k = 0; k < q3; k++)
+            if (ql[k] == ts) { which = (k < q1) ? 1 : (k < q2) ? 2 : 3; break; }
+          if (which) {
+            int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
+            if (sf == 0) keep = false;
+            if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
+          }
         }
       }
     }
-    if (!NOSPECIAL && nrel > 0 && own_list) {
-      int code = 0;   // 0 = not special or weight 1; -1 = weight 0 (excluded); 1..3 = level with a fractional weight
-      if (nrel <= SPMAX) {
+    if (!NOSPECIAL) {
+      // special entries kept in registers (unused slots hold -1 and match nothing)
+      if (!FRAC) {   // no fractional special weight in this run: every kept entry is an exclusion (weight 0.0)
+        const bool hit = (spi[0] == q) | (spi[1] == q) | (spi[2] == q) | (spi[3] == q);
+        keep = keep && !(hit && own_list);
+      } else {
+        int code = 0;   // 0 = not special or weight 1; -1 = weight 0 (excluded); 1..3 = level with a fractional weight
 #pragma unroll
         for (int k = 0; k < SPMAX; k++) code = (spi[k] == q) ? spc[k] : code;
-      } else {
+        if (own_list) { keep = keep && code >= 0; if (code > 0) entry = q | (code << NEIGH_SB_SHIFT); }
+      }
+      if (nrel > SPMAX && own_list && keep) {   // too many for the registers: walk the bead's special list by tag
         int tq = tag[q];
         for (int k = 0; k < kmax; k++)
           if (slist[k] == tq) {
             int which = (k < n1) ? 1 : (k < n2) ? 2 : 3;
             int sf = (which == 1) ? sf1 : (which == 2) ? sf2 : sf3;
-            code = (sf == 0) ? -1 : (sf == 2) ? which : 0;
+            if (sf == 0) keep = false;
+            if (sf == 2) entry = q | (which << NEIGH_SB_SHIFT);
             break;
           }
       }
-      if (code < 0) continue;                        // weight 0.0: excluded from the list
-      if (code > 0) entry = q | (code << NEIGH_SB_SHIFT);
     }
-    if (cnt < maxneigh) neigh[(size_t)cnt * npad + s] = entry;
-    cnt++;
+    if (keep && cnt < maxneigh) *out = entry;
+    if (keep) { out += npad; cnt++; }
   }
 }
 
-template <bool NOSPECIAL, bool ASYM>
+template <bool NOSPECIAL, bool ASYM, bool FRAC>
 __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
                                                        const float4 *__restrict__ posf, float cutf, float bandf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
@@ -363,9 +384,9 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   int x0 = cx - CELL_XSPLIT, x1 = cx + CELL_XSPLIT;   // x-cell range (>= cutneigh each way), may stick out of [0, ncx)
 #define RANGE_T(B, E, STG, SB)                                                                                    \
   do {                                                                                                            \
-    if (all_in) neigh_range<NOSPECIAL, false, ASYM, STG>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, \
+    if (all_in) neigh_range<NOSPECIAL, false, ASYM, STG, FRAC>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, \
                                               sf1, sf2, sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
-    else neigh_range<NOSPECIAL, true, ASYM, STG>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
+    else neigh_range<NOSPECIAL, true, ASYM, STG, FRAC>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
                                       sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
   } while (0)
 #define RANGE(B, E) RANGE_T(B, E, false, 0)
@@ -453,8 +474,8 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   if (cnt > maxneigh) { flags[FLAG_NEIGH_OVERFLOW] = 1; atomicMax(&flags[FLAG_MAXNEIGH], cnt); }
 }
 
-template <bool NOSPECIAL, bool ASYM>
-__global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+template <bool NOSPECIAL, bool ASYM, bool FRAC>
+__global__ __launch_bounds__(BLOCK, BUILD_WAVES_PER_SIMD) void k_build_neigh(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
                                                        const float4 *__restrict__ posf, float cutf, float bandf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
                                                        const int *__restrict__ cell_start,
@@ -466,12 +487,12 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh(int n, int npad, int maxn
                                                        int sf3, const int *__restrict__ bondtab, int bpa,
                                                        int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags, int diag) {
-  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, neigh, numneigh, flags, diag);
+  build_body<NOSPECIAL, ASYM, FRAC>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, neigh, numneigh, flags, diag);
 }
 // same body under a second name: LAMMPS_LE_DIAG_BUILD re-runs the build into scratch outputs with parts switched
 // off, so that a profile of a physically unchanged run shows what each part costs
-template <bool NOSPECIAL, bool ASYM>
-__global__ __launch_bounds__(BLOCK) void k_build_neigh_diag(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+template <bool NOSPECIAL, bool ASYM, bool FRAC>
+__global__ __launch_bounds__(BLOCK, BUILD_WAVES_PER_SIMD) void k_build_neigh_diag(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
                                                        const float4 *__restrict__ posf, float cutf, float bandf,
                                                        const int *__restrict__ tag, const int *__restrict__ map,
                                                        const int *__restrict__ cell_start,
@@ -483,7 +504,7 @@ __global__ __launch_bounds__(BLOCK) void k_build_neigh_diag(int n, int npad, int
                                                        int sf3, const int *__restrict__ bondtab, int bpa,
                                                        int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags, int diag) {
-  build_body<NOSPECIAL, ASYM>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, neigh, numneigh, flags, diag);
+  build_body<NOSPECIAL, ASYM, FRAC>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, neigh, numneigh, flags, diag);
 }
 
 // phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
@@ -543,26 +564,25 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
     float cutf = (float)cutneighsq;
     float bandf = (float)(4.0 * 1.5 * cn * e_d + 3.0 * e_d * e_d + 1e-5 * cutneighsq);
     if (getenv("LAMMPS_LE_BUILD_FP64")) bandf = 1e30f;     // diagnostic: every candidate takes the FP64 test
-#define BUILD(NOSP, AS)                                                                                            \
-  hipLaunchKernelGGL((k_build_neigh<NOSP, AS>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
+    const bool frac = sf1 == 2 || sf2 == 2 || sf3 == 2;      // some special weight is neither 0 nor 1
+    // exclusions = bond partners (`special_bonds fene`-like flags, symmetric lists): read from the bond-partner table
+    const bool from_bpart = sf1 == 0 && sf2 == 1 && sf3 == 1 && d.bpa >= 1 && d.bpa <= SPMAX &&
+                            !d.flags_h[FLAG_SPECIAL_ASYM] && !getenv("LAMMPS_LE_NO_BPART_EXCL");
+    const int *nsp = from_bpart ? (const int *)nullptr : d.nspecial;
+    const int *spl = from_bpart ? (const int *)d.bpart : d.special;
+    const int msp = from_bpart ? d.bpa : d.maxspecial;
+#define BUILD(NOSP, AS, FR)                                                                                        \
+  hipLaunchKernelGGL((k_build_neigh<NOSP, AS, FR>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
-                     d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,  \
+                     d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, nsp, spl, msp, sf1,  \
                      sf2, sf3, d.bpart, d.bpa, d.neigh, d.numneigh, d.flags, 0)
-    if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false);
-    else if (d.flags_h[FLAG_SPECIAL_ASYM]) BUILD(false, true);     // sticky flag, read back at the last sync
-    else if (sf1 == 0 && sf2 == 1 && sf3 == 1 && d.bpa >= 1 && d.bpa <= SPMAX && !getenv("LAMMPS_LE_NO_BPART_EXCL")) {
-      // exclusions = bond partners: read them from the bond-partner table (see build_body)
-#define BUILD_BP()                                                                                                  \
-  hipLaunchKernelGGL((k_build_neigh<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
-                     d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
-                     d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, (const int *)nullptr, (const int *)d.bpart, d.bpa, sf1,  \
-                     sf2, sf3, d.bpart, d.bpa, d.neigh, d.numneigh, d.flags, 0)
-      BUILD_BP();
-#undef BUILD_BP
-    } else BUILD(false, false);
+    if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false, false);
+    else if (d.flags_h[FLAG_SPECIAL_ASYM]) { if (frac) BUILD(false, true, true); else BUILD(false, true, false); }   // sticky flag, read back at the last sync
+    else if (frac) BUILD(false, false, true);
+    else BUILD(false, false, false);
 #undef BUILD
     if (const char *dg = getenv("LAMMPS_LE_DIAG_BUILD")) {   // diagnostics: extra launch, entry stores off, scratch counters
-      hipLaunchKernelGGL((k_build_neigh_diag<false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
+      hipLaunchKernelGGL((k_build_neigh_diag<false, false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
                          d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],
                          d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,
                          sf2, sf3, d.bpart, d.bpa, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
