@@ -17,6 +17,11 @@ python3 profiles/summarize_pmc.py $O/pmc_write/p_counter_collection.csv k_step |
 python3 profiles/summarize_pmc.py $O/pmc_write/p_counter_collection.csv k_build | tee -a $O/pmc_write_summary.txt
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/prof8m -o f --output-format csv -- python3 bench.py --workload chain8m --cpu-steps 0 > $O/bench_chain8m.json 2>> $O/err.txt
 python3 profiles/summarize_stats.py $O/prof8m/f_kernel_stats.csv 8 | tee $O/kernel_stats_8m_top.txt
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch8m -o p --output-format csv -- python3 bench.py --workload chain8m --steps 50 --warmup 50 --cpu-steps 0 > $O/pmc_fetch8m.json 2>> $O/err.txt
+python3 profiles/summarize_pmc.py $O/pmc_fetch8m/p_counter_collection.csv k_step | tee $O/pmc_fetch8m_summary.txt
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write8m -o p --output-format csv -- python3 bench.py --workload chain8m --steps 50 --warmup 50 --cpu-steps 0 > $O/pmc_write8m.json 2>> $O/err.txt
+python3 profiles/summarize_pmc.py $O/pmc_write8m/p_counter_collection.csv k_step | tee $O/pmc_write8m_summary.txt
+rm -rf $O/pmc_fetch8m $O/pmc_write8m $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv
 rm -f $O/prof/f_kernel_trace.csv $O/prof8m/f_kernel_trace.csv $O/pmc_fetch/p_counter_collection.csv.bak
 ls -la $O $O/prof $O/pmc_fetch | head -40
 cat $O/bench_driver_args.json $O/bench_default.json $O/bench_chain8m.json
