@@ -400,7 +400,14 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
 #pragma unroll
     for (int u = 0; u < W; u++) { c[u] = j[u]; j[u] = (kn + u < nn) ? col[(size_t)(kn + u) * npad] : p; }
 #endif
-    if (mixed) {
+    if (mixed && AHEAD) {
+      // small systems (one wavefront's chain of dependent work is what counts, registers are plentiful): unrolled
+#pragma unroll
+      for (int u = 0; u < W; u++) {
+        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, c[u], r[u], fxi, fyi, fzi, e, flags); }
+        else pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c[u], r[u], k + u < nn, fxi, fyi, fzi, e);
+      }
+    } else if (mixed) {
       // rolled over the slots (one copy of each body in the code; unrolled, the two bodies per slot cost ~20 registers)
 #pragma unroll 1
       for (int u = 0; u < W; u++) {
