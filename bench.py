@@ -161,10 +161,32 @@ def main():
         return float(t.item())
 
     period = max(n1, nload)
+    # N > 1: the per-step halo can go through peer windows (the step kernel stores into the neighbour's IPC-mapped buffer,
+    # kernels_dd.hip) instead of a grouped RCCL exchange.  That path has only been validated between processes on ONE
+    # GPU, so the pre-roll runs it in verify mode - every window halo is also sent through RCCL and compared, RCCL's copy
+    # wins - and the timed run uses the windows only if every rank saw them used and not one value differ.
+    halo_mode = "rccl"
+    try_windows = world > 1 and os.environ.get("LAMMPS_LE_FAST_HALO", "1") != "0"
+    if try_windows:
+        os.environ["LAMMPS_LE_FAST_HALO"] = "1"
+        os.environ["LAMMPS_LE_FAST_HALO_VERIFY"] = "1"
     # ---- 1. pre-roll (untimed): off the start lattice, extruders on the chain ----
     pre = args.pre_roll if args.pre_roll >= 0 else 3 * period + 10
+    if try_windows:
+        pre = max(pre, 200)
     if pre > 0:
         lmp.command("run %d" % pre)
+    if try_windows:
+        used = -max_over_ranks(-lmp.stat("halo_window_exchanges"))          # min over ranks
+        bad = max_over_ranks(lmp.stat("halo_window_mismatches"))
+        os.environ["LAMMPS_LE_FAST_HALO_VERIFY"] = "0"
+        if used > 0 and bad == 0:
+            halo_mode = "peer windows (verified against the transport over %d exchanges of the pre-roll)" % int(used)
+        else:
+            os.environ["LAMMPS_LE_FAST_HALO"] = "0"
+            halo_mode = "rccl (peer windows %s)" % ("not available" if used <= 0 else "REJECTED: %d values differed" % int(bad))
+    if shm_rehearsal:
+        halo_mode = halo_mode.replace("rccl", "file mailbox")
     # ---- 2. warm-up (untimed) ----
     if args.warmup > 0:
         lmp.command("run %d" % args.warmup)
@@ -275,7 +297,7 @@ def main():
             "engine_loop_time_s": round(loop, 6), "wall_s": round(wall, 6), "value_wall": round(args.steps / wall, 2),
             "pre_roll_steps": pre, "timed_steps": [step_first, step_first + args.steps - 1],
             "neigh_builds": builds, "extruders": extruders, "le_firing": le_firing,
-            "loop_sections_s": sections, "rccl_nranks": rccl_nranks,
+            "loop_sections_s": sections, "rccl_nranks": rccl_nranks, "halo": halo_mode if world > 1 else None,
             "fene_warnings": int(lmp.stat("fene_warnings")),
         }
         print(json.dumps(out))

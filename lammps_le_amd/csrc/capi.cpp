@@ -8,6 +8,7 @@
 #include "comm.h"
 #include "device.h"
 
+namespace lmp_le { unsigned dd_halo_mismatches(DeviceState &d); }
 using namespace lmp_le;
 
 #define BEGIN_CAPTURE Engine *e = (Engine *)handle; try {
@@ -263,6 +264,8 @@ double lammps_le_stat(void *handle, const char *name) {
     return e->loop_time - all;
   }
   if (k == "comm_nranks") return e->comm ? (double)e->comm->nranks() : 1.0;
+  if (k == "halo_window_mismatches") return e->dev ? (double)dd_halo_mismatches(*e->dev) : 0.0;   // LAMMPS_LE_FAST_HALO_VERIFY
+  if (k == "halo_window_exchanges") return e->dev ? (double)e->dev->halo_seq : 0.0;   // per-step halos that went through the peer windows
   if (k == "pair_kernel_ms") return e->kstat_ms;
   if (k == "pair_kernel_launches") return (double)e->kstat_n;
   if (k == "neigh_pairs") return e->stat_neigh_pairs();

@@ -93,7 +93,9 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.le_scan, std::max(nt, (size_t)d.ncells + 2) / 1024 + 16);
 }
 
+void dd_fast_halo_free(DeviceState &d);   // kernels_dd.hip
 void dev_free(DeviceState &d) {
+  dd_fast_halo_free(d);
   if (d.rng_stream) {
     (void)hipStreamSynchronize(d.rng_stream);
     if (d.stream) (void)hipStreamSynchronize(d.stream);

@@ -43,7 +43,8 @@ enum FlagSlot {
 };
 enum DevErr {
   ERR_NONE = 0, ERR_BAD_FENE = 1, ERR_BOND_MISSING = 2, ERR_EXT_MULTI = 3, ERR_BPA = 4,
-  ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8, ERR_GHOST_ORDER = 9
+  ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8, ERR_GHOST_ORDER = 9,
+  ERR_HALO_TIMEOUT = 10
 };
 
 // Neighbor cells are cutneigh wide in y and z and cutneigh / CELL_XSPLIT wide in x (the fastest index of the cell
@@ -157,6 +158,21 @@ struct DeviceState {
   hipEvent_t ev_phase1 = nullptr, ev_halo = nullptr;
   bool halo_inflight = false;                           // ev_halo guards ghost slots that comm_stream is filling
   bool halo_ahead = false;                              // ghosts of the coming step were already exchanged
+  // Peer windows (kernels_dd.hip "fast halo"): the per-step halo as a side effect of the step kernel.  Every rank owns a
+  // window [parity 2][side 2: from below, from above][halo_cap] of positions plus two arrival counters; the neighbours
+  // map it (hipIpcOpenMemHandle, or the plain pointer when the ranks are threads of one process) and their step kernels
+  // store the new positions of their border beads straight into it, in this rank's sorted ghost order.
+  double4 *halo_win = nullptr;
+  unsigned *halo_flag = nullptr;                        // [2] arrival counters: [0] written by the rank below, [1] by the rank above
+  size_t halo_cap = 0;
+  double4 *peer_win[2] = {nullptr, nullptr};            // the windows of the rank below / above
+  unsigned *peer_flag[2] = {nullptr, nullptr};          // ... and the counter of theirs that is mine to write
+  void *peer_base[2] = {nullptr, nullptr};              // what hipIpcOpenMemHandle returned (to close), nullptr for plain pointers
+  bool fast_halo = false;                               // windows mapped AND switched on for this run (Engine::run re-reads the switch)
+  bool halo_mapped = false, halo_verify = false;
+  unsigned halo_seq = 0;                                // completed window exchanges (same on every rank)
+  int packed_peer = 0;                                  // the last step kernel stored into the neighbours' windows (parity + 1)
+  double halo_timeout_s = 120.0;
   int *gdest = nullptr;                                 // arrival order -> sorted ghost slot
   int *gtag_in = nullptr;                               // ghost tags in arrival order
   double *migbuf[2] = {nullptr, nullptr}, *migin = nullptr;   // migrating beads (MIG_W doubles each)

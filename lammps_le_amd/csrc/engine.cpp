@@ -15,6 +15,9 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
 void dd_halo(DeviceState &d, Comm &comm);
 void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, double4 *dst);
 void dd_halo_wait(DeviceState &d);
+void dd_fast_halo_setup(DeviceState &d, Comm &comm);
+void dd_fast_halo_switch(DeviceState &d);
+unsigned dd_halo_mismatches(DeviceState &d);
 void dd_gather_positions(DeviceState &d, Comm &comm);
 void dd_gather_all(DeviceState &d, Comm &comm, std::vector<double> &rows, int &stride);
 
@@ -173,7 +176,7 @@ void Engine::upload() {
   if (realloc) {
     if (d.pos) dev_free(d);
     dev_alloc(d, natoms, natoms, ntypes, bpa, maxspecial, box, cellcut);
-    if (d.dd) dd_alloc(d, world);
+    if (d.dd) { dd_alloc(d, world); dd_fast_halo_setup(d, *comm); }
     for (auto &f : fixes)
       if (auto *l = dynamic_cast<FixLangevin *>(f.get())) l->dev_ready = false;
   }
@@ -375,6 +378,7 @@ static void check_device_error(Engine *e, DeviceState &d) {
     case ERR_SPECIAL: msg = "New bond exceeded special list size in fix ex_load"; break;
     case ERR_COUNT_MISMATCH: msg = "Numbers of created and broken bonds are not equal"; break;
     case ERR_NONFINITE: msg = "Non-numeric atom coords - simulation unstable"; break;
+    case ERR_HALO_TIMEOUT: msg = "a neighbouring rank did not deliver its halo in time (peer window exchange)"; break;
     case ERR_SPECIAL_SCRATCH: msg = "Special list size exceeded in fix bond/create"; break;
     case ERR_GHOST_ORDER: msg = "internal: ghost blocks of a slab interleave (slab thinner than two ghost shells?)"; break;
   }
@@ -818,6 +822,7 @@ void Engine::run(long nsteps) {
   init();
   double tr1 = wall();
   if (!dev_current || !dev || !dev->pos) upload();
+  if (dev->dd) dd_fast_halo_switch(*dev);
   for (int k = 1; k <= 3; k++) dev->sflag[k] = special_flag(k);
   dev->ident_order = local_order_is_tag_order();
   dev->newton_pair = newton_pair ? 1 : 0;

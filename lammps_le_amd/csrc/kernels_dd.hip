@@ -9,6 +9,8 @@
 //     (x, y are fully periodic on every rank), so no shifted copies and no per-swap PBC arithmetic.
 //   * topology (bonds, specials, extruder table) is replicated and tag-indexed; only positions travel.
 //   * migration and ghost lists are rebuilt at reneighbor time on the device (flag + scan + scatter).
+#include <unistd.h>
+
 #include "comm.h"
 #include "device.h"
 
@@ -293,6 +295,151 @@ static void ensure_gather(DeviceState &d, size_t doubles_per_rank, int world) {
   d.gather_recv = d.gather_send + doubles_per_rank;      // (per call: the two gathers differ in their row width)
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Fast halo: the per-step forward communication (CommBrick::forward_comm, src/comm_brick.cpp:452-512) without a transport
+// call.  A grouped RCCL exchange costs ~25 us per step against a ~12 us step kernel at 125k beads per GPU; here the step
+// kernel of a rank stores the new positions of its border beads straight into the neighbours' windows (peer memory over
+// xGMI, mapped once per allocation through hipIpcOpenMemHandle), and what is left per step is one single-wavefront kernel
+// that publishes "my stores are complete" to both neighbours and waits for theirs, plus the copy of the window into the
+// ghost slots.  Protocol, per rank and exchange number s (parity s & 1; all ranks count the same exchanges):
+//   step kernel:  stores into the neighbours' window[s & 1]                     (it follows this rank's unpack of s - 1)
+//   k_halo_sync:  release-store s into my counter at each neighbour, then spin until both of my counters reach s
+//   unpack:       window[s & 1] -> ghost slots
+// A neighbour writes my window[s & 1] again only in exchange s + 2, after it has seen my counter s + 1, which I publish
+// after my unpack of s: one counter per direction orders both the data (read after write) and the reuse of the buffer.
+// The rebuild keeps its variable-size exchanges on the transport, which also fence the windows across a rebuild.
+// The spin is bounded (halo_timeout_s, the transports' own limit): every wave reaches its exit, a dead neighbour ends
+// in ERR_HALO_TIMEOUT -> LammpsError -> Comm::abort on this rank.
+__global__ __launch_bounds__(64) void k_halo_sync(unsigned *__restrict__ to_dn, unsigned *__restrict__ to_up,
+                                                  const unsigned *__restrict__ mine, unsigned seq, long long timeout_ticks,
+                                                  int *__restrict__ flags) {
+  if (threadIdx.x != 0) return;
+  __threadfence_system();
+  __hip_atomic_store(to_dn, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(to_up, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const long long t0 = wall_clock64();
+  for (int side = 0; side < 2; side++)
+    while ((int)(__hip_atomic_load(mine + side, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > timeout_ticks) { flags[FLAG_ERROR] = ERR_HALO_TIMEOUT; return; }
+    }
+}
+// window -> ghost slots [from below | from above]; the window is read with system-scope loads (never from a stale line)
+__global__ __launch_bounds__(BLOCK) void k_halo_unpack_win(int n0, int n1, const double4 *__restrict__ from_below,
+                                                           const double4 *__restrict__ from_above,
+                                                           double4 *__restrict__ ghost, int corrupt) {
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n0 + n1) return;
+  const unsigned long long *src = (const unsigned long long *)(i < n0 ? from_below + i : from_above + (i - n0));
+  unsigned long long w[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) w[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  double4 r;
+  r.x = __longlong_as_double((long long)w[0]); r.y = __longlong_as_double((long long)w[1]);
+  r.z = __longlong_as_double((long long)w[2]); r.w = __longlong_as_double((long long)w[3]);
+  if (corrupt && i == 0) r.x += 0.25;      // test hook (LAMMPS_LE_TEST_HALO_CORRUPT): the verify mode must notice and repair
+  ghost[i] = r;
+}
+
+// LAMMPS_LE_FAST_HALO_VERIFY=1: the same halo once more through the transport; differences are counted and the transport's
+// copy wins (a first multi-GPU run checks the windows against RCCL for as long as it likes before it relies on them)
+__global__ __launch_bounds__(BLOCK) void k_halo_verify(int m, double4 *__restrict__ ghost, const double4 *__restrict__ ref,
+                                                       unsigned *__restrict__ mismatches) {
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= m) return;
+  const double4 a = ghost[i], b = ref[i];
+  const bool same = __double_as_longlong(a.x) == __double_as_longlong(b.x) && __double_as_longlong(a.y) == __double_as_longlong(b.y) &&
+                    __double_as_longlong(a.z) == __double_as_longlong(b.z) && __double_as_longlong(a.w) == __double_as_longlong(b.w);
+  if (!same) { atomicAdd(mismatches, 1u); ghost[i] = b; }
+}
+
+struct PeerInfo {
+  long long pid;
+  unsigned long long raw;        // the window's address in its owner's address space (ranks that are threads of one process)
+  int exported;
+  int pad;
+  hipIpcMemHandle_t handle;
+};
+static size_t halo_flag_offset(size_t cap) { return 4 * cap * sizeof(double4); }
+constexpr int HALO_MISMATCH_SLOT = 16;    // (behind the two arrival counters, local use only)
+unsigned dd_halo_mismatches(DeviceState &d) {
+  unsigned v = 0;
+  if (d.halo_flag) HIP_CHECK(hipMemcpy(&v, d.halo_flag + HALO_MISMATCH_SLOT, sizeof v, hipMemcpyDeviceToHost));
+  return v;
+}
+
+// per run: LAMMPS_LE_FAST_HALO=0 keeps the mapped windows idle, LAMMPS_LE_FAST_HALO_VERIFY=1 checks every window halo against
+// the transport (same values on every rank: the exchanges are counted in step)
+void dd_fast_halo_switch(DeviceState &d) {
+  const char *env = getenv("LAMMPS_LE_FAST_HALO"), *ver = getenv("LAMMPS_LE_FAST_HALO_VERIFY");
+  d.fast_halo = d.halo_mapped && !(env && atoi(env) == 0);
+  d.halo_verify = ver && atoi(ver) != 0;
+  d.packed_peer = 0;
+}
+
+void dd_fast_halo_free(DeviceState &d) {
+  for (int k = 0; k < 2; k++) {
+    if (d.peer_base[k] && !(k == 1 && d.peer_base[1] == d.peer_base[0])) (void)hipIpcCloseMemHandle(d.peer_base[k]);
+    d.peer_base[k] = nullptr; d.peer_win[k] = nullptr; d.peer_flag[k] = nullptr;
+  }
+  if (d.halo_win) (void)hipFree(d.halo_win);
+  d.halo_win = nullptr; d.halo_flag = nullptr; d.halo_cap = 0;
+  d.fast_halo = d.halo_mapped = false; d.packed_peer = 0; d.halo_seq = 0;
+}
+
+// collective: allocate this rank's window, exchange its address / IPC handle, map the two neighbours' windows.
+// LAMMPS_LE_FAST_HALO=0 switches it off; with RCCL it is opt-in (=1) until it has run on a multi-GPU node.
+void dd_fast_halo_setup(DeviceState &d, Comm &comm) {
+  comm.barrier();                // nobody stores into a window that is about to go
+  dd_fast_halo_free(d);
+  const char *env = getenv("LAMMPS_LE_FAST_HALO");
+  // (not with the in-process transport: its ranks are threads whose streams share the few hardware queues of ONE process, and
+  //  a counter spin queued in front of the very kernel it waits for would never end)
+  const bool want = comm.backend == Comm::LOCAL ? false : env ? atoi(env) != 0 : comm.backend == Comm::SHM;
+  if (!want || comm.world < 2) return;
+  const int P = comm.world, me = comm.rank, nbr[2] = {(me + P - 1) % P, (me + 1) % P};
+  d.halo_cap = (size_t)d.npad;
+  const size_t bytes = halo_flag_offset(d.halo_cap) + 256;
+  long bad = 0;
+  PeerInfo mine{};
+  if (hipMalloc((void **)&d.halo_win, bytes) != hipSuccess) { (void)hipGetLastError(); d.halo_win = nullptr; bad = 1; }
+  if (!bad) {
+    HIP_CHECK(hipMemset(d.halo_win, 0, bytes));
+    HIP_CHECK(hipStreamSynchronize(nullptr));
+    d.halo_flag = (unsigned *)((char *)d.halo_win + halo_flag_offset(d.halo_cap));
+    mine.pid = (long long)getpid();
+    mine.raw = (unsigned long long)(uintptr_t)d.halo_win;
+    mine.exported = hipIpcGetMemHandle(&mine.handle, d.halo_win) == hipSuccess ? 1 : 0;
+    if (!mine.exported) (void)hipGetLastError();
+  }
+  std::vector<PeerInfo> all((size_t)P);
+  comm.allgather_host(&mine, all.data(), sizeof(PeerInfo));
+  for (int k = 0; k < 2 && !bad; k++) {
+    const PeerInfo &pi = all[(size_t)nbr[k]];
+    char *base = nullptr;
+    if (pi.raw == 0) bad = 1;
+    else if (pi.pid == mine.pid) base = (char *)(uintptr_t)pi.raw;
+    else if (k == 1 && nbr[1] == nbr[0]) base = (char *)d.peer_base[0];          // two ranks: one neighbour, mapped once
+    else if (pi.exported) {
+      void *ptr = nullptr;
+      if (hipIpcOpenMemHandle(&ptr, pi.handle, hipIpcMemLazyEnablePeerAccess) == hipSuccess) base = (char *)ptr;
+      else (void)hipGetLastError();
+      d.peer_base[k] = ptr;
+    }
+    if (k == 1 && nbr[1] == nbr[0]) d.peer_base[1] = d.peer_base[0];
+    if (!base) { bad = 1; break; }
+    d.peer_win[k] = (double4 *)base;
+    // my counter at the rank below is its "from above" one, at the rank above its "from below" one
+    d.peer_flag[k] = (unsigned *)(base + halo_flag_offset(d.halo_cap)) + (k == 0 ? 1 : 0);
+  }
+  bad = comm.allreduce_host_max(bad);           // all ranks or none
+  if (bad) { dd_fast_halo_free(d); return; }
+  d.halo_timeout_s = comm.timeout_s;
+  d.halo_mapped = true;
+  dd_fast_halo_switch(d);
+  comm.barrier();
+}
+
 void dd_alloc(DeviceState &d, int world) {
   size_t np = d.npad;
   auto al = [](auto *&p, size_t bytes) {
@@ -326,6 +473,7 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   dd_halo_wait(d);
   d.halo_ahead = false;
   d.packed_ahead = false;
+  d.packed_peer = 0;       // (a halo the step kernel pushed into the neighbours' windows before a rebuild is never consumed)
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
   const double width = d.box.prd[2] / P;   // the SAME expression on every rank and in Engine::upload (owner of a bead)
   int n = d.n, nb = std::max(1, (n + BLOCK - 1) / BLOCK);
@@ -441,6 +589,37 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
 void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, double4 *dst) {
   const int P = comm.world, me = comm.rank, dn_rank = (me + P - 1) % P, up_rank = (me + 1) % P;
   int nsall = d.nsend[0] + d.nsend[1];
+  if (d.packed_peer) {     // the step kernel stored this halo into the neighbours' windows: counters, then window -> ghost slots
+    const int parity = d.packed_peer - 1;
+    const unsigned seq = d.halo_seq + 1u;
+    static int clock_khz = 0;
+    if (!clock_khz) {
+      int dev = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      if (hipDeviceGetAttribute(&clock_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || clock_khz <= 0) clock_khz = 100000;
+    }
+    const long long ticks = (long long)(d.halo_timeout_s * 1e3 * (double)clock_khz);
+    static const int corrupt = getenv("LAMMPS_LE_TEST_HALO_CORRUPT") ? 1 : 0;
+    hipLaunchKernelGGL(k_halo_sync, dim3(1), dim3(64), 0, st, d.peer_flag[0], d.peer_flag[1], d.halo_flag, seq, ticks, d.flags);
+    if (d.nghost)
+      hipLaunchKernelGGL(k_halo_unpack_win, dim3((d.nghost + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nrecv[0], d.nrecv[1],
+                         d.halo_win + (size_t)(parity * 2 + 0) * d.halo_cap, d.halo_win + (size_t)(parity * 2 + 1) * d.halo_cap,
+                         dst + d.n, corrupt);
+    d.halo_seq = seq;
+    d.packed_peer = 0;
+    if (d.halo_verify && nsall + d.nghost > 0) {
+      hipLaunchKernelGGL(k_dd_pack, dim3((std::max(nsall, 1) + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
+                         d.sendlist[0], d.sendlist[1], src, d.sendbuf);
+      comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
+                         {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank}},
+                    {{d.recvbuf + d.nrecv[0], (size_t)d.nrecv[1] * sizeof(double4), up_rank},
+                     {d.recvbuf, (size_t)d.nrecv[0] * sizeof(double4), dn_rank}});
+      if (d.nghost)
+        hipLaunchKernelGGL(k_halo_verify, dim3((d.nghost + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nghost, dst + d.n,
+                           d.recvbuf, d.halo_flag + HALO_MISMATCH_SLOT);
+    }
+    return;
+  }
   if (nsall && !d.packed_ahead)
     hipLaunchKernelGGL(k_dd_pack, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
                        d.sendlist[0], d.sendlist[1], src, d.sendbuf);

@@ -181,8 +181,7 @@ struct ForceArgs {
   int *cell_of, *cell_count, *cell_rank;
   // decomposed runs: border beads also write their new position into the halo send buffer (no pack launch per step)
   const int *sendslot;
-  double4 *sendbuf;
-  int nsend0;
+  double4 *send_dn, *send_up;   // the staging buffer's two halves, or the neighbours' windows (kernels_dd.hip, fast halo)
 };
 
 // reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp from the IEEE quotient 1/x; an IEEE divide is ~35 instructions)
@@ -578,7 +577,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
     pos_next[p] = ri;
     if (A.sendslot) {
       const int sl = A.sendslot[p];
-      if (sl >= 0) A.sendbuf[(sl & ((1 << 30) - 1)) + ((sl >> 30) ? A.nsend0 : 0)] = ri;
+      if (sl >= 0) ((sl >> 30) ? A.send_up : A.send_dn)[sl & ((1 << 30) - 1)] = ri;
     }
     if (check) {
       // Neighbor::check_distance.  Throughput shape: the float copy of the build-time positions (posf, 16 B, what the
@@ -659,7 +658,7 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.nn_limit = lim;
   A.maxrow = d.maxneigh - 1;
   A.diag = 0;
-  A.sendslot = nullptr; A.sendbuf = nullptr; A.nsend0 = 0;
+  A.sendslot = nullptr; A.send_dn = A.send_up = nullptr;
   {
     // posf = (float)xhold: a coordinate is off by <= M * 2^-24, a squared displacement d^2 <= skin^2/4 .. by
     // <= 2 * sqrt(3) * |d| * e + 3 e^2; |d| <= ~skin near the threshold.  Band = four times that bound.
@@ -690,8 +689,19 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
                  hipEvent_t ev_stop, int which, bool swap_buffers) {
   ForceArgs A = force_args(d, sl);
   if (d.dd && next && d.sendslot && !d.sendslot_fallback) {
-    A.sendslot = d.sendslot; A.sendbuf = d.sendbuf; A.nsend0 = d.nsend[0];
-    d.packed_ahead = true;
+    A.sendslot = d.sendslot;
+    if (d.fast_halo && d.direct_recv && which < 0) {
+      // the neighbours' windows, in their sorted ghost order: what I send down arrives there "from above" and vice versa
+      const int parity = (int)((d.halo_seq + 1u) & 1u);
+      A.send_dn = d.peer_win[0] + (size_t)(parity * 2 + 1) * d.halo_cap;
+      A.send_up = d.peer_win[1] + (size_t)(parity * 2 + 0) * d.halo_cap;
+      d.packed_peer = parity + 1;
+      d.packed_ahead = false;
+    } else {
+      A.send_dn = d.sendbuf; A.send_up = d.sendbuf + d.nsend[0];
+      d.packed_ahead = true;
+      d.packed_peer = 0;
+    }
   }
   // lanes per bead: 4 while the launch is latency-bound (few wavefronts per SIMD), 1 once it is throughput-bound
   static const int lpb_env = getenv("LAMMPS_LE_LPB") ? atoi(getenv("LAMMPS_LE_LPB")) : 0;

@@ -41,7 +41,9 @@ res = dict(x=lmp.gather("x"), v=lmp.gather("v"), image=lmp.gather("image"), type
            num_bond=lmp.gather("num_bond"), bond_type=lmp.gather("bond_type"), bond_atom=lmp.gather("bond_atom"),
            nspecial=lmp.gather("nspecial"), special=lmp.gather("special"),
            thermo=np.array([lmp.get_thermo(k) for k in ("temp", "epair", "emol", "etotal", "press", "bonds")]),
-           neigh_pairs=np.array([lmp.stat("neigh_pairs")]), builds=np.array([lmp.stat("neigh_builds")]))
+           neigh_pairs=np.array([lmp.stat("neigh_pairs")]), builds=np.array([lmp.stat("neigh_builds")]),
+           window_exchanges=np.array([lmp.stat("halo_window_exchanges")]),
+           window_mismatches=np.array([lmp.stat("halo_window_mismatches")]))
 for fid in ("loop", "loading", "unloading"):
     try:
         res["f_" + fid] = np.array([lmp.extract_fix(fid, 0, 1, 0), lmp.extract_fix(fid, 0, 1, 1)])

@@ -82,10 +82,14 @@ def bond_set(nb, bt, ba):
     return out
 
 
-@pytest.mark.parametrize("world,n,overlap", [(2, 6000, 0), (3, 20000, 0), (2, 6000, 1)])
-def test_md_across_slabs(tmp_path, world, n, overlap, monkeypatch):
-    """NVE + Langevin for 60 steps incl. reneighbors with migration across slab faces (one process per rank)."""
+@pytest.mark.parametrize("world,n,overlap,windows", [(2, 6000, 0, 1), (3, 20000, 0, 1), (2, 6000, 1, 1), (3, 20000, 0, 0)])
+def test_md_across_slabs(tmp_path, world, n, overlap, windows, monkeypatch):
+    """NVE + Langevin for 60 steps incl. reneighbors with migration across slab faces (one process per rank).  `windows`:
+    the per-step halo goes through the peer windows (the step kernel stores into the neighbour's IPC-mapped buffer) or
+    through the transport."""
     monkeypatch.setenv("LAMMPS_LE_OVERLAP", str(overlap))
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO", str(windows))
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO_VERIFY", "1" if world == 3 else "0")
     s = lattice_chain(n, nchains=2, seed=21)
     script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
         "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 30\nrun 60\n"
@@ -98,6 +102,30 @@ def test_md_across_slabs(tmp_path, world, n, overlap, monkeypatch):
     assert np.abs(r["thermo"][:5] - to[:5]).max() < 1e-9
     assert r["neigh_pairs"][0] == 2 * o.neigh_pairs()
     assert r["builds"][0] == o.neigh_builds()
+    # every step that did not rebuild exchanged its halo through the windows (not in overlap mode, which keeps the transport)
+    # (all of them but the steps that rebuild, the first step and the steps behind a thermo evaluation, whose positions do not
+    # come out of the fused step kernel)
+    nwin = int(r["window_exchanges"][0])
+    if windows and not overlap:
+        assert 60 - int(o.neigh_builds()) - 5 <= nwin <= 60, nwin
+        assert int(r["window_mismatches"][0]) == 0          # every window halo was also sent through the transport and compared
+    else:
+        assert nwin == 0
+
+
+def test_window_halo_verify_mode_repairs_a_corrupted_window(tmp_path, monkeypatch):
+    """LAMMPS_LE_FAST_HALO_VERIFY: a window halo that differs from the transport's copy is counted and replaced (the test hook
+    shifts one ghost per exchange by 0.25 sigma on every rank); the trajectory stays the oracle's."""
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO", "1")
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO_VERIFY", "1")
+    monkeypatch.setenv("LAMMPS_LE_TEST_HALO_CORRUPT", "1")
+    s = lattice_chain(6000, nchains=2, seed=21)
+    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 30\nrun 40\n"
+    o = run_oracle(script, s)
+    r = run_ranks(2, s, script, tmp_path)
+    assert np.abs(r["x"] - o.x()).max() < 1e-9
+    assert int(r["window_exchanges"][0]) > 20 and int(r["window_mismatches"][0]) == int(r["window_exchanges"][0])
 
 
 def test_le_fixes_across_slabs(tmp_path):
