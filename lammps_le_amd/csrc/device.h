@@ -194,7 +194,8 @@ void dev_alloc_neigh(DeviceState &d, int maxneigh);
 
 // integrate (kernels_md.hip)
 void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check);
-void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4], bool eflag, bool has_pair);
+void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4], bool eflag, bool has_pair, int parts = 3);
+void launch_flevel_copy(DeviceState &d, double *flevel, bool to_level, bool add);
 void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start = nullptr,
                  hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true);

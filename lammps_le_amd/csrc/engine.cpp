@@ -47,6 +47,7 @@ Engine::Engine(int argc, char **argv) {
 }
 
 Engine::~Engine() {
+  for (auto *&fl : respa_flevel) if (fl) { (void)hipFree(fl); fl = nullptr; }
   if (dev) {
     try { dev_free(*dev); } catch (...) {}
     delete dev;
@@ -785,6 +786,121 @@ void Engine::iterate(long nsteps) {
   stamp(T_PAIR);              // work still in flight when the host leaves the loop is the last step kernel
 }
 
+// ---------------------------------------------------------------------------------------------
+// run_style respa (src/respa.cpp).  Unfused kernels, one GPU; the per-level force arrays live by tag.
+// ---------------------------------------------------------------------------------------------
+static TypeTables level_tables(Engine *e, double step) {      // FixNVE::*_integrate_respa: dtf = 0.5 * step_respa[ilevel] * ftm2v
+  TypeTables tt{};
+  const double dtf = 0.5 * step * e->ftm2v;
+  for (int t = 1; t <= e->ntypes; t++) { tt.mass[t] = e->mass[t]; tt.dtfm[t] = dtf / e->mass[t]; }
+  return tt;
+}
+void Engine::respa_level_forces(int l) {                       // Respa::recurse, force part (:664-713): pair, then bond
+  const int parts = (respa_level_pair == l ? 1 : 0) | (respa_level_bond == l ? 2 : 0);
+  launch_force(*dev, bondtab, special_lj, false, pair_lj, parts);
+}
+void Engine::respa_setup() {                                   // Respa::setup (:369-468)
+  DeviceState &d = *dev;
+  const int top = respa_levels - 1;
+  respa_step[top] = dt;                                        // Respa::init :340-344
+  for (int l = top - 1; l >= 0; l--) respa_step[l] = respa_step[l + 1] / respa_loop[l];
+  const size_t need = 3 * (size_t)(d.maxtag + 2);
+  for (int l = 0; l <= top; l++) {
+    if (respa_flevel[l] && respa_flevel_n != need) { HIP_CHECK(hipFree(respa_flevel[l])); respa_flevel[l] = nullptr; }
+    if (!respa_flevel[l]) HIP_CHECK(hipMalloc((void **)&respa_flevel[l], need * sizeof(double)));
+    HIP_CHECK(hipMemsetAsync(respa_flevel[l], 0, need * sizeof(double), d.stream));
+  }
+  respa_flevel_n = need;
+  reneighbor();
+  neigh_builds = 0;
+  if (sortfreq > 0) emulate_atom_sort();
+  for (int l = 0; l <= top; l++) {
+    respa_level_forces(l);
+    launch_flevel_copy(d, respa_flevel[l], true, false);
+  }
+  FixLangevin *lg = the_langevin(this);
+  for (auto &f : fixes) f->setup();
+  if (lg) {   // FixLangevin::setup, respa branch (src/fix_langevin.cpp:372-378): into the outermost level's array
+    launch_flevel_copy(d, respa_flevel[top], false, false);
+    langevin_post_force(this, lg, false);
+    launch_flevel_copy(d, respa_flevel[top], true, false);
+  }
+  compute_forces(true);              // energies and virial of the initial state for the thermo line (forces are reloaded per level)
+  last_thermo = eval_thermo();
+  thermo_log.push_back(last_thermo);
+  print_thermo_header();
+  print_thermo(last_thermo);
+  write_dumps(ntimestep);
+}
+// Respa::recurse (:600-741).  `last`: every enclosing loop is in its last trip, i.e. the innermost move that follows is the
+// last of this timestep: its kernel also tests the skin/2 displacement the NEXT step's Neighbor::decide asks about (the
+// reference decides at the outermost level before any inner level has moved x, on the positions the last step left).
+void Engine::respa_recurse(int l, bool last) {
+  DeviceState &d = *dev;
+  const int top = respa_levels - 1;
+  const int nnve = count_nve(this);
+  const double triggersq = 0.25 * skin * skin;
+  FixLangevin *lg = the_langevin(this);
+  launch_flevel_copy(d, respa_flevel[l], false, false);                       // copy_flevel_f
+  const TypeTables ttl = level_tables(this, respa_step[l]);
+  for (int iloop = 0; iloop < respa_loop[l]; iloop++) {
+    const bool last_here = last && iloop == respa_loop[l] - 1;
+    stamp();
+    for (int k = 0; k < nnve; k++) {                                         // initial_integrate_respa (src/fix_nve.cpp:145-155)
+      if (l == 0) {
+        const bool will_check = last_here && k == nnve - 1 && neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
+        launch_initial_integrate(d, ttl, respa_step[0], triggersq, will_check);
+      } else launch_final_integrate(d, ttl);
+    }
+    if (l == top)                                                            // post_integrate_respa: outermost level only
+      for (auto &f : fixes) if (f->has_post_integrate) f->post_integrate();
+    stamp(T_MODIFY);
+    if (l == top && decide()) {
+      const bool sort_due = sortfreq > 0 && ntimestep >= nextsort;
+      stamp();
+      reneighbor();
+      if (sort_due) emulate_atom_sort();
+      stamp(T_NEIGH);
+    }
+    if (l) respa_recurse(l - 1, last_here);
+    stamp();
+    respa_level_forces(l);
+    stamp(T_PAIR);
+    if (l == top && lg) langevin_post_force(this, lg, false);                // post_force_respa (src/fix_langevin.cpp:576-579)
+    for (int k = 0; k < nnve; k++) launch_final_integrate(d, ttl);           // final_integrate_respa (src/fix_nve.cpp:159-163)
+    stamp(T_MODIFY);
+  }
+  launch_flevel_copy(d, respa_flevel[l], true, false);                        // copy_f_flevel
+}
+void Engine::respa_iterate(long nsteps) {                                    // Respa::run (:544-575)
+  DeviceState &d = *dev;
+  for (long it = 0; it < nsteps; it++) {
+    ntimestep++;
+    const bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
+    const bool restart_now = restart_every > 0 && ntimestep % restart_every == 0;
+    const bool dump_now = (!dumps.empty() && dump_due(ntimestep)) || restart_now;
+    respa_recurse(respa_levels - 1, true);
+    if (eflag || dump_now) {
+      stamp();
+      if (eflag) {
+        compute_forces(true);        // the step's energies / virial: pair at the outer, bond at the last inner evaluation = this state
+        last_thermo = eval_thermo();
+        thermo_log.push_back(last_thermo);
+        print_thermo(last_thermo);
+      }
+      // sum_flevel_f (:817-843): the total force of the step, for outputs that read it
+      launch_flevel_copy(d, respa_flevel[0], false, false);
+      for (int l = 1; l < respa_levels; l++) launch_flevel_copy(d, respa_flevel[l], false, true);
+      if (dump_now && !dumps.empty() && dump_due(ntimestep)) write_dumps(ntimestep);
+      if (restart_now) write_periodic_restart(ntimestep);
+      stamp(T_OUTPUT);
+    }
+  }
+  stamp();
+  stream_sync(d);
+  stamp(T_PAIR);
+}
+
 // "MPI task timing breakdown" of src/finish.cpp:318-370 (one task: min = avg = max, %varavg = 0).  Bond is part of the
 // Pair row here: pair and bond forces are ONE kernel (k_step / k_force), there is no boundary to stamp between them.
 void Engine::print_timing_breakdown(long nsteps) {
@@ -843,13 +959,14 @@ void Engine::run(long nsteps) {
   host_current = false;
   double t0 = 0.0;
   try {
-    setup();
+    if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
+    if (respa_levels > 0) respa_setup(); else setup();
     for (int k = 0; k < 8; k++) timers[k] = 0.0;     // Timer::init() comes after setup (src/run.cpp:176-181)
     dev->ev_used = 0;
     ktime_counter = 0;
     ktime_every = nsteps <= 64 ? 1 : 16;
     t0 = wall();
-    iterate(nsteps);
+    if (respa_levels > 0) respa_iterate(nsteps); else iterate(nsteps);
     loop_time = wall() - t0;
   } catch (...) {
     // a rank that leaves the loop on an error must not keep its peers inside a collective: tear the communicator down

@@ -120,8 +120,11 @@ FixExLoad::FixExLoad(Engine *e, const std::vector<std::string> &arg) {
       iarg += 3;
     } else if (arg[iarg] == "atype" || arg[iarg] == "dtype" || arg[iarg] == "itype") {
       if (iarg + 2 > arg.size()) throw LammpsError(ill);
-      if (inumeric(arg[iarg + 1]) != 0)
-        throw LammpsError("MI355X engine: fix " + style + " angle/dihedral/improper creation is not supported");
+      // fix_ex_load.cpp:108-122 parse the type; :236-254 (and MC/fix_bond_create.cpp:256-270) switch the creation of angles /
+      // dihedrals / impropers on only `if (atype && force->angle)`, i.e. when the script defined such a style.  This engine
+      // has no angle / dihedral / improper styles (the commands are refused), so the flag stays 0 exactly as in the reference
+      // for a script without them: the keyword is accepted and has no effect.
+      if (inumeric(arg[iarg + 1]) < 0) throw LammpsError(ill);
       iarg += 2;
     } else throw LammpsError(ill);
   }

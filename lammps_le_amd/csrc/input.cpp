@@ -701,7 +701,54 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
     }
   } else if (cmd == "run_style") {
     need(1);
-    if (arg[0] != "verlet") throw LammpsError("MI355X engine: run_style " + arg[0] + " is not supported (verlet only)");
+    if (arg[0] == "verlet") respa_levels = 0;
+    else if (arg[0] == "respa") {
+      // Respa::Respa (src/respa.cpp:47-262): N, N-1 loop factors, then keyword/level pairs (levels 1-based in the script)
+      const std::string ill = "Illegal run_style respa command";
+      std::vector<std::string> a(arg.begin() + 1, arg.end());
+      if (a.empty()) throw LammpsError(ill);
+      const int nl = inumeric(a[0]);
+      if (nl < 1) throw LammpsError("Respa levels must be >= 1");
+      if (nl > 8) throw LammpsError("MI355X engine: at most 8 respa levels");
+      if ((int)a.size() < nl) throw LammpsError(ill);
+      int loop[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+      for (int k = 1; k < nl; k++) { loop[k - 1] = inumeric(a[k]); if (loop[k - 1] <= 0) throw LammpsError(ill); }
+      int lb = -1, la = -1, ld = -1, li = -1, lp = -1, lk = -1;
+      for (size_t k = (size_t)nl; k < a.size(); k += 2) {
+        if (k + 2 > a.size()) throw LammpsError(ill);
+        const int lev = inumeric(a[k + 1]) - 1;
+        if (a[k] == "bond") lb = lev; else if (a[k] == "angle") la = lev; else if (a[k] == "dihedral") ld = lev;
+        else if (a[k] == "improper") li = lev; else if (a[k] == "pair") lp = lev; else if (a[k] == "kspace") lk = lev;
+        else if (a[k] == "inner" || a[k] == "middle" || a[k] == "outer" || a[k] == "hybrid")
+          throw LammpsError("MI355X engine: run_style respa " + a[k] + " (split pair forces) is not supported");
+        else throw LammpsError(ill);
+      }
+      if (lb == -1) lb = 0;                    // :169-177 defaults
+      if (la == -1) la = lb;
+      if (ld == -1) ld = la;
+      if (li == -1) li = ld;
+      if (lp == -1) lp = nl - 1;
+      if (lk == -1) lk = lp;
+      if (la < lb || ld < la || li < ld || lp < li || lk < lp || lb < 0 || lk >= nl)          // :218-224
+        throw LammpsError("Invalid order of forces within respa levels");
+      respa_levels = nl;
+      for (int k = 0; k < 8; k++) respa_loop[k] = loop[k];
+      respa_loop[nl - 1] = 1;
+      respa_level_bond = lb;
+      respa_level_pair = lp;
+      std::string msg = "Respa levels:\n";     // :198-214
+      for (int k = 0; k < nl; k++) {
+        msg += "  " + std::to_string(k + 1) + " =";
+        if (lb == k) msg += " bond";
+        if (la == k) msg += " angle";
+        if (ld == k) msg += " dihedral";
+        if (li == k) msg += " improper";
+        if (lp == k) msg += " pair";
+        if (lk == k) msg += " kspace";
+        msg += "\n";
+      }
+      say(msg);
+    } else throw LammpsError("MI355X engine: run_style " + arg[0] + " is not supported (verlet, respa)");
   } else if (cmd == "label") {
     need(1);
   } else if (cmd == "jump") {

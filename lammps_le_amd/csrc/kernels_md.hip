@@ -461,7 +461,8 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
 }
 
 // forces only (setup, thermo steps, runs without the standard nve+langevin pair of fixes)
-template <bool EFLAG, bool HAS_PAIR>
+// NOBOND: the bond entries at the head of the lists are skipped (run_style respa with pair and bond forces on different levels)
+template <bool EFLAG, bool HAS_PAIR, bool NOBOND = false>
 __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box box, double *__restrict__ fx,
                                                  double *__restrict__ fy, double *__restrict__ fz,
                                                  double *__restrict__ partial, int *__restrict__ flags) {
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
     double4 ri = A.pos[p];
     const BeadPre L = bead_preload<HAS_PAIR, 1, true>(A, p, 0);
     double fxi = 0.0, fyi = 0.0, fzi = 0.0;
-    bead_force<EFLAG, HAS_PAIR, 1, false, true>(A, bt, box, s_tab, s_bt, p, 0, L, ri, fxi, fyi, fzi, e, flags);
+    bead_force<EFLAG, HAS_PAIR, 1, NOBOND, true>(A, bt, box, s_tab, s_bt, p, 0, L, ri, fxi, fyi, fzi, e, flags);   // (DIAG = NOBOND: A.diag = 1 switches the bonds off)
     fx[p] = fxi; fy[p] = fyi; fz[p] = fzi;
   }
   if (EFLAG && lb < A.nblocks) block_reduce_store<14>(e, partial, lb, 0);
@@ -640,6 +641,23 @@ void launch_langevin(DeviceState &d, const TypeTables &tt, bool ident, bool fuse
   else { if (ident) LGV(false, true); else LGV(false, false); }
 #undef LGV
 }
+// run_style respa: FixRespa's per-level force arrays (src/fix_respa.cpp), kept by tag so that the cell sort of a rebuild
+// does not have to carry them; to_level: flevel[tag[p]] = f[p], else f[p] = flevel[tag[p]] (+= when `add`)
+__global__ __launch_bounds__(BLOCK) void k_flevel_copy(int n, const int *__restrict__ tag, double *__restrict__ fx,
+                                                       double *__restrict__ fy, double *__restrict__ fz,
+                                                       double *__restrict__ flevel, int to_level, int add) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n) return;
+  double *row = flevel + 3 * (size_t)tag[p];
+  if (to_level) { row[0] = fx[p]; row[1] = fy[p]; row[2] = fz[p]; }
+  else if (add) { fx[p] += row[0]; fy[p] += row[1]; fz[p] += row[2]; }
+  else { fx[p] = row[0]; fy[p] = row[1]; fz[p] = row[2]; }
+}
+void launch_flevel_copy(DeviceState &d, double *flevel, bool to_level, bool add) {
+  int nb = (d.n + BLOCK - 1) / BLOCK;
+  hipLaunchKernelGGL(k_flevel_copy, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.tag, d.f[0], d.f[1], d.f[2], flevel,
+                     to_level ? 1 : 0, add ? 1 : 0);
+}
 void launch_ke(DeviceState &d, const TypeTables &tt) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(k_ke, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2], tt, d.partial);
@@ -673,9 +691,24 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.cell_of = d.cell_of; A.cell_count = d.cell_count; A.cell_rank = d.tag_tmp;
   return A;
 }
-void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool eflag, bool has_pair) {
+// `parts`: 3 = pair + bond (the default), 1 = pair only, 2 = bond only, 0 = nothing (forces zeroed); run_style respa
+void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool eflag, bool has_pair, int parts) {
   ForceArgs A = force_args(d, sl);
   int grid = xcd_grid(A.nblocks);
+  if (!has_pair) parts &= 2;
+  if (parts != 3) {
+    if (parts == 0) {
+      for (int k = 0; k < 3; k++) HIP_CHECK(hipMemsetAsync(d.f[k], 0, (size_t)d.n * sizeof(double), d.stream));
+    } else if (parts == 2) {      // bonds only: straight from the bond-partner table
+      if (eflag) hipLaunchKernelGGL((k_force<true, false>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, d.f[0], d.f[1], d.f[2], d.partial, d.flags);
+      else hipLaunchKernelGGL((k_force<false, false>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, d.f[0], d.f[1], d.f[2], d.partial, d.flags);
+    } else {                      // pairs only
+      A.diag = 1;
+      if (eflag) hipLaunchKernelGGL((k_force<true, true, true>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, d.f[0], d.f[1], d.f[2], d.partial, d.flags);
+      else hipLaunchKernelGGL((k_force<false, true, true>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, d.f[0], d.f[1], d.f[2], d.partial, d.flags);
+    }
+    return;
+  }
 #define FRC(E, P)                                                                                            \
   hipLaunchKernelGGL((k_force<E, P>), dim3(grid), dim3(BLOCK), 0, d.stream, A, bt, d.box, d.f[0], d.f[1],   \
                      d.f[2], d.partial, d.flags)

@@ -74,6 +74,10 @@ struct leo {
   int nfix; leo_fix fix[MAXFIX];
   /* sort */
   int sortfreq; long nextsort;
+  /* run_style respa (src/respa.cpp): 0 levels = run_style verlet */
+  int respa_levels, respa_loop[8], respa_level_bond, respa_level_pair;
+  double respa_step[8];
+  double *flevel[8];      /* FixRespa's per-level force arrays (src/fix_respa.cpp), kept BY TAG: immune to pbc / sort permutations */
   /* run state */
   long ntimestep, beginstep, endstep;
   int thermo_every;
@@ -174,6 +178,7 @@ leo_t *leo_new(int natoms, int ntypes, int nbondtypes, int extra_bond, int extra
 void leo_free(leo_t *s) {
   if (!s) return;
   free(s->tag); free(s->type); free(s->img); free(s->x); free(s->v); free(s->f); free(s->xhold);
+  for (int l = 0; l < 8; l++) free(s->flevel[l]);
   free(s->num_bond); free(s->bond_type); free(s->bond_atom); free(s->nspecial); free(s->special);
   free(s->map); free(s->mass);
   free(s->eps); free(s->sig); free(s->cut); free(s->lj1); free(s->lj2); free(s->lj3); free(s->lj4);
@@ -343,6 +348,18 @@ void leo_neighbor(leo_t *s, double skin, int every, int delay, int check) {
   if (check >= 0) s->check = check;
 }
 void leo_atom_sort(leo_t *s, int sortfreq) { s->sortfreq = sortfreq; }
+/* run_style respa N loop_1 .. loop_{N-1} [bond L] [pair L] (src/respa.cpp:47-262: levels are 1-based in the script; defaults
+   bond -> innermost, pair -> outermost; `inner/middle/outer`, `hybrid`, angle.. are outside this path).  nlevels = 0: verlet */
+int leo_run_style_respa(leo_t *s, int nlevels, const int *loops, int level_bond, int level_pair) {
+  if (nlevels < 0 || nlevels > 8) return seterr(s, "Respa levels must be >= 1");
+  s->respa_levels = nlevels;
+  for (int l = 0; l + 1 < nlevels; l++) { if (loops[l] <= 0) return seterr(s, "Illegal run_style respa command"); s->respa_loop[l] = loops[l]; }
+  if (nlevels) s->respa_loop[nlevels - 1] = 1;
+  s->respa_level_bond = level_bond > 0 ? level_bond - 1 : 0;                      /* :169 */
+  s->respa_level_pair = level_pair > 0 ? level_pair - 1 : nlevels - 1;             /* :174-175 */
+  if (nlevels && s->respa_level_pair < s->respa_level_bond) return seterr(s, "Invalid order of forces within respa levels");   /* :221-224 */
+  return 0;
+}
 void leo_newton_pair(leo_t *s, int on) { s->newton_pair = on; }
 void leo_reset_timestep(leo_t *s, long step) { s->ntimestep = step; }
 void leo_thermo_every(leo_t *s, int n) { s->thermo_every = n; }
@@ -1330,9 +1347,123 @@ int leo_setup_forces(leo_t *s) {
   pair_compute(s, 1);
   return bond_compute(s, 1);
 }
+/* ===================== run_style respa (src/respa.cpp) ===================== */
+static void copy_flevel_f(leo_t *s, int l) {                       /* :793-815 */
+  for (int i = 0; i < s->n; i++) memcpy(s->f + 3 * i, s->flevel[l] + 3 * (size_t)(s->tag[i] - 1), 3 * sizeof(double));
+}
+static void copy_f_flevel(leo_t *s, int l) {                       /* :769-791 */
+  for (int i = 0; i < s->n; i++) memcpy(s->flevel[l] + 3 * (size_t)(s->tag[i] - 1), s->f + 3 * i, 3 * sizeof(double));
+}
+static void sum_flevel_f(leo_t *s) {                               /* :817-843: level 0 copied, the others added in order */
+  copy_flevel_f(s, 0);
+  for (int l = 1; l < s->respa_levels; l++)
+    for (int i = 0; i < s->n; i++)
+      for (int d = 0; d < 3; d++) s->f[3 * i + d] += s->flevel[l][3 * (size_t)(s->tag[i] - 1) + d];
+}
+/* FixNVE::initial_integrate_respa / final_integrate_respa (src/fix_nve.cpp:145-163): the innermost level moves x and v,
+   every other level only kicks v, each with its own level's step */
+static void nve_kick(leo_t *s, double step, int drift) {
+  double dtv = step, dtf = 0.5 * step * s->ftm2v;
+  for (int i = 0; i < s->n; i++) {
+    double dtfm = dtf / s->mass[s->type[i]];
+    for (int d = 0; d < 3; d++) {
+      s->v[3 * i + d] += dtfm * s->f[3 * i + d];
+      if (drift) s->x[3 * i + d] += dtv * s->v[3 * i + d];
+    }
+  }
+}
+static int respa_level_forces(leo_t *s, int l, int eflag) {          /* :673-713 (same order as Verlet: pair, then bond) */
+  memset(s->f, 0, 3 * (size_t)s->n * sizeof(double));
+  double t0 = now();
+  if (s->respa_level_pair == l) pair_compute(s, eflag);
+  s->t_pair += now() - t0; t0 = now();
+  if (s->respa_level_bond == l && bond_compute(s, eflag)) return 1;
+  s->t_bond += now() - t0;
+  return 0;
+}
+static int respa_setup(leo_t *s) {                                 /* Respa::setup :369-468 */
+  const int top = s->respa_levels - 1;
+  s->respa_step[top] = s->dt;                                      /* Respa::init :340-344 */
+  for (int l = top - 1; l >= 0; l--) s->respa_step[l] = s->respa_step[l + 1] / s->respa_loop[l];
+  for (int l = 0; l <= top; l++) {
+    free(s->flevel[l]);
+    s->flevel[l] = (double *)calloc(3 * (size_t)(s->maxtag + 1), sizeof(double));
+  }
+  pbc(s);
+  if (s->sortfreq > 0) atom_sort(s);
+  neigh_build(s); s->nbuilds = 0;
+  if (s->errflag) return 1;
+  for (int l = 0; l <= top; l++) {
+    if (respa_level_forces(s, l, 1)) return 1;
+    copy_f_flevel(s, l);
+  }
+  sum_flevel_f(s);
+  /* modify->setup: FixLangevin::setup, respa branch (src/fix_langevin.cpp:372-378): the thermostat force goes into the
+     outermost level's array */
+  for (int k = 0; k < s->nfix; k++)
+    if (s->fix[k].kind == FIX_LANGEVIN) { copy_flevel_f(s, top); langevin_post_force(s, &s->fix[k]); copy_f_flevel(s, top); }
+  for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_BOND_CREATE) bond_create_setup(s, &s->fix[k]);
+  thermo_record(s);
+  return 0;
+}
+static int respa_recurse(leo_t *s, int l, int eflag) {              /* Respa::recurse :600-741 */
+  const int top = s->respa_levels - 1;
+  copy_flevel_f(s, l);
+  for (int iloop = 0; iloop < s->respa_loop[l]; iloop++) {
+    double t0 = now();
+    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_kick(s, s->respa_step[l], l == 0);
+    /* post_integrate_respa: the LE fixes act at the outermost level only (fix_extrusion.cpp:1139-1143, fix_ex_load.cpp:1283-1286,
+       fix_ex_unload.cpp:694-697, MC/fix_bond_create.cpp:1249-1252, MC/fix_bond_break.cpp:693-696:
+       `if (ilevel == nlevels_respa-1) post_integrate()`) */
+    if (l == top)
+      for (int k = 0; k < s->nfix; k++) {
+        leo_fix *fx = &s->fix[k];
+        if (fx->kind < FIX_EXTRUSION) continue;
+        if (s->ntimestep % fx->nevery - fx->phase) continue;
+        if (fire_fix(s, fx)) return 1;
+      }
+    s->t_modify += now() - t0;
+    if (l == top && neigh_decide(s)) {                              /* :616-651: decided BEFORE the inner levels move x */
+      t0 = now();
+      pbc(s);
+      if (s->sortfreq > 0 && s->ntimestep >= s->nextsort) atom_sort(s);
+      neigh_build(s);
+      s->t_neigh += now() - t0;
+      if (s->errflag) return 1;
+    }
+    if (l && respa_recurse(s, l - 1, eflag)) return 1;
+    if (respa_level_forces(s, l, eflag)) return 1;
+    t0 = now();
+    if (l == top)                                                   /* FixLangevin::post_force_respa (src/fix_langevin.cpp:576-579) */
+      for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_post_force(s, &s->fix[k]);
+    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_kick(s, s->respa_step[l], 0);
+    s->t_modify += now() - t0;
+  }
+  copy_f_flevel(s, l);
+  return 0;
+}
+static int respa_run(leo_t *s, int nsteps) {                       /* Respa::run :544-575 */
+  if (respa_setup(s)) return 1;
+  double tstart = now();
+  for (int it = 0; it < nsteps; it++) {
+    s->ntimestep++;
+    int eflag = (s->ntimestep == s->endstep) || (s->thermo_every > 0 && s->ntimestep % s->thermo_every == 0);
+    if (respa_recurse(s, s->respa_levels - 1, eflag)) return 1;
+    sum_flevel_f(s);
+    if (eflag) thermo_record(s);
+  }
+  s->t_total = now() - tstart;
+  return 0;
+}
+
 int leo_run(leo_t *s, int nsteps) {
   if (s->errflag) return 1;
   run_init(s);
+  if (s->respa_levels > 0) {
+    s->beginstep = s->ntimestep; s->endstep = s->ntimestep + nsteps;
+    s->t_pair = s->t_bond = s->t_neigh = s->t_modify = 0.0;
+    return respa_run(s, nsteps);
+  }
   s->beginstep = s->ntimestep; s->endstep = s->ntimestep + nsteps;
   s->t_pair = s->t_bond = s->t_neigh = s->t_modify = 0.0;
   if (verlet_setup(s)) return 1;

@@ -65,6 +65,7 @@ void   leo_bond_coeff(leo_t *s, int btype, int style, double p0, double p1, doub
 void   leo_timestep(leo_t *s, double dt);
 void   leo_neighbor(leo_t *s, double skin, int every, int delay, int check);
 void   leo_atom_sort(leo_t *s, int sortfreq);        /* atom_modify sort N 0 */
+int    leo_run_style_respa(leo_t *s, int nlevels, const int *loops, int level_bond, int level_pair);   /* 0 levels = verlet; level args 1-based, 0 = default */
 void   leo_newton_pair(leo_t *s, int on);            /* newton on|off for pairs: which end stores a pair (visit order of ex_load) */
 void   leo_reset_timestep(leo_t *s, long step);
 void   leo_thermo_every(leo_t *s, int n);            /* thermo N : record a thermo snapshot every N steps */

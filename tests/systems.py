@@ -142,6 +142,23 @@ class OracleScript:
                 o.newton_pair(self.newton_pair)
         elif c in ("atom_style", "comm_modify", "boundary", "thermo_style", "thermo_modify", "echo", "log"):
             pass
+        elif c == "run_style":
+            if o is None:
+                raise ValueError("oracle script: run_style before read_data")
+            if a[0] == "verlet":
+                o.run_style_respa(None)
+            elif a[0] == "respa":
+                n = int(a[1])
+                loops = [int(v) for v in a[2:1 + n]]
+                kw, k = {}, 1 + n
+                while k < len(a):
+                    if a[k] not in ("bond", "pair"):
+                        raise ValueError("oracle script: run_style respa keyword " + a[k])
+                    kw["level_" + a[k]] = int(a[k + 1])
+                    k += 2
+                o.run_style_respa(loops, **kw)
+            else:
+                raise ValueError("oracle script: run_style " + a[0])
         elif c == "atom_modify":
             if a[0] == "sort":
                 self.sort = int(a[1])
@@ -229,6 +246,11 @@ class OracleScript:
                         kw["jmax"], kw["jnew"] = int(p[k + 1]), int(p[k + 2])
                     elif p[k] == "prob":
                         kw["fraction"], kw["seed"] = float(p[k + 1]), int(p[k + 2])
+                    elif p[k] in ("atype", "dtype", "itype"):
+                        # fix_ex_load.cpp:236-254: effective only `if (atype && force->angle)`; these scripts define no
+                        # angle / dihedral / improper style, so the keyword has no effect in the reference either
+                        k += 2
+                        continue
                     k += 3
                 (o.fix_ex_load if style == "ex_load" else o.fix_bond_create)(int(p[0]), int(p[1]), int(p[2]), float(p[3]), int(p[4]), fid=fid, **kw)
             elif style in ("ex_unload", "bond/break"):

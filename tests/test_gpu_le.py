@@ -294,3 +294,64 @@ def test_le_fixes_refuse_newton_bond_on(tmp_path):
     s = melted(3000)
     with pytest.raises(LammpsError, match="newton_bond off"):
         run_product(le_script(left=1, right=1, lr="").replace("newton off", "newton on") + "run 1\n", s, tmp_path)
+
+
+def test_ex_load_atype_without_an_angle_style_has_no_effect(tmp_path):
+    """fix_ex_load.cpp:236-243: `atype` creates angles only when the script defined an angle style; without one (this
+    engine has none) the keyword is accepted and the run is the one without it."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 5))
+    base = le_script(tp=0.5) + "run 44\n"
+    with_kw = base.replace("iparam 1 1 jparam 1 1", "iparam 1 1 jparam 1 1 atype 1 dtype 0 itype 2")
+    assert with_kw != base
+    o = run_oracle(with_kw, s)
+    p = run_product(with_kw, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    q = run_product(base, s, tmp_path)
+    assert np.array_equal(p.gather("x"), q.gather("x")) and np.array_equal(p.gather("bond_atom"), q.gather("bond_atom"))
+    from lammps_le_amd import LammpsError
+    with pytest.raises(LammpsError, match="Illegal fix ex_load"):
+        run_product(base.replace("iparam 1 1 jparam 1 1", "iparam 1 1 jparam 1 1 atype -1"), s, tmp_path)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# run_style respa (SURVEY §8f-4): the LE fixes act through post_integrate_respa at the outermost level
+# (fix_extrusion.cpp:1139-1143, fix_ex_load.cpp:1283-1286, fix_ex_unload.cpp:694-697)
+RESPA_STYLES = ["run_style respa 1", "run_style respa 2 4", "run_style respa 3 2 2 bond 1 pair 3", "run_style respa 2 3 bond 2 pair 2"]
+
+
+@pytest.mark.parametrize("style", RESPA_STYLES)
+def test_le_cycle_under_respa(tmp_path, style):
+    """extrusion + ex_load + ex_unload with the r-RESPA integrator (bond forces on the inner level by default): topology,
+    special lists and fix counters bit-exact against the oracle's restatement of Respa::recurse, positions to 1e-9."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 5))
+    script = le_script(tp=0.5) + style + "\nrun 44\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    assert len([b for b in o.bond_set() if b[0] == 2]) > 5
+    assert p.stat("neigh_builds") == o.neigh_builds()
+
+
+def test_one_level_respa_is_verlet(tmp_path):
+    """`run_style respa 1` performs exactly the operations of run_style verlet in the same order (the single level both
+    moves x and carries every force): the two runs agree to the last bit, in the oracle and in the product."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 5))
+    base = le_script(tp=0.5)
+    ov, orr = run_oracle(base + "run 30\n", s), run_oracle(base + "run_style respa 1\nrun 30\n", s)
+    assert np.array_equal(ov.x(), orr.x()) and ov.bond_set() == orr.bond_set()
+    pv, pr = run_product(base + "run 30\n", s, tmp_path), run_product(base + "run_style respa 1\nrun 30\n", s, tmp_path)
+    # (the product's verlet path is the fused kernel, its respa path the unfused kernels: same arithmetic, same order)
+    assert np.abs(pv.gather("x") - pr.gather("x")).max() < 1e-10
+    assert np.array_equal(pv.gather("bond_atom"), pr.gather("bond_atom"))
+
+
+def test_respa_is_refused_where_it_is_not_supported(tmp_path):
+    from lammps_le_amd import LammpsError
+    s = melted(3000)
+    with pytest.raises(LammpsError, match="split pair forces"):
+        run_product(le_script(left=1, right=1, lr="") + "run_style respa 2 2 inner 1 0.8 1.0 outer 2\n", s, tmp_path)
+    with pytest.raises(LammpsError, match="Invalid order of forces"):
+        run_product(le_script(left=1, right=1, lr="") + "run_style respa 2 2 bond 2 pair 1\n", s, tmp_path)

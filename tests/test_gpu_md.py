@@ -77,6 +77,25 @@ def test_langevin_stream_parity(tmp_path):
     assert p.stat("neigh_builds") == o.neigh_builds()
 
 
+@pytest.mark.parametrize("style,sort", [("run_style respa 2 4", 0), ("run_style respa 3 2 3 bond 1 pair 2", 0),
+                                        ("run_style respa 2 2", 5)])
+def test_respa_trajectory_and_thermo(tmp_path, style, sort):
+    """r-RESPA (src/respa.cpp:600-741) with nve + langevin over two runs incl. rebuilds (decided at the outermost level on
+    the positions the previous step left) and, in the third case, Atom::sort: trajectory, every thermo line and the
+    rebuild count against the oracle."""
+    s = lattice_chain(5000, seed=11)
+    script = CHAIN_SCRIPT.replace("atom_modify sort 0 0", "atom_modify sort %d 0" % sort) + \
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 10\n" + style + "\nrun 40\nrun 25\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert relerr(p.gather("x"), o.x()) < 1e-9
+    assert relerr(p.gather("v"), o.v()) < 1e-8
+    to = o.thermo()
+    for k, key in enumerate(("temp", "epair", "emol", "etotal", "press")):
+        assert abs(p.get_thermo(key) - to[k]) < 1e-9 * max(1.0, abs(to[k])), key
+    assert p.stat("neigh_builds") == o.neigh_builds()
+
+
 @pytest.mark.parametrize("n", [3000, 70000])
 def test_velocity_create_between_runs(tmp_path, n):
     """`velocity all create` before the first run and again between two runs (the second call has to fetch the

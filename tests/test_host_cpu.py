@@ -399,3 +399,19 @@ run 120
     assert o.fix_vector("loading")[1] - o.fix_vector("unloading")[1] == len(ext)
     for i in range(n):                                                      # 1-2 block = bond partners
         assert sorted(sp[i, :ns[i, 0]]) == sorted(int(ba[i, m]) for m in range(nb[i])), i + 1
+
+
+def test_oracle_one_level_respa_is_verlet():
+    """Respa::recurse with a single level performs Verlet::run's operations in Verlet::run's order (src/respa.cpp:600-741 vs
+    src/verlet.cpp:240-353): the oracle's two integrators must agree to the last bit; more levels must not."""
+    from systems import CHAIN_SCRIPT, lattice_chain, run_oracle
+    s = lattice_chain(600, nchains=1, seed=3)
+    base = CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 10\n"
+    a = run_oracle(base + "run 40\n", s)
+    b = run_oracle(base + "run_style respa 1\nrun 40\n", s)
+    assert np.array_equal(a.x(), b.x()) and np.array_equal(a.v(), b.v())
+    assert np.array_equal(np.array(a.thermo()), np.array(b.thermo()))
+    c = run_oracle(base + "run_style respa 2 4\nrun 40\n", s)
+    d = run_oracle(base + "run_style respa 3 2 2 bond 1 pair 3\nrun 40\n", s)      # an empty middle level changes nothing
+    assert 1e-6 < np.abs(a.x() - c.x()).max() < 0.1
+    assert np.abs(c.x() - d.x()).max() < 1e-9
