@@ -66,8 +66,18 @@ def test_errors_match_reference_messages(tmp_path):
     with pytest.raises(LammpsError, match="Illegal fix bond/break command"):
         lmp.command("fix bad2b all bond/break 1000 2 0.5 prob 1.5 1")
     lmp.command("run_style verlet")
-    with pytest.raises(LammpsError, match="run_style respa is not supported"):
-        lmp.command("run_style respa 2 2")
+    lmp.command("run_style respa 2 2")
+    with pytest.raises(LammpsError, match="Respa levels must be >= 1"):           # src/respa.cpp:57
+        lmp.command("run_style respa 0")
+    with pytest.raises(LammpsError, match="Illegal run_style respa command"):     # :60-64
+        lmp.command("run_style respa 3 2")
+    with pytest.raises(LammpsError, match="Invalid order of forces within respa levels"):   # :218-224
+        lmp.command("run_style respa 2 2 bond 2 pair 1")
+    with pytest.raises(LammpsError, match="run_style respa inner"):
+        lmp.command("run_style respa 2 2 inner 1 0.8 1.0 outer 2")
+    with pytest.raises(LammpsError, match="run_style verlet/split is not supported"):
+        lmp.command("run_style verlet/split")
+    lmp.command("run_style verlet")
     with pytest.raises(LammpsError, match="Unknown fix style"):
         lmp.command("fix bad3 all nvt temp 1 1 1")
     with pytest.raises(LammpsError, match="Fix langevin period must be > 0.0"):
