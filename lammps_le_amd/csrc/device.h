@@ -52,6 +52,8 @@ enum DevErr {
 // cover 2.25 instead of 3 cutoffs -> 25 % fewer candidates in the list build.
 constexpr int CELL_XSPLIT = 4;
 
+constexpr int LE_MAX_FIXES = 16;   // extrusion / ex_load / ex_unload / bond/create / bond/break instances with a device RanMars state each
+
 struct DeviceState {
   hipStream_t stream = nullptr;
   int n = 0;        // owned atoms
@@ -133,7 +135,7 @@ struct DeviceState {
   int *le_i[16] = {nullptr};       // integer scratch arrays [maxtag+2]
   double *le_d[2] = {nullptr};     // double scratch [maxtag+2]
   unsigned long long *le_bits = nullptr;
-  uint32_t *le_rng_state = nullptr;   // [3][100]: w[97], n_lo, n_hi per LE fix slot
+  uint32_t *le_rng_state = nullptr;   // [LE_MAX_FIXES][100]: w[97], n_lo, n_hi per LE fix slot
   uint32_t *le_draws = nullptr;       // [maxtag+2]
   int *le_list = nullptr;             // extruder listings [4][maxtag+2]
   int *le_scan = nullptr;

@@ -223,7 +223,7 @@ void FixExtrusion::post_integrate() {
   if (eng->ntimestep % nevery - 1) return;               // src/USER-LE/fix_extrusion.cpp:265
   DeviceState &d = *eng->dev;
   int slot = le_slot(eng, this);
-  if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
+  if (slot >= LE_MAX_FIXES) throw LammpsError("MI355X engine supports at most " + std::to_string(LE_MAX_FIXES) + " extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
   if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob};
@@ -241,7 +241,7 @@ void FixExLoad::post_integrate() {
   if (eng->ntimestep % nevery - phase) return;           // src/USER-LE/fix_ex_load.cpp:338, src/MC/fix_bond_create.cpp:356
   DeviceState &d = *eng->dev;
   int slot = le_slot(eng, this);
-  if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
+  if (slot >= LE_MAX_FIXES) throw LammpsError("MI355X engine supports at most " + std::to_string(LE_MAX_FIXES) + " extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
   ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction};
   if (stock) {
@@ -265,7 +265,7 @@ void FixExUnload::post_integrate() {
   if (eng->ntimestep % nevery - phase) return;           // src/USER-LE/fix_ex_unload.cpp:178, src/MC/fix_bond_break.cpp:178
   DeviceState &d = *eng->dev;
   int slot = le_slot(eng, this);
-  if (slot >= 3) throw LammpsError("MI355X engine supports at most 3 extrusion/ex_load/ex_unload fixes");
+  if (slot >= LE_MAX_FIXES) throw LammpsError("MI355X engine supports at most " + std::to_string(LE_MAX_FIXES) + " extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
   if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
   ExUnloadParams p{btype, cutsq, fraction};

@@ -355,3 +355,17 @@ def test_respa_is_refused_where_it_is_not_supported(tmp_path):
         run_product(le_script(left=1, right=1, lr="") + "run_style respa 2 2 inner 1 0.8 1.0 outer 2\n", s, tmp_path)
     with pytest.raises(LammpsError, match="Invalid order of forces"):
         run_product(le_script(left=1, right=1, lr="") + "run_style respa 2 2 bond 2 pair 1\n", s, tmp_path)
+
+
+def test_five_le_fixes_at_once(tmp_path):
+    """More than one instance per LE style (two loaders with different seeds and periods, two unloaders, one extrusion): every
+    instance keeps its own RanMars stream and counters; bit-exact against the oracle."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 5))
+    script = le_script(tp=0.5) + \
+        "fix loading2 all ex_load 7 1 1 1.12 2 prob 0.4 91823 iparam 1 1 jparam 1 1\n" \
+        "fix unloading2 all ex_unload 13 2 0.8 prob 0.2 55113\nrun 64\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading", "loading2", "unloading2"))
+    assert o.fix_vector("loading2")[1] > 0 and o.fix_vector("unloading2")[1] > 0
