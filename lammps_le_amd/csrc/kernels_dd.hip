@@ -402,7 +402,18 @@ void dd_fast_halo_setup(DeviceState &d, Comm &comm) {
   const size_t bytes = halo_flag_offset(d.halo_cap) + 256;
   long bad = 0;
   PeerInfo mine{};
-  if (hipMalloc((void **)&d.halo_win, bytes) != hipSuccess) { (void)hipGetLastError(); d.halo_win = nullptr; bad = 1; }
+  // Uncached (else fine-grained) device memory, as RCCL allocates the buffers its peers write: a neighbour GPU stores into
+  // this window while kernels of this GPU are running, which ordinary (coarse-grained) device memory is only coherent
+  // for at kernel boundaries of ONE device - this GPU's L2 could keep serving a line of the previous exchange.
+  if (hipExtMallocWithFlags((void **)&d.halo_win, bytes, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    d.halo_win = nullptr;
+    if (hipExtMallocWithFlags((void **)&d.halo_win, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      d.halo_win = nullptr;
+      bad = 1;
+    }
+  }
   if (!bad) {
     HIP_CHECK(hipMemset(d.halo_win, 0, bytes));
     HIP_CHECK(hipStreamSynchronize(nullptr));
