@@ -20,12 +20,6 @@ constexpr int BLOCK = 256;
 // the throughput variant of k_step is bound by (resident wavefronts) / (lifetime of one wavefront): occupancy was
 // varied on purpose with unused LDS and 16 -> 12 -> 8 waves per CU cost x1.22 and x1.79.  Asking the compiler for five
 // waves per SIMD makes it fit 92 VGPRs without scratch (it takes 126 when left alone).
-#ifndef LATE_OWN_LOADS
-#define LATE_OWN_LOADS 0
-#endif
-#ifndef STEP_IDX_AHEAD
-#define STEP_IDX_AHEAD 1
-#endif
 #ifndef STEP_STAGE_W
 #define STEP_STAGE_W 4
 #endif
@@ -367,13 +361,6 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
 #pragma unroll
     for (int u = 0; u < W; u++) j[u] = (u < nn) ? col[u * npad] : p;
   }
-#if STEP_IDX_AHEAD == 2
-  // the indices run TWO stages ahead of the gathers (4 registers): a stage then waits for its gathers only, the index
-  // rows - streamed from HBM, the longest latency of the loop - have a whole stage more to arrive
-  int jn[W];
-#pragma unroll
-  for (int u = 0; u < W; u++) jn[u] = (W + u < nn) ? col[(size_t)(W + u) * npad] : p;
-#endif
   for (int k = 0; k < nn; k += W) {
     if (DIAGP && (A.diag & 8)) {          // diagnostics: same arithmetic, gathers replaced by coalesced loads
 #pragma unroll
@@ -390,15 +377,9 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
 #pragma unroll
       for (int u = 0; u < W; u++) r[u] = A.pos[j[u] & NEIGH_MASK];
     }
-#if STEP_IDX_AHEAD == 2
-    const int kn = k + 2 * W;
-#pragma unroll
-    for (int u = 0; u < W; u++) { c[u] = j[u]; j[u] = jn[u]; jn[u] = (kn + u < nn) ? col[(size_t)(kn + u) * npad] : p; }
-#else
     const int kn = k + W;
 #pragma unroll
     for (int u = 0; u < W; u++) { c[u] = j[u]; j[u] = (kn + u < nn) ? col[(size_t)(kn + u) * npad] : p; }
-#endif
     if (mixed && AHEAD) {
       // small systems (one wavefront's chain of dependent work is what counts, registers are plentiful): unrolled
 #pragma unroll
@@ -522,35 +503,22 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
   // check behind this kernel); store nothing, it will rebuild and launch again
   // ---- level 0: all loads addressed by p, issued back to back before any of them is used ----
   double4 ri = A.pos[p];
-  // throughput shape: velocity and draws are only needed behind the neighbor loop; fetching them there keeps ten
-  // registers free across the loop (5 wavefronts per SIMD without spills)
-  constexpr bool LATE = !AHEAD && LATE_OWN_LOADS;
-  double a = 0.0, b = 0.0, c = 0.0;
-  if (!LATE) { a = vx[p]; b = vy[p]; c = vz[p]; }
+  double a = vx[p], b = vy[p], c = vz[p];
   int t = 0;
-  if (LANGEVIN && !LATE) t = tag[p];
+  if (LANGEVIN) t = tag[p];
   const BeadPre L = bead_preload<HAS_PAIR, LPB, AHEAD>(A, p, sub);
   double4 hold = ri;
   if (AHEAD && NEXT && check) hold = xhold[p];
-  int poisoned = LATE ? 0 : flags[FLAG_NEIGH_OVERFLOW];
+  const int poisoned = flags[FLAG_NEIGH_OVERFLOW];
   // ---- level 1: the draws (by canonical rank), then - inside bead_force - the partners' positions ----
   uint32_t d0 = 0, d1 = 0, d2 = 0;
-  if (!LATE && LANGEVIN && !(DIAG && (A.diag & 4))) {
+  if (LANGEVIN && !(DIAG && (A.diag & 4))) {
     int rank = IDENT ? (t - 1) : crank[t];
     d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
   }
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
   double e[14];
   bead_force<false, HAS_PAIR, LPB, DIAG, AHEAD>(A, bt, box, s_tab, s_bt, p, sub, L, ri, f0, f1, f2, e, flags);
-  if (LATE) {
-    a = vx[p]; b = vy[p]; c = vz[p];
-    poisoned = flags[FLAG_NEIGH_OVERFLOW];
-    if (LANGEVIN) t = tag[p];
-    if (LANGEVIN && !(DIAG && (A.diag & 4))) {
-      int rank = IDENT ? (t - 1) : crank[t];
-      d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
-    }
-  }
   if (LPB > 1) {
 #pragma unroll
     for (int o = 1; o < LPB; o <<= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); }

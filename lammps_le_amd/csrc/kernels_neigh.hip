@@ -182,9 +182,6 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, const int
 #ifndef BUILD_WAVES_PER_SIMD
 #define BUILD_WAVES_PER_SIMD 5
 #endif
-#ifndef BUILD_ILP
-#define BUILD_ILP 2
-#endif
 constexpr int STAGE_CAP = 192;   // float4 slots of one wavefront's staged row interval (2.5 KB)
 constexpr int SPMAX = 4;   // special entries THAT MATTER (weight != 1) translated to indices and kept in registers
 static_assert(SPMAX == 4, "neigh_range compares against spi[0..3]");
