@@ -213,7 +213,7 @@ void launch_sort_owned(DeviceState &d, int m_in = -1, int n_out = -1, const int 
 void launch_lists(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
 
 // Atom::sort emulation (kernels_sort.hip): crank[tag] := rank in the reference's sorted local order
-void launch_atom_sort(DeviceState &d, const int nb[3], const double binv[3]);
+void launch_atom_sort(DeviceState &d, const int nb[3], const double binv[3], bool by_tag = false);
 void sort_scratch_free(DeviceState &d);
 
 // rng (kernels_rng.hip)

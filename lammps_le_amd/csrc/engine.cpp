@@ -158,7 +158,6 @@ void Engine::upload() {
   double cellcut = cutneighmax > 0.0 ? cutneighmax : std::max({box.prd[0], box.prd[1], box.prd[2]}) / 3.0;
   if (world > 1) {
     // z-slab decomposition: rank r owns z in [lo + r*w, lo + (r+1)*w); ghost shell = max(neighbor cutoff, comm cutoff)
-    if (sortfreq > 0) throw LammpsError("spatial decomposition needs atom_modify sort 0 0 (canonical draw order)");
     d.dd = 1;
     double w = box.prd[2] / world;
     d.slab_lo = box.lo[2] + rank * w;
@@ -489,7 +488,8 @@ void Engine::emulate_atom_sort() {
   if ((long)nb[0] * nb[1] * nb[2] == 1) return;
   // on the device (kernels_sort.hip): keys (bin, previous rank), radix sort, crank[tag] = new rank.  The host copy of
   // `crank` is refreshed by download().
-  launch_atom_sort(*dev, nb, binv);
+  if (world > 1) dd_gather_positions(*dev, *comm);      // decomposed: the one-rank order from everybody's wrapped positions
+  launch_atom_sort(*dev, nb, binv, world > 1);
   crank_on_device = true;
 }
 

@@ -490,13 +490,14 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
                  {d.box.lo[0], d.box.lo[1], d.box.lo[2]}, {d.ref_bininv[0], d.ref_bininv[1], d.ref_bininv[2]},
                  {d.ref_nbin[0], d.ref_nbin[1], d.ref_nbin[2]}, d.xht};
   int *tmp_a = d.le_i[I_F], *tmp_b = d.le_i[I_G];
-  if (d.dd) {
+  const bool id_order_scan = d.ident_order && !d.newton_pair;
+  if (d.dd && id_order_scan) {
     int *base_i = d.le_i[I_E];
     hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
     comm->allreduce_int_max(st, base_i, nt);       // the owner of bead a knows whether (a, a+2) is in its list
     hipLaunchKernelGGL(k_exload_bits, dim3(nbw), dim3(BLOCK), 0, st, nt, base_i, d.le_bits);
     hipLaunchKernelGGL((k_exload_partner<false>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
-  } else if (d.ident_order && !d.newton_pair) {
+  } else if (id_order_scan) {
     hipLaunchKernelGGL((k_exload_base<0>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], (int *)nullptr);
     hipLaunchKernelGGL((k_exload_partner<false>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], d.crank, partner, has);
   } else {
@@ -505,6 +506,7 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
     int *base_i = d.le_i[I_E], *state = tmp_a, *key = tmp_b;
     hipLaunchKernelGGL(k_exload_keys, dim3(nb), dim3(BLOCK), 0, st, T, V, key);
     hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
+    if (d.dd) comm->allreduce_int_max(st, base_i, nt);   // (keys and everything after are functions of replicated data: same rounds on every rank)
     hipLaunchKernelGGL(k_exload_greedy_init, dim3(nb), dim3(BLOCK), 0, st, nt, base_i, state);
     for (int batch = 0; batch < 4096; batch++) {
       HIP_CHECK(hipMemsetAsync(d.flags + FLAG_AUX, 0, sizeof(int), st));

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_keys(int n, const double4 *__res
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
   const double4 r = pos[p];
-  const int t = tag[p];
+  const int t = tag ? tag[p] : p + 1;       // (decomposed runs: `pos` is the gathered table by tag, entry p belongs to tag p + 1)
   // src/atom.cpp:2060-2071: ix = static_cast<int>((x - bboxlo) * bininv), clamped to [0, nbin - 1]
   int ix = (int)((r.x - box.lo[0]) * bix), iy = (int)((r.y - box.lo[1]) * biy), iz = (int)((r.z - box.lo[2]) * biz);
   ix = min(max(ix, 0), nbx - 1); iy = min(max(iy, 0), nby - 1); iz = min(max(iz, 0), nbz - 1);
@@ -60,8 +60,10 @@ void sort_scratch_free(DeviceState &d) {
 
 // crank[tag] := position of the bead in the reference's freshly sorted local order.  Positions must be the wrapped ones
 // of the reneighbor this sort belongs to (the caller runs it right behind Engine::reneighbor).
-void launch_atom_sort(DeviceState &d, const int nb[3], const double binv[3]) {
-  const int n = d.n;
+// `by_tag` (decomposed runs): every rank sorts ALL beads from the all-gathered positions by tag (d.xt, filled by
+// dd_gather_positions right before), so that the replicated `crank` is the one-rank order on every rank.
+void launch_atom_sort(DeviceState &d, const int nb[3], const double binv[3], bool by_tag) {
+  const int n = by_tag ? d.maxtag : d.n;
   SortScratch &s = scratch_of(d);
   if (s.cap < n) {
     for (int k = 0; k < 2; k++) {
@@ -79,7 +81,7 @@ void launch_atom_sort(DeviceState &d, const int nb[3], const double binv[3]) {
   int bits = 1;
   while (bits < 64 && ((nbins * ntot) >> bits) != 0ull) bits++;
   const int grid = (n + BLOCK - 1) / BLOCK;
-  hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(BLOCK), 0, d.stream, n, d.pos, d.tag, d.crank, d.box, nb[0], nb[1], nb[2],
+  hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(BLOCK), 0, d.stream, n, by_tag ? d.xt + 1 : d.pos, by_tag ? (const int *)nullptr : d.tag, d.crank, d.box, nb[0], nb[1], nb[2],
                      binv[0], binv[1], binv[2], ntot, s.keys[0], s.vals[0]);
   size_t need = 0;
   HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need, s.keys[0], s.keys[1], s.vals[0], s.vals[1], (size_t)n, 0u, (unsigned)bits, d.stream));

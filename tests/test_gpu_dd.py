@@ -189,6 +189,27 @@ def test_le_fixes_across_three_slabs_in_process(tmp_path, overlap, monkeypatch):
     assert np.abs(r["x"] - o.x()).max() < 1e-7
 
 
+def test_le_fixes_across_slabs_under_atom_sort(tmp_path):
+    """`atom_modify sort 5 0` on three slabs: every rank derives the one-rank Atom::sort order from the all-gathered positions
+    (the reference's own decomposed order depends on the decomposition; the engine's result is the 1-rank one), so Langevin
+    draws and the LE fixes' visit order follow the oracle's single-rank run: topology and counters bit-exact."""
+    n = 60000
+    s = melted(n, nchains=3, seed=9, types=barrier_types(n, 17))
+    base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 6.2") \
+        .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 10.0 6.0 1.0 1.0").replace("atom_modify sort 0 0", "atom_modify sort 5 0")
+    script = base + LE.format(n1=20, nl=10, nu=10, neutral=1, left=2, right=3, tp=0.5, lr="4",
+                              lprob="prob 0.5 684474", uprob="prob 0.3 456456", rmax=0.5) + "run 50\n"
+    o = run_oracle(script, s)
+    r = run_ranks_local(3, s, script, tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+    for fid in ("loop", "loading", "unloading"):
+        assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1]
+    assert np.abs(r["x"] - o.x()).max() < 1e-7
+    # the order matters in this scenario: the run with the ID order gives another topology
+    o0 = run_oracle(script.replace("atom_modify sort 5 0", "atom_modify sort 0 0"), s)
+    assert o0.bond_set() != o.bond_set()
+
+
 def test_script_commands_between_runs_when_decomposed(tmp_path):
     """Host-side commands between two runs of a decomposed system (three slabs, in process): `velocity create` replaces
     the velocities on every rank's replicated host copy (the download before it is collective), periodic restart files
