@@ -176,6 +176,7 @@ void Engine::upload() {
   if (realloc) {
     if (d.pos) dev_free(d);
     dev_alloc(d, natoms, natoms, ntypes, bpa, maxspecial, box, cellcut);
+    if (comm) comm->main_stream = d.stream;
     if (d.dd) { dd_alloc(d, world); dd_fast_halo_setup(d, *comm); }
     for (auto &f : fixes)
       if (auto *l = dynamic_cast<FixLangevin *>(f.get())) l->dev_ready = false;
