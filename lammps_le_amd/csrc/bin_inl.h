@@ -8,10 +8,13 @@ namespace lmp_le {
 // Numbering of the (y, z) rows of cells.  A row's x-cells are always consecutive cell ids (the list build and the cell
 // sort rely on one contiguous bead range per row); the ROWS are numbered in tiles of ROW_TILE x ROW_TILE instead of plain
 // z-major order, so that the beads a group of concurrently running workgroups needs - their own rows and the rows +-1 in
-// y and z - are a compact ~10 x 10 bundle of rows (1.3 MB of positions at 8M beads) instead of three whole z-layers
+// y and z - are a compact ~18 x 18 bundle of rows (2.6 MB of positions at 8M beads) instead of three whole z-layers
 // (5.5 MB at 8M beads, more than an XCD's 4 MB L2).  tile = 0: plain z-major numbering (decomposed runs: the slab code
 // relies on ghosts from below / above forming the first / last cell layers).
-constexpr int ROW_TILE = 8;
+#ifndef ROW_TILE_SIZE
+#define ROW_TILE_SIZE 16
+#endif
+constexpr int ROW_TILE = ROW_TILE_SIZE;   // measured at 8M beads: k_step 517 / 514 / 521 / 534 us for tiles of 8 / 16 / 32 / 64 rows (1M: no difference)
 // (`tile` is 0 or ROW_TILE: the tiled branch divides by the compile-time constant - shifts; an integer division by a
 // run-time value is ~40 instructions, and the list build numbers 18 rows per bead)
 __device__ __forceinline__ int row_id(int ay, int az, int ncy, int ncz, int tile) {

@@ -1,6 +1,7 @@
 // device.cpp — HBM allocation for one engine instance (288 GB per MI355X: everything stays resident).
 #include "comm.h"
 #include "device.h"
+#include "bin_inl.h"
 
 #include <algorithm>
 #include <atomic>
@@ -42,7 +43,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   d.box = box;
   d.ntotal = maxtag;
   if (!d.dd) d.zlo_ext = box.lo[2];
-  d.row_tile = (d.dd || getenv("LAMMPS_LE_NO_ROW_TILES")) ? 0 : 8;      // = ROW_TILE of bin_inl.h (row_id relies on it)
+  d.row_tile = (d.dd || getenv("LAMMPS_LE_NO_ROW_TILES")) ? 0 : ROW_TILE;      // (row_id relies on it being ROW_TILE or 0)
   size_t np = d.npad, nt = (size_t)maxtag + 2;
   dalloc(d.pos, np); dalloc(d.pos_tmp, np); dalloc(d.xhold, np); dalloc(d.posf, np);
   for (int k = 0; k < 3; k++) { dalloc(d.v[k], np); dalloc(d.v_tmp[k], np); dalloc(d.f[k], np); }

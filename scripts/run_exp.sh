@@ -14,6 +14,6 @@ suite asbuilt || exit 1
 IFS='|'
 for extra in $EXP_EXTRAS; do
   tagname=$(echo "$extra" | tr -c 'A-Za-z0-9=\n' '_')
-  (cd lammps_le_amd/csrc && rm -f kernels_md.o kernels_neigh.o && make EXTRA="$extra" > /dev/null 2>&1) && IFS=' ' suite "$tagname" || exit 1
+  (cd lammps_le_amd/csrc && rm -f *.o && make -j16 EXTRA="$extra" > /dev/null 2>&1) && IFS=' ' suite "$tagname" || exit 1
   IFS='|'
 done
