@@ -13,6 +13,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liblammps_le.so")
+if os.environ.get("LAMMPS_LE_LIBRARY"):      # development only: A/B runs of two builds of the engine (scripts/run_ab.sh)
+    _SO = os.path.abspath(os.environ["LAMMPS_LE_LIBRARY"])
 
 __all__ = ["lammps", "LammpsError", "library_path", "comm_unique_id", "init_from_torch_distributed"]
 
