@@ -369,3 +369,45 @@ def test_five_le_fixes_at_once(tmp_path):
     p = run_product(script, s, tmp_path)
     compare(p, o, ("loop", "loading", "unloading", "loading2", "unloading2"))
     assert o.fix_vector("loading2")[1] > 0 and o.fix_vector("unloading2")[1] > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# degenerate inputs of the LE fixes: nothing to do, everything to do, the shortest chains
+@pytest.mark.parametrize("case", ["no_loadable_type", "prob_zero", "unload_everything", "chains_of_three", "chains_of_four", "chains_of_five"])
+def test_le_fixes_degenerate_inputs(tmp_path, case):
+    """Empty and extreme cases against the oracle: no bead of the loadable type (the three fixes find nothing and the run is
+    plain MD), `prob 0.0` on the loader, an unloader that removes every extruder one step after it was loaded (`prob 1.0`,
+    `Rmax 0`), and systems of the shortest chains: with 3 or 4 beads every (i, i+2) pair contains a chain end, which cannot be
+    loaded, so nothing happens; 5 beads is the shortest chain that loads (its one admissible pair is next to both ends)."""
+    if case == "chains_of_three":
+        s = melted(3 * 700, nchains=700, seed=4)
+    elif case == "chains_of_four":
+        s = melted(4 * 600, nchains=600, seed=4)
+    elif case == "chains_of_five":
+        s = melted(5 * 500, nchains=500, seed=4)
+    else:
+        s = melted(3000)
+    kw = dict(left=1, right=1, lr="")
+    if case == "no_loadable_type":
+        s = dict(s)
+        s["type"] = np.full_like(s["type"], 2)
+        s["ntypes"] = max(int(s["ntypes"]), 2)
+        s["mass"] = list(s["mass"]) + [1.0] * (s["ntypes"] - len(s["mass"]))
+        script = le_script(neutral=1, **kw)
+    elif case == "prob_zero":
+        script = le_script(lprob="prob 0.0 684474", **kw)
+    elif case == "unload_everything":
+        script = le_script(uprob="prob 1.0 456456", rmax=0.0, nu=5, **kw)
+    else:
+        script = le_script(**kw)
+    script += "run 44\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    loads = o.fix_vector("loading")[1]
+    if case in ("no_loadable_type", "prob_zero", "chains_of_three", "chains_of_four"):
+        assert loads == 0 and not [b for b in o.bond_set() if b[0] == 2]
+    elif case == "unload_everything":
+        assert loads > 0 and o.fix_vector("unloading")[1] > 0
+    else:
+        assert loads > 0
