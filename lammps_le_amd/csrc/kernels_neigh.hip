@@ -180,9 +180,13 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, const int
 // branch-free and skipped by wavefronts that are wholly interior.  Entries come out in (row segment, index)
 // order, which depends only on the sorted positions -> deterministic.
 #ifndef BUILD_WAVES_PER_SIMD
-#define BUILD_WAVES_PER_SIMD 5
+#define BUILD_WAVES_PER_SIMD 6
 #endif
-constexpr int STAGE_CAP = 192;   // float4 slots of one wavefront's staged row interval (2.5 KB)
+#ifndef BUILD_STAGE_CAP
+#define BUILD_STAGE_CAP 128
+#endif
+constexpr int STAGE_CAP = BUILD_STAGE_CAP;   // float4 slots of one wavefront's staged row interval (2 KB).  128 slots and 80 VGPRs
+                                             // give 6 workgroups per CU: 127.5 vs 141 us per build for 192 slots / 88 VGPRs / 5 (96 slots: 135)
 constexpr int SPMAX = 4;   // special entries THAT MATTER (weight != 1) translated to indices and kept in registers
 static_assert(SPMAX == 4, "neigh_range compares against spi[0..3]");
 
@@ -425,10 +429,11 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
   int mb, me, B, E;
   bool fits;
   interval(0, mb, me, B, E, fits);
-  float4 t0, t1, t2;
+  float4 t0, t1, t2 = make_float4(0.f, 0.f, 0.f, 0.f);
   {
     const int lm = min(max(E - B - 1, 0), npad - 1 - B);      // (an interval that does not fit is not staged: stay in bounds)
-    t0 = posf[B + min(lane, lm)]; t1 = posf[B + min(lane + 64, lm)]; t2 = posf[B + min(lane + 128, lm)];
+    t0 = posf[B + min(lane, lm)]; t1 = posf[B + min(lane + 64, lm)];
+    if (STAGE_CAP > 128) t2 = posf[B + min(lane + 128, lm)];
   }
   for (int r = 0; r < 9; r++) {
     bool zskip;
@@ -438,14 +443,14 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
       const int len = E - B;
       if (lane < len) stg[lane] = t0;
       if (lane + 64 < len) stg[lane + 64] = t1;
-      if (lane + 128 < len) stg[lane + 128] = t2;
+      if (STAGE_CAP > 128 && lane + 128 < len) stg[lane + 128] = t2;
     }
     const int cmb = mb, cme = me, cB = B;
     const bool cfits = fits;
     if (r + 1 < 9) {   // next row: its interval is known (pass A), issue its loads now
       interval(r + 1, mb, me, B, E, fits);
       const int lm = min(max(E - B - 1, 0), npad - 1 - B);
-      if (!(diag & 64)) { t0 = posf[B + min(lane, lm)]; t1 = posf[B + min(lane + 64, lm)]; t2 = posf[B + min(lane + 128, lm)]; }
+      if (!(diag & 64)) { t0 = posf[B + min(lane, lm)]; t1 = posf[B + min(lane + 64, lm)]; if (STAGE_CAP > 128) t2 = posf[B + min(lane + 128, lm)]; }
     }
     __builtin_amdgcn_wave_barrier();                       // LDS ops of one wavefront execute in order
     if (cfits) { if (live) RANGE_T(cmb, cme, true, cB); }
