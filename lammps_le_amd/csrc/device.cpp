@@ -26,6 +26,8 @@ static void dfree(T *&p) {
 }
 
 void dev_alloc_neigh(DeviceState &d, int maxneigh) {
+  // (a bead's count word keeps the entries in 16 bits next to the number of bond entries: engine.h NN_BOND_SHIFT)
+  if (maxneigh > NN_COUNT_MASK) throw LammpsError("Neighbor list overflow: more than 65535 neighbors per bead");
   dfree(d.neigh);
   d.maxneigh = maxneigh;
   dalloc(d.neigh, (size_t)maxneigh * d.npad);
