@@ -138,8 +138,13 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
   const char *mode = getenv("LAMMPS_LE_RNG_MODE");
   d.rng_mode = (mode && !strcmp(mode, "block")) ? 0 : 1;
   if (d.rng_mode == 1) {
-    // calls per batch: as many wavefronts as hide each other's latency, bounded by 2 pools of W*3N draws <= 16 GiB
-    long long w = (16ll << 30) / (8 * total);
+    // calls per batch: as many wavefronts as hide each other's latency, bounded by 2 pools of W*3N draws <= 16 GiB.
+    // Decomposed runs: every rank generates the WHOLE stream (3 * N_total draws per call, one wavefront per call), while
+    // its steps get shorter with the rank count - at 8M beads a batch of 89 calls takes 59 ms, i.e. 1.5 calls per ms,
+    // the rate ONE GPU consumes them at; 64 GiB of pools (of 288) let 4x as many calls run side by side.  (Generating only
+    // the stream segments that hold a rank's own tags is the real fix: DESIGN.md section 6.)
+    const long long pool_cap = d.dd ? (64ll << 30) : (16ll << 30);
+    long long w = pool_cap / (8 * total);
     int W = (int)std::min<long long>(512, std::max<long long>(8, w));
     if (getenv("LAMMPS_LE_RNG_W")) W = std::max(2, atoi(getenv("LAMMPS_LE_RNG_W")));
     if (W != d.rng_W || total != d.rng_total) {
