@@ -114,7 +114,7 @@ struct DeviceState {
   // ---- Langevin RNG (block-parallel RanMars) ----
   int rng_B = 0, rng_nblocks = 0;
   uint32_t *rng_state = nullptr;   // [nblocks][97]
-  uint32_t *rng_jump = nullptr;    // [97] coefficients of x^(3N)
+  uint32_t *rng_jump = nullptr;    // coefficients of the jump polynomial(s): [97] block mode, [2][97] batch mode (full / last segment)
   uint32_t *rng_out = nullptr;     // [3N] 24-bit draws of the current call, canonical order
   uint32_t *rng_buf[2] = {nullptr, nullptr};   // double buffer: the next call's draws are generated on rng_stream
   int rng_cur = 0;
@@ -125,6 +125,8 @@ struct DeviceState {
   int rng_mode = 1;                // 1 = batch (k_rng_calls), 0 = block-parallel per call (k_rng_langevin)
   int rng_W = 0;
   long long rng_total = 0;         // draws per call = 3 * beads in the system
+  int rng_nseg = 1;                // batch generator: segments per call (one wavefront each) and their length
+  long long rng_seglen = 0;
   uint32_t *rng_wstate = nullptr;  // [W][97] window in front of each wave's next call
   uint32_t *rng_pool[2] = {nullptr, nullptr};   // [W][3N]
   uint64_t rng_batch_raw[2] = {0, 0};           // raw index of the first draw held by each pool (0 = empty)

@@ -70,38 +70,45 @@ __global__ __launch_bounds__(64) void k_rng_langevin(int B, long long total, uns
 // latency-bound trickle (one wave per block, ~1 KB LDS) that runs on rng_stream underneath the step kernels of
 // the previous batch; per consumed call nothing is launched at all.
 // ring index of y_i (i = draw index within this wave's call) is (i + 97) & 255.
-__global__ __launch_bounds__(64) void k_rng_calls(long long total, unsigned long long base_raw,
-                                                  uint32_t *__restrict__ wstate, const uint32_t *__restrict__ jump,
-                                                  uint32_t *__restrict__ pool) {
+__global__ __launch_bounds__(64) void k_rng_calls(long long total, long long seglen, int nseg,
+                                                  unsigned long long base_raw, uint32_t *__restrict__ wstate,
+                                                  const uint32_t *__restrict__ jump, uint32_t *__restrict__ pool) {
   __shared__ uint32_t ring[256];
   __shared__ uint32_t a[97];
   const int CM = 16777213, STEP64 = (int)((64ull * 7654321ull) % 16777213ull);
-  int w = blockIdx.x, lane = threadIdx.x;
-  uint32_t *st = wstate + (size_t)w * 97;
-  uint32_t *out = pool + (size_t)w * total;
-  unsigned long long raw0 = base_raw + (unsigned long long)w * (unsigned long long)total;
-  for (int k = lane; k < 97; k += 64) { ring[k] = st[k]; a[k] = jump[k]; }
+  // One wavefront per (call, segment): a call of 3N draws is cut into `nseg` segments of `seglen` draws (the last one
+  // shorter), each with its own 97-value window in front of its first draw, so that the generator's throughput does not
+  // hang on ONE wavefront per call when N is large (an 8M-bead call is 24 M dependent draws: 0.66 ms).
+  const int w = blockIdx.x / nseg, sg = blockIdx.x % nseg, lane = threadIdx.x;
+  const long long seg0 = (long long)sg * seglen;
+  const long long len = min(seglen, total - seg0);             // draws of this segment
+  uint32_t *st = wstate + (size_t)blockIdx.x * 97;
+  uint32_t *out = pool + (size_t)w * total + seg0;
+  unsigned long long raw0 = base_raw + (unsigned long long)w * (unsigned long long)total + (unsigned long long)seg0;
+  const uint32_t *jp = jump + (sg == nseg - 1 ? 97 : 0);        // the last segment is shorter: its own jump distance
+  for (int k = lane; k < 97; k += 64) { ring[k] = st[k]; a[k] = jp[k]; }
   __syncthreads();
   if (lane < 33) {   // draws 0..32 with the plain recurrence (the 64-wide form needs y_{i-130}, i >= 33)
     uint32_t y = (ring[lane] - ring[lane + 64]) & M24;
     ring[lane + 97] = y;
-    if (lane < total) __builtin_nontemporal_store((uint32_t)((y - c_of_dev(raw0 + lane)) & M24), &out[lane]);
+    if (lane < len) __builtin_nontemporal_store((uint32_t)((y - c_of_dev(raw0 + lane)) & M24), &out[lane]);
   }
   __syncthreads();
-  long long G = total + 96;   // 96 values past the end feed the jump below
+  long long G = len + 96;   // 96 values past the end feed the jump below
   int c = (int)c_of_dev(raw0 + 33ull + (unsigned long long)lane);
   for (long long base = 33; base < G; base += 64) {
     long long i = base + lane;
     int r = (int)(i & 255);
     uint32_t y = (ring[r] - ring[(r - 33) & 255] + ring[(r + 31) & 255]) & M24;   // y_{i-97} - y_{i-130} + y_{i-66}
     ring[(r + 97) & 255] = y;
-    if (i < total) __builtin_nontemporal_store((uint32_t)((y - (uint32_t)c) & M24), &out[i]);   // 6 GB per batch, read once 1..512 steps later: keep it out of the caches the step kernel lives in
+    if (i < len) __builtin_nontemporal_store((uint32_t)((y - (uint32_t)c) & M24), &out[i]);   // 6 GB per batch, read once 1..512 steps later: keep it out of the caches the step kernel lives in
     c -= STEP64;
     if (c < 0) c += CM;
     __syncthreads();
   }
-  // window (W-1) calls ahead: y'[k] = sum_j a[j] * y_{total - 97 + k + j}; ring index of y_{total-97+m} is (total+m)&255
-  int t0 = (int)(total & 255);
+  // window of the same segment W calls later: y'[k] = sum_j a[j] * y_{len - 97 + k + j} with a = x^(W*total - len);
+  // ring index of y_{len-97+m} is (len+m)&255
+  int t0 = (int)(len & 255);
   uint32_t acc0 = 0, acc1 = 0;
   int i1 = lane + 64;
   for (int j = 0; j < 97; j++) {
@@ -150,11 +157,22 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
     if (W != d.rng_W || total != d.rng_total) {
       rng_free_batch(d);
       d.rng_W = W; d.rng_total = total;
+      // segments per call: ~1024 wavefronts per batch, segments no shorter than 64k draws (measured: 8M beads 1389 / 1430 /
+      // 1437 / 1433 timesteps/s with 1 / 4 / 8 / 23 segments of W = 89 calls; 1M beads, W = 512: 12.20k / 12.24k / 11.93k with 1 / 2 / 4)
+      int S = (int)std::min<long long>(std::max<long long>(1, 1024 / W), std::max<long long>(1, total / 65536));
+      if (getenv("LAMMPS_LE_RNG_SEGMENTS")) S = std::max(1, atoi(getenv("LAMMPS_LE_RNG_SEGMENTS")));
+      if ((long long)S * 256 > total) S = 1;
+      d.rng_nseg = S;
+      d.rng_seglen = (total + S - 1) / S;
       for (int k = 0; k < 2; k++) HIP_CHECK(hipMalloc(&d.rng_pool[k], (size_t)W * total * sizeof(uint32_t)));
-      HIP_CHECK(hipMalloc(&d.rng_wstate, (size_t)W * 97 * sizeof(uint32_t)));
-      if (!d.rng_jump) HIP_CHECK(hipMalloc(&d.rng_jump, 97 * sizeof(uint32_t)));
-      uint32_t a[97];
-      ranmars_jump_poly((uint64_t)total * (uint64_t)(W - 1), a);
+      HIP_CHECK(hipMalloc(&d.rng_wstate, (size_t)W * S * 97 * sizeof(uint32_t)));
+      if (d.rng_jump) { (void)hipFree(d.rng_jump); d.rng_jump = nullptr; }
+      HIP_CHECK(hipMalloc(&d.rng_jump, 2 * 97 * sizeof(uint32_t)));
+      // a segment's window goes from the end of the segment to the start of the same segment W calls later
+      uint32_t a[2 * 97];
+      const long long len_last = total - (long long)(S - 1) * d.rng_seglen;
+      ranmars_jump_poly((uint64_t)total * (uint64_t)W - (uint64_t)d.rng_seglen, a);
+      ranmars_jump_poly((uint64_t)total * (uint64_t)W - (uint64_t)len_last, a + 97);
       HIP_CHECK(hipMemcpyAsync(d.rng_jump, a, sizeof a, hipMemcpyHostToDevice, d.stream));
       HIP_CHECK(hipStreamSynchronize(d.stream));
     }
@@ -203,8 +221,8 @@ static void rng_generate(DeviceState &d, int buf, uint64_t first_raw) {
 }
 static void rng_gen_batch(DeviceState &d, int pool, uint64_t base_raw, bool wait_consumed) {
   if (wait_consumed) HIP_CHECK(hipStreamWaitEvent(d.rng_stream, d.rng_consumed[pool], 0));
-  hipLaunchKernelGGL(k_rng_calls, dim3(d.rng_W), dim3(64), 0, d.rng_stream, d.rng_total, (unsigned long long)base_raw,
-                     d.rng_wstate, d.rng_jump, d.rng_pool[pool]);
+  hipLaunchKernelGGL(k_rng_calls, dim3(d.rng_W * d.rng_nseg), dim3(64), 0, d.rng_stream, d.rng_total, d.rng_seglen, d.rng_nseg,
+                     (unsigned long long)base_raw, d.rng_wstate, d.rng_jump, d.rng_pool[pool]);
   HIP_CHECK(hipEventRecord(d.rng_done[pool], d.rng_stream));
   d.rng_batch_raw[pool] = base_raw;
 }
@@ -215,19 +233,30 @@ static void rng_seed_batches(DeviceState &d, uint64_t first_raw) {
   RanMarsInt r = d.rng_origin;
   if (first_raw < r.n) throw LammpsError("internal: Langevin stream asked to go backwards");
   r.jump(first_raw - r.n);
-  uint32_t a[97], y[193];
-  ranmars_jump_poly((uint64_t)d.rng_total, a);
-  std::vector<uint32_t> st((size_t)d.rng_W * 97);
-  for (int w = 0; w < d.rng_W; w++) {
-    for (int k = 0; k < 97; k++) st[(size_t)w * 97 + k] = r.w[k];
-    if (w + 1 == d.rng_W) break;
-    std::memcpy(y, r.w, sizeof r.w);
+  uint32_t a[97], al[97], y[193];
+  ranmars_jump_poly((uint64_t)d.rng_total, a);          // call -> next call
+  ranmars_jump_poly((uint64_t)d.rng_seglen, al);        // segment -> next segment of the same call
+  auto jumped = [&](const uint32_t *win, const uint32_t *poly, uint32_t *res) {
+    std::memcpy(y, win, 97 * sizeof(uint32_t));
     for (int i = 97; i < 193; i++) y[i] = (y[i - 97] - y[i - 33]) & M24;
     for (int i = 0; i < 97; i++) {
       uint32_t acc = 0;
-      for (int j = 0; j < 97; j++) acc += a[j] * y[i + j];
-      r.w[i] = acc & M24;
+      for (int j = 0; j < 97; j++) acc += poly[j] * y[i + j];
+      res[i] = acc & M24;
     }
+  };
+  const int S = d.rng_nseg;
+  std::vector<uint32_t> st((size_t)d.rng_W * S * 97);
+  uint32_t cur[97], nxt[97];
+  for (int w = 0; w < d.rng_W; w++) {
+    std::memcpy(cur, r.w, sizeof cur);
+    for (int sg = 0; sg < S; sg++) {
+      std::memcpy(&st[((size_t)w * S + sg) * 97], cur, sizeof cur);
+      if (sg + 1 < S) { jumped(cur, al, nxt); std::memcpy(cur, nxt, sizeof cur); }
+    }
+    if (w + 1 == d.rng_W) break;
+    jumped(r.w, a, nxt);
+    std::memcpy(r.w, nxt, sizeof nxt);
   }
   HIP_CHECK(hipMemcpyAsync(d.rng_wstate, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.rng_stream));
   HIP_CHECK(hipStreamSynchronize(d.rng_stream));

@@ -64,9 +64,14 @@ def test_nve_trajectory(tmp_path):
     assert abs(p.get_thermo("etotal") - o.thermo()[3]) < 1e-9
 
 
-def test_langevin_stream_parity(tmp_path):
+@pytest.mark.parametrize("segments", [0, 3, 7])
+def test_langevin_stream_parity(tmp_path, segments, monkeypatch):
     """fix langevin: 3 RanMars draws per bead per call in canonical order, bit-exact stream; two runs
-    (each run calls setup() again and consumes another 3N draws, src/verlet.cpp:153)."""
+    (each run calls setup() again and consumes another 3N draws, src/verlet.cpp:153).  `segments`: the batch generator cuts
+    every call into that many independently generated pieces (one wavefront and one jumped window each, the last one
+    shorter; 0 = its own choice, one piece at this size) - the stream must not notice."""
+    if segments:
+        monkeypatch.setenv("LAMMPS_LE_RNG_SEGMENTS", str(segments))
     s = lattice_chain(5000, seed=11)
     script = CHAIN_SCRIPT + "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 20\nrun 40\nrun 30\n"
     o = run_oracle(script, s)
