@@ -66,6 +66,7 @@ WORKLOADS = {
     # like to every tag-indexed gather (the serpentine lattice start flatters them)
     "walk1m": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
     "walk100k": (100000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
+    "walk8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5, "walk", 0.01),        # chain8m from the scrambled start (the one that survives long runs)
 }
 
 

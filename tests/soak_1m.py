@@ -7,8 +7,12 @@ import os, sys, tempfile, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from lammps_le_amd import lammps
 from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
-n = 1000000
-sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
+n = int(os.environ.get("SOAK_BEADS", "1000000"))
+if os.environ.get("SOAK_GEN") == "walk":      # scrambled start (random Hamiltonian path inside every 10^3-site block)
+    from lammps_le_amd.synth import scrambled_chains
+    sysd = scrambled_chains(n, nchains=int(os.environ.get("SOAK_CHAINS", "1")), seed=1, barrier_every=200)
+else:
+    sysd = lattice_chains(n, nchains=int(os.environ.get("SOAK_CHAINS", "1")), seed=1, barrier_every=200)
 data = os.path.join(tempfile.mkdtemp(), "data")
 write_data(data, sysd)
 pload = float(sys.argv[1]) if len(sys.argv) > 1 else 0.01
