@@ -211,6 +211,15 @@ def test_le_fixes_across_slabs_under_atom_sort(tmp_path):
     assert o0.bond_set() != o.bond_set()
 
 
+def test_respa_is_refused_when_decomposed(tmp_path):
+    """run_style respa is the one-GPU slow path of unfused kernels: a decomposed run refuses it on every rank."""
+    s = lattice_chain(6000, nchains=2, seed=21)
+    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
+        "fix 1 all nve\nrun_style respa 2 2\nrun 5\n"
+    with pytest.raises(AssertionError, match="respa runs on one GPU only"):
+        run_ranks_local(2, s, script, tmp_path)
+
+
 def test_script_commands_between_runs_when_decomposed(tmp_path):
     """Host-side commands between two runs of a decomposed system (three slabs, in process): `velocity create` replaces
     the velocities on every rank's replicated host copy (the download before it is collective), periodic restart files
