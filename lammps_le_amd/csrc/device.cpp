@@ -55,6 +55,10 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.num_bond, nt); dalloc(d.bond_type, nt * bpa); dalloc(d.bond_atom, nt * bpa);
   dalloc(d.nspecial, nt * 3); dalloc(d.special, nt * (size_t)maxspecial);
   dalloc(d.num_bond0, nt); dalloc(d.bond_type0, nt * bpa); dalloc(d.bond_atom0, nt * bpa);
+  if (maxtag >= (1 << BOND_TYPE_SHIFT)) throw LammpsError("MI355X engine: atom IDs must stay below 2^26");
+  d.bond_pack_stride = ((1 + bpa) + 3) & ~3;
+  dalloc(d.bond_pack, nt * (size_t)d.bond_pack_stride);
+  d.bond_pack_dirty = true;
   // cells of edge >= cutneigh
   d.ncells = 1;
   for (int k = 0; k < 3; k++) {
@@ -110,7 +114,7 @@ void dev_free(DeviceState &d) {
   for (int k = 0; k < 3; k++) { dfree(d.v[k]); dfree(d.v_tmp[k]); dfree(d.f[k]); }
   dfree(d.tag); dfree(d.tag_tmp); dfree(d.img); dfree(d.img_tmp);
   dfree(d.map); dfree(d.type_t); dfree(d.crank);
-  dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special); dfree(d.num_bond0); dfree(d.bond_type0); dfree(d.bond_atom0);
+  dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special); dfree(d.num_bond0); dfree(d.bond_type0); dfree(d.bond_atom0); dfree(d.bond_pack);
   dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
   dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.pairtab); dfree(d.partial);
   if (d.partial_h) (void)hipHostFree(d.partial_h);

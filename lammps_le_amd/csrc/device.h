@@ -81,6 +81,11 @@ struct DeviceState {
   int *num_bond0 = nullptr, *bond_type0 = nullptr, *bond_atom0 = nullptr;
   int le_snapshot = 0;             // keep the snapshot (set when an LE fix exists)
   bool topo_dirty = true;          // bond tables changed since the snapshot was taken
+  // one record per tag {num_bond, (type << 26) | partner tag, ..} for the rebuild's bond-partner table: ONE line per bead
+  // instead of three (num_bond, bond_type row, bond_atom row) when tag order is not memory order; refreshed when dirty
+  int *bond_pack = nullptr;
+  int bond_pack_stride = 0;
+  bool bond_pack_dirty = true;
   // ---- cells / neighbor list ----
   int ncell[3] = {0, 0, 0}, ncells = 0;
   int row_tile = 0;          // (y, z) rows of cells numbered in tiles of this edge (bin_inl.h row_id); 0 = z-major (decomposed runs)

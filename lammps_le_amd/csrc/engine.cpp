@@ -955,6 +955,7 @@ void Engine::run(long nsteps) {
   dev->le_snapshot = 0;
   for (auto &f : fixes) if (f->force_reneighbor) dev->le_snapshot = 1;
   dev->topo_dirty = true;     // bond tables may have been edited between runs
+  dev->bond_pack_dirty = true;
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
   host_current = false;

@@ -229,6 +229,7 @@ void FixExtrusion::post_integrate() {
   ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob};
   launch_extrusion(d, p, slot);
   d.topo_dirty = true;
+  d.bond_pack_dirty = true;
   sync_flags(d);
   check_le_error(d, "extrusion");
   last_break = d.flags_h[FLAG_COUNT_A];
@@ -252,6 +253,7 @@ void FixExLoad::post_integrate() {
     launch_ex_load(d, p, slot, eng->comm);
   }
   d.topo_dirty = true;
+  d.bond_pack_dirty = true;
   sync_flags(d);
   check_le_error(d, style.c_str());
   last_create = d.flags_h[FLAG_COUNT_A];
@@ -271,6 +273,7 @@ void FixExUnload::post_integrate() {
   ExUnloadParams p{btype, cutsq, fraction};
   launch_ex_unload(d, p, slot);
   d.topo_dirty = true;
+  d.bond_pack_dirty = true;
   sync_flags(d);
   check_le_error(d, style.c_str());
   last_break = d.flags_h[FLAG_COUNT_A];

@@ -145,18 +145,22 @@ __global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *_
 struct BondTabArgs {
   int bpa, maxtag;
   const int *num_bond, *bond_type, *bond_atom;
+  const int *pack;         // packed records by tag (DeviceState::bond_pack), stride ints each
+  int stride;
   int *bpart;              // nullptr = nothing to do
   unsigned char *phase;
 };
 __device__ __forceinline__ void bond_table_row(int s, int n, int npad, int t, const int *__restrict__ map,
                                                const BondTabArgs &B, int *__restrict__ flags) {
-  int nb = B.num_bond[t];
+  const int *rec = B.pack + (size_t)t * B.stride;
+  int nb = rec[0];
   bool ghost = false;
   for (int m = 0; m < B.bpa; m++) {
     int e = -1;
     if (m < nb) {
-      int bt = B.bond_type[(size_t)t * B.bpa + m];
-      int u = B.bond_atom[(size_t)t * B.bpa + m];
+      const int w = rec[1 + m];
+      int bt = w >> BOND_TYPE_SHIFT;
+      int u = w & BOND_IDX_MASK;
       int q = (u >= 1 && u <= B.maxtag) ? map[u] : -1;
       if (q < 0) flags[FLAG_ERROR] = ERR_BOND_MISSING;
       else if (bt > 0) { e = (bt << BOND_TYPE_SHIFT) | q; ghost = ghost || q >= n; }
@@ -164,6 +168,18 @@ __device__ __forceinline__ void bond_table_row(int s, int n, int npad, int t, co
     B.bpart[(size_t)m * npad + s] = e;
   }
   if (B.phase && ghost) B.phase[s] = 1;     // reads a ghost position: phase 1 of a decomposed step
+}
+// packed bond records by tag (see DeviceState::bond_pack); run when the bond tables changed
+__global__ __launch_bounds__(BLOCK) void k_bond_pack(int maxtag, int bpa, int stride, const int *__restrict__ num_bond,
+                                                     const int *__restrict__ bond_type, const int *__restrict__ bond_atom,
+                                                     int *__restrict__ pack) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t < 1 || t > maxtag) return;
+  int *rec = pack + (size_t)t * stride;
+  const int nb = num_bond[t];
+  rec[0] = nb;
+  for (int m = 0; m < bpa; m++)
+    rec[1 + m] = (m < nb) ? ((max(bond_type[(size_t)t * bpa + m], 0) << BOND_TYPE_SHIFT) | (bond_atom[(size_t)t * bpa + m] & BOND_IDX_MASK)) : 0;   // (a type <= 0 is a bond that is switched off)
 }
 __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, const int *__restrict__ tag,
                                                       const int *__restrict__ map, BondTabArgs B,
@@ -549,7 +565,12 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
   if (nb == 0) nb = 1;
   hipStream_t st = d.stream;
-  BondTabArgs BT{d.bpa, d.maxtag, d.num_bond, d.bond_type, d.bond_atom, d.bpart, d.dd ? d.phase : nullptr};
+  if (d.bond_pack_dirty) {
+    hipLaunchKernelGGL(k_bond_pack, dim3((d.maxtag + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.maxtag, d.bpa, d.bond_pack_stride,
+                       d.num_bond, d.bond_type, d.bond_atom, d.bond_pack);
+    d.bond_pack_dirty = false;
+  }
+  BondTabArgs BT{d.bpa, d.maxtag, d.num_bond, d.bond_type, d.bond_atom, d.bond_pack, d.bond_pack_stride, d.bpart, d.dd ? d.phase : nullptr};
   // (a launch of its own: folded into the prologue of the list build it made that kernel 48 us slower to save 16, and
   // even the unused extra kernel argument cost the build 32 us)
   hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.tag, d.map, BT, d.flags);
