@@ -5,10 +5,18 @@ Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (
 velocity-Verlet timestep of the whole system (pair lj/cut + bond fene + fix nve + fix langevin + the three
 USER-LE fixes on their firing steps, reneighboring included), inputs resident in HBM when timing starts.
 
-Default workload = BASELINE.json configs[3] at N=1 (the configuration the north-star target is quoted on):
-a 1M-bead single chain at melt density (strong scaling over N GPUs as z-slabs), barrier beads every 200,
-`extrusion 1000` / `ex_load 1000 prob 0.01` / `ex_unload 1000 prob 0.01` (the dense LE parameter set BASELINE.md
-measured the reference with).
+Default workload `walk1m` = BASELINE.json configs[3] at N=1 (the configuration the north-star target is quoted on):
+a 1M-bead single chain at melt density from the SCRAMBLED start (a random Hamiltonian path inside every 10^3-site
+block: chain order is not memory order, as in a melt and as the reference's own generator tools/chain.f makes them;
+`--workload chain1m` is the serpentine-lattice start, which flatters every tag-indexed gather), strong scaling over N
+GPUs as z-slabs, barrier beads every 200, `extrusion 1000` / `ex_load 1000 prob 0.002` / `ex_unload 1000 prob 0.05`.
+BASELINE.md timed the reference with the dense set 0.01 / 0.01 over 2-4k steps; that set ends in `Bad FENE bond` in
+BOTH engines on long runs, so the line says `deviates_from_baseline` and `--workload chain1m_dense`
+keeps the dense set for comparison.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (one child process
+per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, nothing touches HIP in the parent), relays rank 0's JSON
+line and exits non-zero if any rank did; under `torch.distributed.run` it is one of the ranks as before.
 
 Order of a run (whatever K and W are, so that a 20-step line and a 2000-step line measure the same thing):
   1. untimed PRE-ROLL to a state that has left the start lattice and carries extruders (default: to step 3010, i.e.
@@ -80,16 +88,55 @@ def bonds_by_tag(lmp):
     return np.stack([bt[keep], own[keep], ba[keep]], axis=1).astype(np.int32)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: be the launcher.  N children, one per GPU, each a fresh process (the
+    parent never imports torch or touches HIP, and no process that has is ever re-exec'ed); rank 0 inherits stdout, so its
+    one JSON line is this command's output.  A rank that fails takes the others down (bounded: the engine's own
+    communicator time-out ends them, the parent only kills what is still there after a grace period).  Exit code =
+    first non-zero child code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, t_fail = 0, None
+    live = list(range(n))
+    while live:
+        time.sleep(0.2)
+        for r in list(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.remove(r)
+            if c != 0 and rc == 0:
+                rc, t_fail = c, time.time()
+                print("bench.py: rank %d exited with code %d" % (r, c), file=sys.stderr)
+        if t_fail is not None and live and time.time() - t_fail > 60.0:
+            for r in live:
+                procs[r].kill()           # exactly the children started above
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--workload", default="chain1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="walk1m", choices=sorted(WORKLOADS))
     ap.add_argument("--pre-roll", type=int, default=-1,
                     help="untimed steps before the warm-up (default: past three firings of every LE fix)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="oracle sample length (0 = skip the CPU baseline)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -197,7 +244,8 @@ def main():
     lmp.command("run %d" % args.steps)             # `run` = Verlet::setup + K steps, synchronised at the end
     barrier()
     wall = max_over_ranks(time.perf_counter() - t0)
-    loop = max_over_ranks(lmp.stat("loop_time"))   # the reference's Loop time: K steps, setup excluded
+    my_loop = lmp.stat("loop_time")
+    loop = max_over_ranks(my_loop)                 # the reference's Loop time: K steps, setup excluded
     step_first = int(lmp.get_thermo("step")) - args.steps + 1
     kms = lmp.stat("pair_kernel_ms")
     klaunches = int(lmp.stat("pair_kernel_launches"))
@@ -277,6 +325,16 @@ def main():
                          % (cpu_steps, nbeads, extruders, cwall),
                "split_pct": {k: round(100 * tm[k] / tm["total"], 1) for k in ("pair", "bond", "neigh", "modify")}}
 
+    # one record per rank: what it owned and how long its own loop and step kernel took (the line's value is the max)
+    mine = {"rank": rank, "owned_beads": int(nlocal), "ghost_beads": int(lmp.stat("nghost")),
+            "us_per_step": round(1e6 * my_loop / args.steps, 3), "k_step_us": round(1e3 * kms, 3),
+            "halo": halo_mode if world > 1 else None, "device": torch.cuda.current_device()}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    dense = (pload == 0.01 and punload == 0.01)
+
     if rank == 0:
         out = {
             "metric": "MD timesteps/sec, bead-spring LJ+FENE chain with loop extrusion",
@@ -300,6 +358,12 @@ def main():
             "neigh_builds": builds, "extruders": extruders, "le_firing": le_firing,
             "loop_sections_s": sections, "rccl_nranks": rccl_nranks, "halo": halo_mode if world > 1 else None,
             "fene_warnings": int(lmp.stat("fene_warnings")),
+            "per_rank": per_rank,
+            # BASELINE.md timed the reference with ex_load 0.01 / ex_unload 0.01 over 2-4k steps from the lattice start
+            "deviates_from_baseline": None if (dense and gen == "lattice") else
+            ", ".join(x for x in ("" if dense else "LE probabilities %g / %g instead of 0.01 / 0.01 (the dense set aborts with "
+                                  "`Bad FENE bond` on long runs in both engines, DESIGN.md 4)" % (pload, punload),
+                                  "" if gen == "lattice" else "scrambled (melt-like) start instead of the serpentine lattice") if x),
         }
         print(json.dumps(out))
     lmp.close()

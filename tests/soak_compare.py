@@ -1,17 +1,19 @@
 """Long-run behaviour of the dense LE parameter set on a mid-size system: product (GPU) or oracle (CPU), printing the
 extruder count, FENE warnings and temperature every 10 000 steps.  Trajectories diverge chaotically, so this is a
 statistical comparison (do both jam / abort the same way?), not a parity test.
-usage: soak_compare.py product|oracle [NBEADS] [BLOCKS] [PLOAD] [PUNLOAD]   (defaults: the dense set 0.01 / 0.01)"""
+usage: soak_compare.py product|oracle [NBEADS] [BLOCKS] [PLOAD] [PUNLOAD] [lattice|walk]   (defaults: the dense set 0.01 / 0.01,
+serpentine-lattice start; `walk` = the scrambled start of bench.py's default workload)"""
 import os, sys, tempfile, time
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
-from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
+from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, scrambled_chains, write_data
 which = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 pload = float(sys.argv[4]) if len(sys.argv) > 4 else 0.01
 punload = float(sys.argv[5]) if len(sys.argv) > 5 else pload
-sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
+gen = sys.argv[6] if len(sys.argv) > 6 else "lattice"
+sysd = (scrambled_chains if gen == "walk" else lattice_chains)(n, nchains=1, seed=1, barrier_every=200)
 data = os.path.join(tempfile.mkdtemp(), "data")
 write_data(data, sysd)
 script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=pload, punload=punload)

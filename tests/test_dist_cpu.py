@@ -52,3 +52,17 @@ def test_two_rank_gloo_plumbing(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert all("ok" in o for o in outs)
+
+
+def test_bench_self_launch_relays_failure():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks.  Without a GPU every rank stops
+    with the loud no-device message; the launcher must come back with a non-zero code instead of hanging or hiding it."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0",
+                        "--workload", "chain32k"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        return                      # on a GPU box the launch is covered by tests/test_gpu_dd.py
+    assert p.returncode != 0
+    assert b"needs a HIP device" in p.stderr and b"rank" in p.stderr
+    assert p.stdout.strip() == b""

@@ -350,3 +350,25 @@ def test_overlap_two_ranks_one_million_beads(tmp_path, monkeypatch):
     assert a[3] == one[3] > n - 1                # extruders were loaded, and as many as on one rank
     assert np.array_equal(a[1], one[1]) and np.array_equal(a[2], one[2])      # bit-exact topology
     assert np.abs(a[0] - one[0]).max() < 1e-6
+
+
+def test_bench_launches_its_own_ranks():
+    """`python3 bench.py --gpus 4` WITHOUT a launcher (how a driver may start the scaling run): the script
+    starts its four ranks itself, rank 0 prints the one JSON line, exit code 0.  Rehearsal transport (file mailbox, all
+    ranks on the test GPU), a 100k-bead system and a short pre-roll so that the test takes seconds, not minutes; the
+    full-size form of the same command is recorded under profiles/r03."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["LAMMPS_LE_BENCH_SHM"] = "1"
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "20", "--warmup", "5",
+                        "--workload", "walk100k", "--pre-roll", "1010"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.split("\n") if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["steps"] == 20 and out["value"] > 0
+    assert len(out["per_rank"]) == 4 and sorted(r["rank"] for r in out["per_rank"]) == [0, 1, 2, 3]
+    assert sum(r["owned_beads"] for r in out["per_rank"]) == 100000
+    assert all(r["ghost_beads"] > 0 and r["us_per_step"] > 0 for r in out["per_rank"])
+    assert out["extruders"] > 0
