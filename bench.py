@@ -138,6 +138,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
+    # stdout carries exactly ONE line, the JSON: everything else a library may print there (gloo's connection banner, RCCL
+    # notices) goes to stderr - fd 1 is pointed at fd 2 and the result is written to a private copy of the real stdout
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -365,7 +371,7 @@ def main():
                                   "`Bad FENE bond` on long runs in both engines, DESIGN.md 4)" % (pload, punload),
                                   "" if gen == "lattice" else "scrambled (melt-like) start instead of the serpentine lattice") if x),
         }
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     lmp.close()
     if world > 1:
         dist.destroy_process_group()

@@ -134,10 +134,15 @@ void Comm::shm_recv(int src, void *buf, size_t bytes) {
   long seq = shm_rcvd[src]++;
   std::string fin = box_path(shm_dir, src, rank, seq);
   struct stat st;
-  long waited = 0;
+  long waited = 0, polls = 0;
+  const std::string stop = shm_dir + "/ABORTED";
   while (stat(fin.c_str(), &st) != 0) {
     usleep(50);
-    if ((waited += 50) > 120L * 1000000L) throw LammpsError("shm transport: timeout waiting for " + fin);
+    if ((++polls & 0xFF) == 0) {
+      struct stat sa;
+      if (stat(stop.c_str(), &sa) == 0) { aborted = true; throw LammpsError("communicator aborted: another rank left the run with an error (re-init required)"); }
+    }
+    if ((waited += 50) > (long)(timeout_s * 1e6)) { abort(); throw LammpsError("shm transport: timeout waiting for " + fin + " (communicator aborted)"); }
   }
   if ((size_t)st.st_size != bytes)
     throw LammpsError("shm transport: size mismatch on " + fin + " (" + std::to_string(st.st_size) + " vs " + std::to_string(bytes) + ")");
@@ -160,6 +165,7 @@ struct LocalMsg {
 struct LocalHub {
   std::mutex mu;
   std::condition_variable cv;
+  bool aborted = false;     // some rank left its run with an error: every wait ends
   std::map<std::pair<int, int>, std::deque<std::shared_ptr<LocalMsg>>> box;   // (src, dst) -> messages in order
 };
 namespace {
@@ -185,7 +191,9 @@ std::shared_ptr<LocalHub> hub_for(const std::string &session) {
 }
 // one phase: post every send, serve every receive, then wait until the peers have taken the sends
 void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std::vector<Msg> &sends,
-                    const std::vector<Msg> &recvs) {
+                    const std::vector<Msg> &recvs, double timeout_s) {
+  const auto limit = std::chrono::duration<double>(timeout_s);
+  auto gone = [&] { if (h.aborted) throw LammpsError("communicator aborted: another rank left the run with an error (re-init required)"); };
   std::vector<std::shared_ptr<LocalMsg>> mine;
   for (auto &m : sends) {
     auto msg = std::make_shared<LocalMsg>();
@@ -203,8 +211,11 @@ void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std:
     {
       std::unique_lock<std::mutex> lk(h.mu);
       auto &q = h.box[{m.peer, rank}];
-      if (!h.cv.wait_for(lk, std::chrono::seconds(120), [&] { return !q.empty(); }))
-        throw LammpsError("local transport: timeout waiting for rank " + std::to_string(m.peer));
+      if (!h.cv.wait_for(lk, limit, [&] { return !q.empty() || h.aborted; })) {
+        h.aborted = true; h.cv.notify_all();
+        throw LammpsError("local transport: timeout waiting for rank " + std::to_string(m.peer) + " (communicator aborted)");
+      }
+      if (q.empty()) gone();
       msg = q.front(); q.pop_front();
     }
     if (msg->bytes != m.bytes || msg->host != host)
@@ -224,8 +235,11 @@ void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std:
   for (auto &msg : mine) {
     {
       std::unique_lock<std::mutex> lk(h.mu);
-      if (!h.cv.wait_for(lk, std::chrono::seconds(120), [&] { return msg->acked; }))
-        throw LammpsError("local transport: timeout waiting for an acknowledgement");
+      if (!h.cv.wait_for(lk, limit, [&] { return msg->acked || h.aborted; })) {
+        h.aborted = true; h.cv.notify_all();
+        throw LammpsError("local transport: timeout waiting for an acknowledgement (communicator aborted)");
+      }
+      if (!msg->acked) gone();
     }
     // the send buffer may be rewritten only after the receiver's copy has run
     if (msg->done) HIP_CHECK(hipStreamWaitEvent(st, msg->done, 0));
@@ -236,6 +250,8 @@ void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std:
 // ---------------------------------------------------------------------------------------------
 void Comm::init(const std::string &backend_name, int rank_, int world_, const void *id, const std::string &session) {
   rank = rank_; world = world_;
+  aborted = false;
+  if (const char *t = getenv("LAMMPS_LE_COMM_TIMEOUT")) timeout_s = std::max(1.0, atof(t));     // every backend
   if (world <= 1) { backend = NONE; return; }
   if (backend_name == "rccl") {
     rccl.load();
@@ -245,7 +261,6 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
     NCCL_CHECK(rccl.CommInitRank(&c, world, uid, rank));
     rccl_comm = c;
     backend = RCCL;
-    if (const char *t = getenv("LAMMPS_LE_COMM_TIMEOUT")) timeout_s = std::max(1.0, atof(t));
   } else if (backend_name == "local") {
     hub = hub_for(session);
     backend = LOCAL;
@@ -257,10 +272,17 @@ void Comm::init(const std::string &backend_name, int rank_, int world_, const vo
   } else throw LammpsError("unknown comm backend " + backend_name);
 }
 void Comm::abort() {
-  if (backend == RCCL && rccl_comm) { rccl.CommAbort((ncclComm_t)rccl_comm); rccl_comm = nullptr; backend = NONE; }
+  if (world <= 1 || aborted) return;
+  aborted = true;
+  if (backend == RCCL && rccl_comm) { rccl.CommAbort((ncclComm_t)rccl_comm); rccl_comm = nullptr; }
+  else if (backend == LOCAL && hub) { { std::lock_guard<std::mutex> g(hub->mu); hub->aborted = true; } hub->cv.notify_all(); }
+  else if (backend == SHM) { FILE *f = fopen((shm_dir + "/ABORTED").c_str(), "wb"); if (f) fclose(f); }
+}
+void Comm::require_alive() const {
+  if (aborted) throw LammpsError("communicator aborted: a rank left an earlier run with an error (re-init required)");
 }
 void Comm::wait_stream(hipStream_t st) {
-  if (backend != RCCL) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+  if (backend != RCCL || aborted) { HIP_CHECK(hipStreamSynchronize(st)); return; }
   const auto t0 = std::chrono::steady_clock::now();
   long it = 0;
   for (;;) {
@@ -295,10 +317,12 @@ int Comm::nranks() {
 void Comm::finalize() {
   if (backend == RCCL && rccl_comm) { rccl.CommDestroy((ncclComm_t)rccl_comm); rccl_comm = nullptr; }
   backend = NONE;
+  aborted = false;
 }
 
 // host collectives (small, rebuild-time only)
 void Comm::allgather_host(const void *send, void *recv, size_t bytes) {
+  require_alive();
   if (backend == NONE) { memcpy(recv, send, bytes); return; }
   if (backend == LOCAL) {
     std::vector<Msg> ss, rr;
@@ -307,7 +331,7 @@ void Comm::allgather_host(const void *send, void *recv, size_t bytes) {
       ss.push_back({const_cast<void *>(send), bytes, r});
       rr.push_back({(char *)recv + (size_t)r * bytes, bytes, r});
     }
-    local_exchange(*hub, rank, nullptr, true, ss, rr);
+    local_exchange(*hub, rank, nullptr, true, ss, rr, timeout_s);
     return;
   }
   if (backend == SHM) {
@@ -356,6 +380,7 @@ long Comm::allreduce_host_max(long v) {
 
 // device collectives
 void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
+  require_alive();
   if (backend == NONE) return;
   if (backend == RCCL) { NCCL_CHECK(rccl.AllReduce(dev, dev, n, ncclInt32, ncclMax, (ncclComm_t)rccl_comm, st)); return; }
   std::vector<int> h(n), all((size_t)world * n);
@@ -367,6 +392,7 @@ void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
   HIP_CHECK(hipStreamSynchronize(st));
 }
 void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_t bytes) {
+  require_alive();
   if (backend == NONE) { HIP_CHECK(hipMemcpyAsync(recv_dev, send_dev, bytes, hipMemcpyDeviceToDevice, st)); return; }
   if (backend == RCCL) { NCCL_CHECK(rccl.AllGather(send_dev, recv_dev, bytes, ncclInt8, (ncclComm_t)rccl_comm, st)); return; }
   if (backend == LOCAL) {
@@ -376,7 +402,7 @@ void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_
       ss.push_back({const_cast<void *>(send_dev), bytes, r});
       rr.push_back({(char *)recv_dev + (size_t)r * bytes, bytes, r});
     }
-    local_exchange(*hub, rank, st, false, ss, rr);
+    local_exchange(*hub, rank, st, false, ss, rr, timeout_s);
     return;
   }
   ensure_hbuf(bytes * (world + 1));
@@ -388,6 +414,7 @@ void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_
 }
 // grouped point-to-point: all sends and receives of one halo / migration phase
 void Comm::exchange(hipStream_t st, const std::vector<Msg> &sends, const std::vector<Msg> &recvs) {
+  require_alive();
   if (backend == NONE) return;
   if (backend == RCCL) {
     NCCL_CHECK(rccl.GroupStart());
@@ -396,7 +423,7 @@ void Comm::exchange(hipStream_t st, const std::vector<Msg> &sends, const std::ve
     NCCL_CHECK(rccl.GroupEnd());
     return;
   }
-  if (backend == LOCAL) { local_exchange(*hub, rank, st, false, sends, recvs); return; }
+  if (backend == LOCAL) { local_exchange(*hub, rank, st, false, sends, recvs, timeout_s); return; }
   size_t mx = 0;
   for (auto &m : sends) mx = std::max(mx, m.bytes);
   for (auto &m : recvs) mx = std::max(mx, m.bytes);
@@ -412,8 +439,9 @@ void Comm::exchange(hipStream_t st, const std::vector<Msg> &sends, const std::ve
 }
 // host-memory variant of exchange (counts; also the GPU-less transport self-test)
 void Comm::exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &recvs) {
+  require_alive();
   if (backend == NONE) return;
-  if (backend == LOCAL) { local_exchange(*hub, rank, nullptr, true, sends, recvs); return; }
+  if (backend == LOCAL) { local_exchange(*hub, rank, nullptr, true, sends, recvs, timeout_s); return; }
   if (backend == SHM) {
     for (auto &m : sends) shm_send(m.peer, m.dev, m.bytes);
     for (auto &m : recvs) shm_recv(m.peer, m.dev, m.bytes);
@@ -427,7 +455,7 @@ void Comm::exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &
   std::vector<Msg> ds, dr;
   for (auto &m : sends) { HIP_CHECK(hipMemcpyAsync(p, m.dev, m.bytes, hipMemcpyHostToDevice, main_stream)); ds.push_back({p, m.bytes, m.peer}); p += m.bytes; }
   for (auto &m : recvs) { dr.push_back({p, m.bytes, m.peer}); p += m.bytes; }
-  HIP_CHECK(hipStreamSynchronize(main_stream));    // the host send buffers are stack variables of the caller
+  wait_stream(main_stream);                         // the host send buffers are stack variables of the caller (bounded wait)
   exchange(main_stream, ds, dr);
   for (size_t k = 0; k < recvs.size(); k++) HIP_CHECK(hipMemcpyAsync(recvs[k].dev, dr[k].dev, recvs[k].bytes, hipMemcpyDeviceToHost, main_stream));
   wait_stream(main_stream);

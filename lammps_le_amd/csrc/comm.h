@@ -12,6 +12,11 @@ struct Msg { void *dev; size_t bytes; int peer; };
 
 struct Comm {
   enum Backend { NONE, RCCL, SHM, LOCAL } backend = NONE;
+  // set by abort(): the communicator is gone (ncclCommAbort) or poisoned (test transports: the peers were told to stop
+  // waiting); from then on every collective of this handle throws `communicator aborted ...` instead of quietly doing
+  // nothing or a one-rank version of itself, and Engine::run refuses to start.  world stays what it was.
+  bool aborted = false;
+  void require_alive() const;
   int rank = 0, world = 1;
   // RCCL calls are issued on the engine's stream (one total order per rank); the opt-in halo/compute overlap
   // (LAMMPS_LE_OVERLAP) additionally issues the per-step halo on comm_stream, ordered against the main stream by events
@@ -22,7 +27,9 @@ struct Comm {
   // transports use), aborts the communicator and throws, so that every rank ends with an error instead of hanging.
   double timeout_s = 120.0;
   void wait_stream(hipStream_t st);
-  void abort();      // ncclCommAbort (no-op for the test transports); called by a rank that leaves a run with an error
+  // called by a rank that leaves a run with an error: ncclCommAbort for RCCL; the test transports raise a flag their
+  // peers' waits look at (hub flag / marker file), so that those end at once with the same message instead of timing out
+  void abort();
   void init(const std::string &backend_name, int rank, int world, const void *unique_id, const std::string &session);
   void finalize();
   int nranks();      // size of the communicator as the transport itself reports it (ncclCommCount for RCCL)

@@ -76,6 +76,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   int mn = (int)(expect * 1.5) + 24;
   dalloc(d.numneigh, np);
   dalloc(d.bpart, (size_t)std::max(bpa, 1) * np);   // >= 1 row: the step kernel loads before it masks
+  dalloc(d.bshift, np);
   dev_alloc_neigh(d, mn);
   dalloc(d.pairtab, (size_t)6 * (ntypes + 1) * (ntypes + 1));
   d.nred_blocks = (n + 255) / 256 + 8;
@@ -116,7 +117,7 @@ void dev_free(DeviceState &d) {
   dfree(d.map); dfree(d.type_t); dfree(d.crank);
   dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special); dfree(d.num_bond0); dfree(d.bond_type0); dfree(d.bond_atom0); dfree(d.bond_pack);
   dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
-  dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.pairtab); dfree(d.partial);
+  dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial);
   if (d.partial_h) (void)hipHostFree(d.partial_h);
   d.partial_h = nullptr;
   dfree(d.flags);

@@ -96,6 +96,9 @@ struct DeviceState {
   int *neigh = nullptr;      // [maxneigh][npad] full list, special bits in the top 2 bits
   int *numneigh = nullptr;   // [npad]
   int *bpart = nullptr;      // [bpa][npad] (type << 26) | partner p ; -1 = none
+  // [npad] frozen periodic image of each bond partner, BSHIFT_BITS per COMPACTED bond slot (= the bond's row in the bead's
+  // list), written by k_bond_table from the positions of the build; 0 for nearly every bead (engine.h NN_SHIFTED_BIT)
+  unsigned long long *bshift = nullptr;
   double *pairtab = nullptr; // 6 * nt*nt : cutsq lj1 lj2 lj3 lj4 offset
   int newton_pair = 0;           // `newton on [off]`: which end stores a pair in the reference's half list (ex_load's visit order)
   int ref_nbin[3] = {1, 1, 1};   // the reference's neighbor bins (cutneighmax / 2 fitted to the box, nbin_standard.cpp:53-186)

@@ -418,12 +418,12 @@ void Engine::reneighbor(bool defer_check) {
 // Timer::stamp (src/timer.cpp:100-135): wall clock between stamps goes to a section; `timer sync` drains the device first
 void Engine::stamp() {
   if (timer_level < 2) return;
-  if (timer_sync && dev && dev->stream) HIP_CHECK(hipStreamSynchronize(dev->stream));
+  if (timer_sync && dev && dev->stream) stream_sync(*dev);     // (decomposed runs: a bounded wait, Comm::wait_stream)
   timer_prev = wall();
 }
 void Engine::stamp(int which) {
   if (timer_level < 2) return;
-  if (timer_sync && dev && dev->stream) HIP_CHECK(hipStreamSynchronize(dev->stream));
+  if (timer_sync && dev && dev->stream) stream_sync(*dev);
   double now = wall();
   timers[which] += now - timer_prev;
   timer_prev = now;
@@ -556,7 +556,7 @@ double Engine::stat_neigh_pairs() {
   HIP_CHECK(hipMemcpy(nn.data(), dev->numneigh, (size_t)dev->n * sizeof(int), hipMemcpyDeviceToHost));
   nn[dev->n] = 0;
   double s = 0.0;
-  for (int v : nn) s += (v & NN_COUNT_MASK) - (v >> NN_BOND_SHIFT);     // pair entries (a bead's bonds open its list)
+  for (int v : nn) s += (v & NN_COUNT_MASK) - ((v >> NN_BOND_SHIFT) & NN_NBOND_MASK);     // pair entries (a bead's bonds open its list)
   if (world > 1) s = comm->allreduce_host_sum(s);
   return s;
 }
@@ -698,8 +698,16 @@ void Engine::iterate(long nsteps) {
   // LAMMPS_LE_OVERLAP_RCCL=1 says otherwise
   bool overlap = getenv("LAMMPS_LE_OVERLAP") != nullptr && atoi(getenv("LAMMPS_LE_OVERLAP")) != 0;
   if (overlap && comm && comm->backend == Comm::RCCL && !getenv("LAMMPS_LE_OVERLAP_RCCL")) overlap = false;
+  // test hook (LAMMPS_LE_TEST_FAIL_AT="rank:step"): this rank stops with an error in the middle of a run, the way a
+  // rank-local failure (capacity check, LE fix throw) would; its peers must end with an error too, not hang
+  long fail_at = -1;
+  if (const char *fa = getenv("LAMMPS_LE_TEST_FAIL_AT")) {
+    int fr = -1; long fs = -1;
+    if (sscanf(fa, "%d:%ld", &fr, &fs) == 2 && fr == rank) fail_at = fs;
+  }
   for (long it = 0; it < nsteps; it++) {
     ntimestep++;
+    if (ntimestep == fail_at) throw LammpsError("test hook: rank " + std::to_string(rank) + " fails at step " + std::to_string(fail_at));
     bool eflag = (ntimestep == endstep) || (thermo_every > 0 && ntimestep % thermo_every == 0);
     const bool restart_now = restart_every > 0 && ntimestep % restart_every == 0;
     const bool dump_now = (!dumps.empty() && dump_due(ntimestep)) || restart_now;   // needs the complete state of this step: unfused path
@@ -934,6 +942,11 @@ void Engine::print_timing_breakdown(long nsteps) {
 
 void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
+  // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
+  if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
+  // a run that ended in an error tore the communicator down (below); halo sequence numbers and arrival counters of the
+  // ranks may disagree from then on, so nothing decomposed runs on this handle again
+  if (comm && world > 1) comm->require_alive();
   const bool trace = getenv("LAMMPS_LE_TRACE_RUN") != nullptr;
   double tr0 = wall();
   init();
@@ -961,7 +974,6 @@ void Engine::run(long nsteps) {
   host_current = false;
   double t0 = 0.0;
   try {
-    if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
     if (respa_levels > 0) respa_setup(); else setup();
     for (int k = 0; k < 8; k++) timers[k] = 0.0;     // Timer::init() comes after setup (src/run.cpp:176-181)
     dev->ev_used = 0;

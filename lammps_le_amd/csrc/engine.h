@@ -30,6 +30,12 @@ constexpr int BOND_IDX_MASK = (1 << BOND_TYPE_SHIFT) - 1;
 // entries in the bond-partner table's encoding (kernels_md.hip pair_loop)
 constexpr int NN_BOND_SHIFT = 16;
 constexpr int NN_COUNT_MASK = (1 << NN_BOND_SHIFT) - 1;
+constexpr int NN_NBOND_MASK = 0xFF;          // bond entries of the word: (word >> NN_BOND_SHIFT) & NN_NBOND_MASK
+// bit 30 of the word: some bond of this bead reaches its partner through a periodic image.  The image of a bond partner is
+// FROZEN at the reneighbor (src/ntopo_bond_all.cpp:52-73: domain->closest_image picks a ghost, whose shift then stays),
+// two bits per dimension and bond slot in DeviceState::bshift (0 none, 1 partner at +prd, 2 partner at -prd)
+constexpr int NN_SHIFTED_BIT = 1 << 30;
+constexpr int BSHIFT_BITS = 6;
 
 // ---------------------------------------------------------------------------------------------
 // RanMars in exact integer arithmetic (src/random_mars.cpp:29-95; every value is k * 2^-24)

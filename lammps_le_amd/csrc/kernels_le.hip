@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
       const int p = V.map[is], q = V.map[js];
       if (p >= 0 && p < V.n_owned && q >= 0) {
         const int w = V.numneigh[p], nn = w & NN_COUNT_MASK;       // (the bead's bond entries come first: skipped)
-        for (int k = w >> NN_BOND_SHIFT; k < nn; k++)
+        for (int k = (w >> NN_BOND_SHIFT) & NN_NBOND_MASK; k < nn; k++)
           if ((V.neigh[(size_t)k * V.npad + p] & NEIGH_MASK) == q) { base = true; break; }
       }
     }
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams
     const int n1 = tp.nspecial[3 * (size_t)t];
     const int w = numneigh[p], nn = w & NN_COUNT_MASK;             // (the bead's bond entries come first: skipped)
     double best = 1.0e20;
-    for (int k = w >> NN_BOND_SHIFT; k < nn; k++) {
+    for (int k = (w >> NN_BOND_SHIFT) & NN_NBOND_MASK; k < nn; k++) {
       const int j = neigh[(size_t)k * npad + p] & NEIGH_MASK;
       const int tj = tag[j];
       const int jtype = tp.type_t[tj];

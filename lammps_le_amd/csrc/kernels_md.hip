@@ -156,6 +156,7 @@ struct ForceArgs {
   int n, npad, nblocks, bpa, nt;
   const double4 *pos;
   const int *neigh, *numneigh, *bpart;
+  const unsigned long long *bshift;   // frozen partner images of the bonds (DeviceState::bshift)
   const double *pairtab;
   double sl0, sl1, sl2, sl3;
   // all type pairs share one coefficient set (pair_coeff * * ...): scalars instead of the LDS table
@@ -282,20 +283,24 @@ __device__ __forceinline__ BeadPre bead_preload(const ForceArgs &A, int p, int s
 
 // one bond term seen from bead p (BondFENE::compute / BondHarmonic::compute; every bond is evaluated from both ends).
 // `eb` = (bond type << BOND_TYPE_SHIFT) | partner's index, rj = the partner's position.
+// `sh` = the partner's periodic image as frozen at the last reneighbor (BSHIFT_BITS of DeviceState::bshift; 0 for nearly
+// every bond): the reference evaluates a bond against the ghost Domain::closest_image picked when the bond list was built
+// (src/ntopo_bond_all.cpp:52-73), i.e. x_j + S with a fixed S, not against the minimum image of every step.
 template <bool EFLAG>
 __device__ __forceinline__ void bond_term(const Box &box, const double *__restrict__ s_bt, int p, const double4 &ri,
-                                          int eb, const double4 &rj, double &fxi, double &fyi, double &fzi,
+                                          int eb, const double4 &rj, unsigned sh, double &fxi, double &fyi, double &fzi,
                                           double (&e)[14], int *__restrict__ flags) {
   const int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
   const double *row = s_bt + type * BT_W;
   const int style = (int)row[0];
   if (style == 0) return;
-  const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
-  const double px = box.prd[0], py = box.prd[1], pz = box.prd[2];
-  double delx = ri.x - rj.x, dely = ri.y - rj.y, delz = ri.z - rj.z;
-  if (delx > hx) delx -= px; else if (delx < -hx) delx += px;
-  if (dely > hy) dely -= py; else if (dely < -hy) dely += py;
-  if (delz > hz) delz -= pz; else if (delz < -hz) delz += pz;
+  double xj = rj.x, yj = rj.y, zj = rj.z;
+  if (sh) {
+    if (sh & 1u) xj += box.prd[0]; else if (sh & 2u) xj -= box.prd[0];
+    if (sh & 4u) yj += box.prd[1]; else if (sh & 8u) yj -= box.prd[1];
+    if (sh & 16u) zj += box.prd[2]; else if (sh & 32u) zj -= box.prd[2];
+  }
+  const double delx = ri.x - xj, dely = ri.y - yj, delz = ri.z - zj;
   double rsq = delx * delx + dely * dely + delz * delz;
   double fbond, ebond = 0.0;
   if (style == 1) {
@@ -344,8 +349,8 @@ __device__ __forceinline__ void bond_term(const Box &box, const double *__restri
 template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB, int LPB, bool AHEAD, bool DIAGP = false>
 __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, const double *__restrict__ s_tab,
                                           const double *__restrict__ s_bt, int p, int sub, const BeadPre &L, int nall,
-                                          int nb, const double4 &ri, double &fxi, double &fyi, double &fzi,
-                                          double (&e)[14], int *__restrict__ flags) {
+                                          int nb, unsigned long long bsh, const double4 &ri, double &fxi, double &fyi,
+                                          double &fzi, double (&e)[14], int *__restrict__ flags) {
   // software pipeline, W neighbors per stage: while the W position gathers of the current stage are in flight the
   // (coalesced) index loads of the next stage are issued, so a stage costs one exposed round trip.  Lists are
   // consumed in groups of W; slots past the end are predicated off (index = own bead, cached).
@@ -384,7 +389,7 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
       // small systems (one wavefront's chain of dependent work is what counts, registers are plentiful): unrolled
 #pragma unroll
       for (int u = 0; u < W; u++) {
-        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, c[u], r[u], fxi, fyi, fzi, e, flags); }
+        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, c[u], r[u], (unsigned)(bsh >> (BSHIFT_BITS * (g0 + u * LPB))) & 63u, fxi, fyi, fzi, e, flags); }
         else pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c[u], r[u], k + u < nn, fxi, fyi, fzi, e);
       }
     } else if (mixed) {
@@ -395,7 +400,7 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
         double4 ru = r[0];
 #pragma unroll
         for (int w = 1; w < W; w++) if (u == w) { cu = c[w]; ru = r[w]; }
-        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, cu, ru, fxi, fyi, fzi, e, flags); }
+        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, cu, ru, (unsigned)(bsh >> (BSHIFT_BITS * (g0 + u * LPB))) & 63u, fxi, fyi, fzi, e, flags); }
         else pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, cu, ru, k + u < nn, fxi, fyi, fzi, e);
       }
     } else {
@@ -413,14 +418,17 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
                                            double &fzi, double (&e)[14], int *__restrict__ flags) {
   if (HAS_PAIR) {
     const int nall = (DIAG && (A.diag & 2)) ? 0 : min(L.nall & NN_COUNT_MASK, A.nn_limit);
-    const int nb = min(L.nall >> NN_BOND_SHIFT, nall);
+    const int nb = min((L.nall >> NN_BOND_SHIFT) & NN_NBOND_MASK, nall);
+    // frozen partner images: a word of the side table for the few beads that have a bond across a periodic face
+    unsigned long long bsh = 0ull;
+    if (L.nall & NN_SHIFTED_BIT) bsh = A.bshift[p];
     // wave-uniform choice: a wavefront whose 64 beads all sit deeper than `margin` inside the box skips
     // the minimum-image arithmetic of the pair terms (cell order makes most wavefronts interior)
     const double m = A.margin;
     bool interior = ri.x > box.lo[0] + m && ri.x < box.hi[0] - m && ri.y > box.lo[1] + m && ri.y < box.hi[1] - m &&
                     ri.z > box.lo[2] + m && ri.z < box.hi[2] - m;
     bool all_in = __all(interior);
-#define LE_LOOP(MI, UN, SB) pair_loop<EFLAG, MI, UN, SB, LPB, AHEAD, DIAG>(A, box, s_tab, s_bt, p, sub, L, nall, nb, ri, fxi, fyi, fzi, e, flags)
+#define LE_LOOP(MI, UN, SB) pair_loop<EFLAG, MI, UN, SB, LPB, AHEAD, DIAG>(A, box, s_tab, s_bt, p, sub, L, nall, nb, bsh, ri, fxi, fyi, fzi, e, flags)
     if (A.uniform && !A.has_sb) {
       if (all_in) LE_LOOP(false, true, false); else LE_LOOP(true, true, false);
     } else if (!A.has_sb) {
@@ -433,11 +441,15 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
   }
   // no pair style (no list): the bonds come straight from the bond-partner table
   const int nbond = (DIAG && (A.diag & 1)) ? 0 : A.bpa;
-  for (int m = sub; m < nbond; m += LPB) {
+  const unsigned long long bsh = A.bshift[p];
+  int slot = 0;                                    // the images are stored by compacted slot (k_bond_table)
+  for (int m = 0; m < nbond; m++) {
     const int eb = A.bpart[(size_t)m * A.npad + p];
     if (eb < 0) continue;
+    const int myslot = slot++;
+    if ((m % LPB) != sub) continue;
     const double4 rj = A.pos[eb & BOND_IDX_MASK];
-    bond_term<EFLAG>(box, s_bt, p, ri, eb, rj, fxi, fyi, fzi, e, flags);
+    bond_term<EFLAG>(box, s_bt, p, ri, eb, rj, (unsigned)(bsh >> (BSHIFT_BITS * myslot)) & 63u, fxi, fyi, fzi, e, flags);
   }
 }
 
@@ -633,7 +645,7 @@ void launch_ke(DeviceState &d, const TypeTables &tt) {
 static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   ForceArgs A;
   A.n = d.n; A.npad = d.npad; A.nblocks = (d.n + BLOCK - 1) / BLOCK; A.bpa = d.bpa; A.nt = d.ntypes + 1;
-  A.pos = d.pos; A.neigh = d.neigh; A.numneigh = d.numneigh; A.bpart = d.bpart; A.pairtab = d.pairtab;
+  A.pos = d.pos; A.neigh = d.neigh; A.numneigh = d.numneigh; A.bpart = d.bpart; A.bshift = d.bshift; A.pairtab = d.pairtab;
   A.sl0 = sl[0]; A.sl1 = sl[1]; A.sl2 = sl[2]; A.sl3 = sl[3];
   A.uniform = d.pair_uniform; A.u_cutsq = d.pair_u[0]; A.u_lj1 = d.pair_u[1]; A.u_lj2 = d.pair_u[2];
   A.u_lj3 = d.pair_u[3]; A.u_lj4 = d.pair_u[4]; A.u_off = d.pair_u[5];

@@ -372,3 +372,74 @@ def test_bench_launches_its_own_ranks():
     assert sum(r["owned_beads"] for r in out["per_rank"]) == 100000
     assert all(r["ghost_beads"] > 0 and r["us_per_step"] > 0 for r in out["per_rank"])
     assert out["extruders"] > 0
+
+
+def test_a_failing_rank_ends_every_rank(tmp_path, monkeypatch):
+    """the failure paths.  Rank 1 of a 2-process run (peer windows on) stops with an error at step 31 (test
+    hook).  Rank 0 must not hang in its halo wait or in the next collective: it ends with the communicator / halo error
+    within the short time-out set here, and both processes exit non-zero."""
+    import time
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO", "1")
+    monkeypatch.setenv("LAMMPS_LE_TEST_FAIL_AT", "1:31")
+    monkeypatch.setenv("LAMMPS_LE_COMM_TIMEOUT", "6")
+    s = lattice_chain(6000, nchains=2, seed=21)
+    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
+        "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 0\nrun 60\n"
+    session = uuid.uuid4().hex[:12]
+    sysfile, scriptfile, out = (os.path.join(str(tmp_path), n) for n in ("system.pkl", "script.txt", "out.npz"))
+    pickle.dump(s, open(sysfile, "wb"))
+    open(scriptfile, "w").write(script)
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dd_worker.py"), str(r), "2", session, sysfile,
+                               scriptfile, out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    took = time.time() - t0
+    assert all(p.returncode != 0 for p in procs), "\n".join(logs)
+    assert "test hook: rank 1 fails at step 31" in logs[1]
+    assert ("communicator aborted" in logs[0]) or ("did not deliver its halo" in logs[0]) or ("timeout" in logs[0]), logs[0]
+    assert took < 120, took
+
+
+def test_aborted_communicator_refuses_further_collectives(tmp_path, monkeypatch):
+    """After a run that ended in an error the handle's communicator is in the ABORTED state: the peer wakes up at once
+    (no time-out), and a later run or gather on either handle raises `communicator aborted` instead of quietly
+    degrading to a one-rank version of the collective."""
+    import threading
+    import time
+    from lammps_le_amd import lammps
+    from systems import write_data
+    monkeypatch.setenv("LAMMPS_LE_TEST_FAIL_AT", "0:12")
+    monkeypatch.setenv("LAMMPS_LE_COMM_TIMEOUT", "60")
+    s = lattice_chain(6000, nchains=2, seed=21)
+    path = os.path.join(str(tmp_path), "data.local")
+    write_data(path, s)
+    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + "fix 1 all nve\nthermo 0\n"
+    session = uuid.uuid4().hex[:12]
+    first, later = [None, None], [None, None]
+
+    def work(rank):
+        lmp = lammps(cmdargs=["-screen", "none"])
+        lmp.comm_init("local", rank, 2, session=session)
+        for ln in script.split("\n"):
+            w = ln.split("#")[0].split()
+            lmp.command("read_data " + path if w and w[0] == "read_data" else ln)
+        try:
+            lmp.command("run 40")
+        except Exception as e:
+            first[rank] = str(e)
+        for cmd in ("run 5", None):
+            try:
+                lmp.command(cmd) if cmd else lmp.gather("x")
+            except Exception as e:
+                later[rank] = (later[rank] or "") + "|" + str(e)
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert time.time() - t0 < 45                       # the peer did not sit out the 60 s time-out
+    assert "test hook" in first[0] and "communicator aborted" in first[1], first
+    for r in range(2):
+        assert later[r] is not None and later[r].count("communicator aborted") == 2, later
