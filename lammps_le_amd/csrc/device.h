@@ -99,6 +99,11 @@ struct DeviceState {
   // [npad] frozen periodic image of each bond partner, BSHIFT_BITS per COMPACTED bond slot (= the bond's row in the bead's
   // list), written by k_bond_table from the positions of the build; 0 for nearly every bead (engine.h NN_SHIFTED_BIT)
   unsigned long long *bshift = nullptr;
+  // 1: the minimum image of every step IS the frozen image, provably - every bond style is fene and 2 R0 < half the box,
+  // so a bond component cannot reach half the box without `Bad FENE bond` ending the run at that very step (rlogarg <= -3
+  // <=> r >= 2 R0); the force kernels then keep their three compares per bond and the rebuild skips the partner gathers
+  // (k_bond_table: 25 instead of 56 us per rebuild at 1M beads).  0: images are frozen at the rebuild (bshift).
+  int bond_minimg = 0;
   double *pairtab = nullptr; // 6 * nt*nt : cutsq lj1 lj2 lj3 lj4 offset
   int newton_pair = 0;           // `newton on [off]`: which end stores a pair in the reference's half list (ex_load's visit order)
   int ref_nbin[3] = {1, 1, 1};   // the reference's neighbor bins (cutneighmax / 2 fitted to the box, nbin_standard.cpp:53-186)

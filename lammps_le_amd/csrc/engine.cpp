@@ -691,6 +691,9 @@ void Engine::iterate(long nsteps) {
   int nnve = count_nve(this);
   double triggersq = 0.25 * skin * skin;
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
+  // bond morse (the reference's unit-test partner of bond hybrid, not a style of the chromatin model) lives in the
+  // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
+  for (int b = 1; b <= nbondtypes; b++) if (bondtab.style[b] == 3) fusable = false;
   bool ident = d.ident_order;
   bool pre_integrated = false;
   // halo/compute overlap issues the per-step halo on a second stream.  With RCCL that means two streams feeding ONE
@@ -955,6 +958,18 @@ void Engine::run(long nsteps) {
   if (dev->dd) dd_fast_halo_switch(*dev);
   for (int k = 1; k <= 3; k++) dev->sflag[k] = special_flag(k);
   dev->ident_order = local_order_is_tag_order();
+  {
+    // bond partner images: frozen at the reneighbor as in the reference (src/ntopo_bond_all.cpp:52-73), unless the minimum
+    // image of every step is provably the same thing (device.h bond_minimg)
+    double r0max = 0.0;
+    bool all_fene = nbondtypes > 0;
+    for (int b = 1; b <= nbondtypes; b++) {
+      if (bondtab.style[b] == 1) r0max = std::max(r0max, bondtab.p1[b]);
+      else if (bondtab.style[b] != 0) all_fene = false;
+    }
+    const double halfmin = 0.5 * std::min({box.prd[0], box.prd[1], box.prd[2]});
+    dev->bond_minimg = (all_fene && 2.0 * r0max * 1.000001 < halfmin && !getenv("LAMMPS_LE_FREEZE_IMAGES")) ? 1 : 0;
+  }
   dev->newton_pair = newton_pair ? 1 : 0;
   for (int k = 0; k < 3; k++) {
     const double binsize_optimal = cutneighmax > 0.0 ? 0.5 * cutneighmax : box.prd[0];

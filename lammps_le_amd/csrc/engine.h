@@ -74,7 +74,7 @@ struct PairTable {  // lj/cut per type pair, row-major (ntypes+1)^2; lives in de
 };
 
 struct BondTable {  // by-value kernel argument
-  int style[MAXTYPES + 1];  // 0 none/zero, 1 fene, 2 harmonic
+  int style[MAXTYPES + 1];  // 0 none/zero, 1 fene, 2 harmonic, 3 morse (unfused force kernel only)
   double p0[MAXTYPES + 1], p1[MAXTYPES + 1], p2[MAXTYPES + 1], p3[MAXTYPES + 1];
 };
 

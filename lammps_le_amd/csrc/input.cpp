@@ -410,11 +410,11 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
     for (int b = 0; b <= MAXTYPES; b++) bondtab.style[b] = 0;
     if (arg[0] == "hybrid") {
       for (size_t i = 1; i < arg.size(); i++) {
-        if (arg[i] != "fene" && arg[i] != "harmonic" && arg[i] != "zero") throw LammpsError("Unknown bond style " + arg[i]);
+        if (arg[i] != "fene" && arg[i] != "harmonic" && arg[i] != "morse" && arg[i] != "zero") throw LammpsError("Unknown bond style " + arg[i]);
         bond_hybrid_styles.push_back(arg[i]);
       }
       if (bond_hybrid_styles.empty()) throw LammpsError("Illegal bond_style command");
-    } else if (arg[0] != "fene" && arg[0] != "harmonic" && arg[0] != "zero" && arg[0] != "none")
+    } else if (arg[0] != "fene" && arg[0] != "harmonic" && arg[0] != "morse" && arg[0] != "zero" && arg[0] != "none")
       throw LammpsError("Unknown bond style " + arg[0]);
   } else if (cmd == "bond_coeff") {
     need(1);
@@ -443,6 +443,11 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
         if (arg.size() != a0 + 2) throw LammpsError("Incorrect args for bond coefficients");
         bondtab.style[b] = 2;
         bondtab.p0[b] = numeric(arg[a0]); bondtab.p1[b] = numeric(arg[a0 + 1]);
+      } else if (st == "morse") {
+        // D alpha r0 (src/MOLECULE/bond_morse.cpp:130-152); evaluated by the unfused force kernel only (Engine::iterate)
+        if (arg.size() != a0 + 3) throw LammpsError("Incorrect args for bond coefficients");
+        bondtab.style[b] = 3;
+        bondtab.p0[b] = numeric(arg[a0]); bondtab.p1[b] = numeric(arg[a0 + 1]); bondtab.p2[b] = numeric(arg[a0 + 2]);
       } else bondtab.style[b] = 0;
     }
   } else if (cmd == "pair_style") {

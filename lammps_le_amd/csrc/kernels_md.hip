@@ -157,6 +157,7 @@ struct ForceArgs {
   const double4 *pos;
   const int *neigh, *numneigh, *bpart;
   const unsigned long long *bshift;   // frozen partner images of the bonds (DeviceState::bshift)
+  int bond_minimg;                    // DeviceState::bond_minimg: per-step minimum image is provably the frozen image
   const double *pairtab;
   double sl0, sl1, sl2, sl3;
   // all type pairs share one coefficient set (pair_coeff * * ...): scalars instead of the LDS table
@@ -199,11 +200,11 @@ __device__ __forceinline__ void fill_bond_table(const BondTable &bt, double *__r
     double *row = s_bt + t * BT_W;
     row[0] = (double)st;
     row[1] = K;
-    row[2] = (st == 1) ? 1.0 / (R0 * R0) : R0;
+    row[2] = (st == 1) ? 1.0 / (R0 * R0) : R0;     // harmonic: r0; morse: alpha
     row[3] = 48.0 * epsb;
     row[4] = sigb * sigb;
     row[5] = TWO_1_3 * sigb * sigb;
-    row[6] = R0 * R0;
+    row[6] = (st == 3) ? epsb : R0 * R0;            // morse: r0 (third coefficient)
     row[7] = epsb;
   }
 }
@@ -286,10 +287,10 @@ __device__ __forceinline__ BeadPre bead_preload(const ForceArgs &A, int p, int s
 // `sh` = the partner's periodic image as frozen at the last reneighbor (BSHIFT_BITS of DeviceState::bshift; 0 for nearly
 // every bond): the reference evaluates a bond against the ghost Domain::closest_image picked when the bond list was built
 // (src/ntopo_bond_all.cpp:52-73), i.e. x_j + S with a fixed S, not against the minimum image of every step.
-template <bool EFLAG>
+template <bool EFLAG, bool ALLSTYLES = false>
 __device__ __forceinline__ void bond_term(const Box &box, const double *__restrict__ s_bt, int p, const double4 &ri,
-                                          int eb, const double4 &rj, unsigned sh, double &fxi, double &fyi, double &fzi,
-                                          double (&e)[14], int *__restrict__ flags) {
+                                          int eb, const double4 &rj, unsigned sh, bool minimg, double &fxi, double &fyi,
+                                          double &fzi, double (&e)[14], int *__restrict__ flags) {
   const int q = eb & BOND_IDX_MASK, type = eb >> BOND_TYPE_SHIFT;
   const double *row = s_bt + type * BT_W;
   const int style = (int)row[0];
@@ -300,7 +301,13 @@ __device__ __forceinline__ void bond_term(const Box &box, const double *__restri
     if (sh & 4u) yj += box.prd[1]; else if (sh & 8u) yj -= box.prd[1];
     if (sh & 16u) zj += box.prd[2]; else if (sh & 32u) zj -= box.prd[2];
   }
-  const double delx = ri.x - xj, dely = ri.y - yj, delz = ri.z - zj;
+  double delx = ri.x - xj, dely = ri.y - yj, delz = ri.z - zj;
+  if (minimg) {     // (wave-uniform) all-FENE systems in a large box: see DeviceState::bond_minimg
+    const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
+    if (delx > hx) delx -= box.prd[0]; else if (delx < -hx) delx += box.prd[0];
+    if (dely > hy) dely -= box.prd[1]; else if (dely < -hy) dely += box.prd[1];
+    if (delz > hz) delz -= box.prd[2]; else if (delz < -hz) delz += box.prd[2];
+  }
   double rsq = delx * delx + dely * dely + delz * delz;
   double fbond, ebond = 0.0;
   if (style == 1) {
@@ -325,6 +332,11 @@ __device__ __forceinline__ void bond_term(const Box &box, const double *__restri
       ebond = -0.5 * K * row[6] * log(rlogarg);
       if (rsq < row[5]) ebond += 4.0 * row[7] * sr6 * (sr6 - 1.0) + row[7];
     }
+  } else if (ALLSTYLES && style == 3) {
+    // BondMorse::compute (src/MOLECULE/bond_morse.cpp:50-115): D = row[1], alpha = row[2], r0 = row[6]
+    const double r = sqrt(rsq), dr = r - row[6], ralpha = exp(-row[2] * dr);
+    fbond = (r > 0.0) ? -2.0 * row[1] * row[2] * (1 - ralpha) * ralpha / r : 0.0;
+    if (EFLAG) ebond = row[1] * (1 - ralpha) * (1 - ralpha);
   } else {
     double r = sqrt(rsq);
     double dr = r - row[2];
@@ -346,7 +358,7 @@ __device__ __forceinline__ void bond_term(const Box &box, const double *__restri
 // gathers as the pair partners', instead of a chain of dependent loads (table entry -> position, one bond after the
 // other) behind the pair loop.  Stages that hold a bond entry in some lane (the first one; the second for a wavefront
 // with an extruder anchor) run the mixed body, all later ones the plain pair body.
-template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB, int LPB, bool AHEAD, bool DIAGP = false>
+template <bool EFLAG, bool MINIMG, bool UNIFORM, bool HAS_SB, int LPB, bool AHEAD, bool DIAGP = false, bool ALLSTYLES = false>
 __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, const double *__restrict__ s_tab,
                                           const double *__restrict__ s_bt, int p, int sub, const BeadPre &L, int nall,
                                           int nb, unsigned long long bsh, const double4 &ri, double &fxi, double &fyi,
@@ -389,7 +401,7 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
       // small systems (one wavefront's chain of dependent work is what counts, registers are plentiful): unrolled
 #pragma unroll
       for (int u = 0; u < W; u++) {
-        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, c[u], r[u], (unsigned)(bsh >> (BSHIFT_BITS * (g0 + u * LPB))) & 63u, fxi, fyi, fzi, e, flags); }
+        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG, ALLSTYLES>(box, s_bt, p, ri, c[u], r[u], (unsigned)(bsh >> (BSHIFT_BITS * (g0 + u * LPB))) & 63u, A.bond_minimg != 0, fxi, fyi, fzi, e, flags); }
         else pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, c[u], r[u], k + u < nn, fxi, fyi, fzi, e);
       }
     } else if (mixed) {
@@ -400,7 +412,7 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
         double4 ru = r[0];
 #pragma unroll
         for (int w = 1; w < W; w++) if (u == w) { cu = c[w]; ru = r[w]; }
-        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG>(box, s_bt, p, ri, cu, ru, (unsigned)(bsh >> (BSHIFT_BITS * (g0 + u * LPB))) & 63u, fxi, fyi, fzi, e, flags); }
+        if (g0 + u * LPB < nb) { if (bonds_on) bond_term<EFLAG, ALLSTYLES>(box, s_bt, p, ri, cu, ru, (unsigned)(bsh >> (BSHIFT_BITS * (g0 + u * LPB))) & 63u, A.bond_minimg != 0, fxi, fyi, fzi, e, flags); }
         else pair_term<EFLAG, MINIMG, UNIFORM, HAS_SB>(A, box, s_tab, itype, ri, cu, ru, k + u < nn, fxi, fyi, fzi, e);
       }
     } else {
@@ -411,7 +423,7 @@ __device__ __forceinline__ void pair_loop(const ForceArgs &A, const Box &box, co
   }
 }
 
-template <bool EFLAG, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD>
+template <bool EFLAG, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ALLSTYLES = false>
 __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &bt, const Box &box,
                                            const double *__restrict__ s_tab, const double *__restrict__ s_bt, int p,
                                            int sub, const BeadPre &L, const double4 &ri, double &fxi, double &fyi,
@@ -428,7 +440,7 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
     bool interior = ri.x > box.lo[0] + m && ri.x < box.hi[0] - m && ri.y > box.lo[1] + m && ri.y < box.hi[1] - m &&
                     ri.z > box.lo[2] + m && ri.z < box.hi[2] - m;
     bool all_in = __all(interior);
-#define LE_LOOP(MI, UN, SB) pair_loop<EFLAG, MI, UN, SB, LPB, AHEAD, DIAG>(A, box, s_tab, s_bt, p, sub, L, nall, nb, bsh, ri, fxi, fyi, fzi, e, flags)
+#define LE_LOOP(MI, UN, SB) pair_loop<EFLAG, MI, UN, SB, LPB, AHEAD, DIAG, ALLSTYLES>(A, box, s_tab, s_bt, p, sub, L, nall, nb, bsh, ri, fxi, fyi, fzi, e, flags)
     if (A.uniform && !A.has_sb) {
       if (all_in) LE_LOOP(false, true, false); else LE_LOOP(true, true, false);
     } else if (!A.has_sb) {
@@ -441,7 +453,7 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
   }
   // no pair style (no list): the bonds come straight from the bond-partner table
   const int nbond = (DIAG && (A.diag & 1)) ? 0 : A.bpa;
-  const unsigned long long bsh = A.bshift[p];
+  const unsigned long long bsh = A.bond_minimg ? 0ull : A.bshift[p];
   int slot = 0;                                    // the images are stored by compacted slot (k_bond_table)
   for (int m = 0; m < nbond; m++) {
     const int eb = A.bpart[(size_t)m * A.npad + p];
@@ -449,7 +461,7 @@ __device__ __forceinline__ void bead_force(const ForceArgs &A, const BondTable &
     const int myslot = slot++;
     if ((m % LPB) != sub) continue;
     const double4 rj = A.pos[eb & BOND_IDX_MASK];
-    bond_term<EFLAG>(box, s_bt, p, ri, eb, rj, (unsigned)(bsh >> (BSHIFT_BITS * myslot)) & 63u, fxi, fyi, fzi, e, flags);
+    bond_term<EFLAG, ALLSTYLES>(box, s_bt, p, ri, eb, rj, (unsigned)(bsh >> (BSHIFT_BITS * myslot)) & 63u, A.bond_minimg != 0, fxi, fyi, fzi, e, flags);
   }
 }
 
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
     double4 ri = A.pos[p];
     const BeadPre L = bead_preload<HAS_PAIR, 1, true>(A, p, 0);
     double fxi = 0.0, fyi = 0.0, fzi = 0.0;
-    bead_force<EFLAG, HAS_PAIR, 1, NOBOND, true>(A, bt, box, s_tab, s_bt, p, 0, L, ri, fxi, fyi, fzi, e, flags);   // (DIAG = NOBOND: A.diag = 1 switches the bonds off)
+    bead_force<EFLAG, HAS_PAIR, 1, NOBOND, true, true>(A, bt, box, s_tab, s_bt, p, 0, L, ri, fxi, fyi, fzi, e, flags);   // (DIAG = NOBOND: A.diag = 1 switches the bonds off)
     fx[p] = fxi; fy[p] = fyi; fz[p] = fzi;
   }
   if (EFLAG && lb < A.nblocks) block_reduce_store<14>(e, partial, lb, 0);
@@ -645,7 +657,7 @@ void launch_ke(DeviceState &d, const TypeTables &tt) {
 static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   ForceArgs A;
   A.n = d.n; A.npad = d.npad; A.nblocks = (d.n + BLOCK - 1) / BLOCK; A.bpa = d.bpa; A.nt = d.ntypes + 1;
-  A.pos = d.pos; A.neigh = d.neigh; A.numneigh = d.numneigh; A.bpart = d.bpart; A.bshift = d.bshift; A.pairtab = d.pairtab;
+  A.pos = d.pos; A.neigh = d.neigh; A.numneigh = d.numneigh; A.bpart = d.bpart; A.bshift = d.bshift; A.bond_minimg = d.bond_minimg; A.pairtab = d.pairtab;
   A.sl0 = sl[0]; A.sl1 = sl[1]; A.sl2 = sl[2]; A.sl3 = sl[3];
   A.uniform = d.pair_uniform; A.u_cutsq = d.pair_u[0]; A.u_lj1 = d.pair_u[1]; A.u_lj2 = d.pair_u[2];
   A.u_lj3 = d.pair_u[3]; A.u_lj4 = d.pair_u[4]; A.u_off = d.pair_u[5];

@@ -158,7 +158,9 @@ __device__ __forceinline__ void bond_table_row(int s, int n, int npad, int t, co
   const int *rec = B.pack + (size_t)t * B.stride;
   int nb = rec[0];
   bool ghost = false;
-  const double4 rs = B.pos[s];
+  const bool freeze = B.bshift != nullptr;
+  double4 rs = make_double4(0.0, 0.0, 0.0, 0.0);
+  if (freeze) rs = B.pos[s];
   unsigned long long code = 0ull;
   int slot = 0;                             // row of this bond in the bead's list (switched-off bonds take none)
   for (int m = 0; m < B.bpa; m++) {
@@ -173,17 +175,19 @@ __device__ __forceinline__ void bond_table_row(int s, int n, int npad, int t, co
         e = (bt << BOND_TYPE_SHIFT) | q; ghost = ghost || q >= n;
         // Domain::closest_image at the build (src/ntopo_bond_all.cpp:59): the partner's image stays what it is now until
         // the next reneighbor, however the bond stretches in between
-        const double4 rq = B.pos[q];
-        const double dx = rs.x - rq.x, dy = rs.y - rq.y, dz = rs.z - rq.z;
-        const unsigned c = (dx > B.hx ? 1u : dx < -B.hx ? 2u : 0u) | (dy > B.hy ? 4u : dy < -B.hy ? 8u : 0u) |
-                           (dz > B.hz ? 16u : dz < -B.hz ? 32u : 0u);
-        code |= (unsigned long long)c << (BSHIFT_BITS * slot);
+        if (freeze) {
+          const double4 rq = B.pos[q];
+          const double dx = rs.x - rq.x, dy = rs.y - rq.y, dz = rs.z - rq.z;
+          const unsigned c = (dx > B.hx ? 1u : dx < -B.hx ? 2u : 0u) | (dy > B.hy ? 4u : dy < -B.hy ? 8u : 0u) |
+                             (dz > B.hz ? 16u : dz < -B.hz ? 32u : 0u);
+          code |= (unsigned long long)c << (BSHIFT_BITS * slot);
+        }
         slot++;
       }
     }
     B.bpart[(size_t)m * npad + s] = e;
   }
-  B.bshift[s] = code;
+  if (freeze) B.bshift[s] = code;
   if (B.phase && ghost) B.phase[s] = 1;     // reads a ghost position: phase 1 of a decomposed step
 }
 // packed bond records by tag (see DeviceState::bond_pack); run when the bond tables changed
@@ -503,7 +507,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
 #undef RANGE
 #undef RANGE_T
   if (!active) return;
-  numneigh[s] = min(cnt, maxneigh) | (min(nbond, maxneigh) << NN_BOND_SHIFT) | (bshift[s] ? NN_SHIFTED_BIT : 0);
+  numneigh[s] = min(cnt, maxneigh) | (min(nbond, maxneigh) << NN_BOND_SHIFT) | ((bshift && bshift[s]) ? NN_SHIFTED_BIT : 0);
   // The longest list is only needed when a list did not fit (the host then grows the table to it).  Recording it
   // unconditionally - one atomicMax per wavefront on ONE address - serialises 15.6k read-modify-writes in a single
   // L2 channel: 170 us of a 255 us kernel at 1M beads.
@@ -591,7 +595,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
     d.bond_pack_dirty = false;
   }
   BondTabArgs BT{d.bpa, d.maxtag, d.num_bond, d.bond_type, d.bond_atom, d.bond_pack, d.bond_pack_stride, d.bpart, d.dd ? d.phase : nullptr,
-                 d.pos, d.bshift, d.box.half[0], d.box.half[1], d.box.half[2]};
+                 d.pos, d.bond_minimg ? nullptr : d.bshift, d.box.half[0], d.box.half[1], d.box.half[2]};
   // (a launch of its own: folded into the prologue of the list build it made that kernel 48 us slower to save 16, and
   // even the unused extra kernel argument cost the build 32 us)
   hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.tag, d.map, BT, d.flags);
@@ -619,7 +623,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   hipLaunchKernelGGL((k_build_neigh<NOSP, AS, FR>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
                      d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, nsp, spl, msp, sf1,  \
-                     sf2, sf3, d.bpart, d.bpa, d.bshift, d.neigh, d.numneigh, d.flags, 0)
+                     sf2, sf3, d.bpart, d.bpa, d.bond_minimg ? nullptr : d.bshift, d.neigh, d.numneigh, d.flags, 0)
     if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false, false);
     else if (d.flags_h[FLAG_SPECIAL_ASYM]) { if (frac) BUILD(false, true, true); else BUILD(false, true, false); }   // sticky flag, read back at the last sync
     else if (frac) BUILD(false, false, true);
@@ -629,7 +633,7 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
       hipLaunchKernelGGL((k_build_neigh_diag<false, false, false>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map,
                          d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],
                          d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, d.nspecial, d.special, d.maxspecial, sf1,
-                         sf2, sf3, d.bpart, d.bpa, d.bshift, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
+                         sf2, sf3, d.bpart, d.bpa, d.bond_minimg ? nullptr : d.bshift, d.neigh, d.cell_of, d.flags + FLAG_AUX - FLAG_MAXNEIGH, atoi(dg) | 1);
     }
   }
 }

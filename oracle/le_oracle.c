@@ -699,7 +699,7 @@ static void pair_compute(leo_t *s, int eflag) {
     f[3 * i] += fx; f[3 * i + 1] += fy; f[3 * i + 2] += fz;
   }
 }
-/* src/MOLECULE/bond_fene.cpp:52-128, bond_harmonic.cpp:48-101, dispatch as bond_hybrid.cpp:66-152.
+/* src/MOLECULE/bond_fene.cpp:52-128, bond_harmonic.cpp:48-101, bond_morse.cpp:50-115, dispatch as bond_hybrid.cpp:66-152.
    A straddling bond is listed from both owned ends; each listing only updates its owned end
    (newton_bond off, i2 >= nlocal) and tallies half the energy/virial (src/bond.cpp ev_tally). */
 static int bond_compute(leo_t *s, int eflag) {
@@ -735,6 +735,10 @@ static int bond_compute(leo_t *s, int eflag) {
       double r = sqrt(rsq), dr = r - s->bp1[type], rk = s->bp0[type] * dr;
       fbond = (r > 0.0) ? -2.0 * rk / r : 0.0;
       if (eflag) ebond = rk * dr;
+    } else if (s->bstyle[type] == 3) {                 /* src/MOLECULE/bond_morse.cpp:50-115: D alpha r0 */
+      double r = sqrt(rsq), dr = r - s->bp2[type], ralpha = exp(-s->bp1[type] * dr);
+      fbond = (r > 0.0) ? -2.0 * s->bp0[type] * s->bp1[type] * (1 - ralpha) * ralpha / r : 0.0;
+      if (eflag) ebond = s->bp0[type] * (1 - ralpha) * (1 - ralpha);
     } else return seterr(s, "Bond coeffs not set");
     f[3 * i1] += dx * fbond; f[3 * i1 + 1] += dy * fbond; f[3 * i1 + 2] += dz * fbond;
     if (!ghost) { f[3 * i2] -= dx * fbond; f[3 * i2 + 1] -= dy * fbond; f[3 * i2 + 2] -= dz * fbond; }

@@ -58,7 +58,7 @@ void   leo_special_coul(leo_t *s, double c1, double c2, double c3);
 /* pair_style lj/cut rc ; mix: 0 geometric, 1 arithmetic ; shift: pair_modify shift yes */
 void   leo_pair_lj_cut(leo_t *s, double cut_global, int shift, int mix);
 void   leo_pair_coeff(leo_t *s, int i, int j, double eps, double sigma, double cut /* <0: global */);
-/* bond styles per bond type: 1 = fene (K R0 eps sigma), 2 = harmonic (K r0) */
+/* bond styles per bond type: 1 = fene (K R0 eps sigma), 2 = harmonic (K r0), 3 = morse (D alpha r0) */
 void   leo_bond_coeff(leo_t *s, int btype, int style, double p0, double p1, double p2, double p3);
 
 /* ---- settings ---- */

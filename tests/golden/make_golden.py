@@ -13,6 +13,7 @@ Sources (relative to /root/reference):
   unittest/force-styles/tests/mol-pair-lj_cut.yaml          -> lj_cut.json  (known answers)
   unittest/force-styles/tests/bond-fene.yaml                -> bond_fene.json
   unittest/force-styles/tests/bond-harmonic.yaml            -> bond_harmonic.json
+  unittest/force-styles/tests/bond-hybrid.yaml              -> bond_hybrid.json (hybrid harmonic morse: per-type dispatch)
   bench/data.chain                                          -> chain32k.npz (system)
   bench/log.6Oct16.chain.fixed.icc.1:48-49,68-76            -> chain32k_thermo.json
 """
@@ -77,7 +78,10 @@ def known_answers(path, ekey):
     text = open(path).read()
     out = {"epsilon": yaml_scalar(text, "epsilon")}
     coeff_key = "pair_coeff" if "pair_coeff" in text else "bond_coeff"
-    out[coeff_key] = yaml_block(text, coeff_key)
+    m = re.search(r"^%s: ! \|[-0-9]*\n((?:[ \t]+.*\n)+)" % re.escape(coeff_key), text, re.M)
+    rows = [r.split() for r in m.group(1).strip().split("\n")]
+    # hybrid styles name the sub-style in front of the numbers: keep it as a string
+    out[coeff_key] = [[float(v) if re.match(r"^[-+0-9.eE]+$", v) else v for v in r] for r in rows]
     for phase in ("init", "run"):
         out[phase + "_energy"] = yaml_scalar(text, "%s_%s" % (phase, ekey))
         out[phase + "_stress"] = yaml_block(text, phase + "_stress")[0]
@@ -110,6 +114,7 @@ def main():
     json.dump(lj, open(OUT + "/lj_cut.json", "w"))
     json.dump(known_answers(ft + "bond-fene.yaml", "energy"), open(OUT + "/bond_fene.json", "w"))
     json.dump(known_answers(ft + "bond-harmonic.yaml", "energy"), open(OUT + "/bond_harmonic.json", "w"))
+    json.dump(known_answers(ft + "bond-hybrid.yaml", "energy"), open(OUT + "/bond_hybrid.json", "w"))
 
     hdr, sec = parse_data(REF + "/bench/data.chain")
     a = np.array(sec["Atoms"], dtype=object)  # id mol type x y z ix iy iz  (atom_style bond)

@@ -107,7 +107,7 @@ class Oracle:
 
     def bond_coeff(self, bt, style, *p):
         p = list(p) + [0.0] * (4 - len(p))
-        self.L.leo_bond_coeff(self.h, C.c_int(bt), C.c_int({"fene": 1, "harmonic": 2}[style]), *[C.c_double(v) for v in p])
+        self.L.leo_bond_coeff(self.h, C.c_int(bt), C.c_int({"fene": 1, "harmonic": 2, "morse": 3}[style]), *[C.c_double(v) for v in p])
 
     def timestep(self, dt):
         self.L.leo_timestep(self.h, C.c_double(dt))

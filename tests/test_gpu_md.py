@@ -212,3 +212,40 @@ def test_device_ranmars_serial_stream():
         assert fn(seed, skip, count, ncalls, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) == 0
         ref = ranmars_stream(seed, skip + count)[skip:]
         assert np.array_equal(out, ref), (seed, skip, count, ncalls, np.nonzero(out != ref)[0][:5])
+
+
+@pytest.mark.parametrize("style,fixture", [("fene", "bond_fene.json"), ("harmonic", "bond_harmonic.json"),
+                                           ("hybrid harmonic morse", "bond_hybrid.json")])
+def test_fourmol_bond_known_answers(tmp_path, style, fixture):
+    """The HIP path against the reference's OWN known answers (unittest/force-styles/tests/bond-fene.yaml, bond-harmonic.yaml,
+    bond-hybrid.yaml on data.fourmol; fixtures made by tests/golden/make_golden.py): forces and bond energy of the initial
+    state and after 4 NVE steps, through the C-ABI.  The harness' `pair_style zero 8.0` becomes `zero 2.0` (no pair forces
+    either way; the engine's cell lists want a box of three neighbor cutoffs, data.fourmol's is 15 A)."""
+    from lammps_le_amd import lammps
+    d = json.load(open(os.path.join(G, "fourmol.json")))
+    g = json.load(open(os.path.join(G, fixture)))
+    tag = np.array(d["tag"])
+    order = np.argsort(tag)
+    n = d["natoms"]
+    sysd = dict(box=np.array(d["box"]), x=np.array(d["x"])[order], type=np.array(d["type"])[order], mol=np.array(d["mol"])[order],
+                image=np.array(d["image"])[order], v=np.array([d["vel"][str(t)] for t in tag[order]]),
+                bonds=np.array(d["bonds"], dtype=np.int32), ntypes=d["ntypes"], nbondtypes=d["nbondtypes"],
+                mass=[d["mass"][str(t + 1)] for t in range(d["ntypes"])])
+    data = os.path.join(str(tmp_path), "data.fourmol")
+    write_data(data, sysd)
+    lmp = lammps(cmdargs=["-screen", "none"])
+    for ln in ("units real", "atom_style bond", "atom_modify map array", "neigh_modify delay 2 every 2 check no", "timestep 0.1",
+               "special_bonds lj %g %g %g" % tuple(d["special_lj"]), "pair_style zero 2.0", "bond_style " + style,
+               "read_data " + data, "pair_coeff * *"):
+        lmp.command(ln)
+    for row in g["bond_coeff"]:
+        lmp.command("bond_coeff %d %s" % (int(row[0]), " ".join(str(v) for v in row[1:])))
+    lmp.command("thermo_modify norm no")
+    lmp.command("run 0")
+    assert abs(lmp.get_thermo("ebond") - g["init_energy"]) / abs(g["init_energy"]) < 5e-12
+    assert relerr(lmp.gather("f"), g["init_forces"]) < 1e-11
+    lmp.command("fix 1 all nve")
+    lmp.command("run 4")
+    assert abs(lmp.get_thermo("ebond") - g["run_energy"]) / abs(g["run_energy"]) < 5e-11
+    assert relerr(lmp.gather("f"), g["run_forces"]) < 1e-10
+    lmp.close()
