@@ -264,6 +264,8 @@ double lammps_le_stat(void *handle, const char *name) {
     return e->loop_time - all;
   }
   if (k == "comm_nranks") return e->comm ? (double)e->comm->nranks() : 1.0;
+  if (k == "comm_bytes_allgather") return e->comm ? e->comm->bytes_allgather : 0.0;
+  if (k == "comm_bytes_allreduce") return e->comm ? e->comm->bytes_allreduce : 0.0;
   if (k == "halo_window_mismatches") return e->dev ? (double)dd_halo_mismatches(*e->dev) : 0.0;   // LAMMPS_LE_FAST_HALO_VERIFY
   if (k == "halo_window_exchanges") return e->dev ? (double)e->dev->halo_seq : 0.0;   // per-step halos that went through the peer windows
   if (k == "pair_kernel_ms") return e->kstat_ms;

@@ -37,7 +37,7 @@ namespace lmp_le {
 namespace {
 typedef struct ncclComm *ncclComm_t;
 struct ncclUniqueId_ { char internal[128]; };
-enum { ncclInt32 = 2, ncclInt8 = 0, ncclFloat64 = 8 };
+enum { ncclInt32 = 2, ncclInt8 = 0, ncclUint32 = 3, ncclFloat64 = 8 };
 enum { ncclSum = 0, ncclMax = 2 };
 struct Rccl {
   void *h = nullptr;
@@ -382,6 +382,7 @@ long Comm::allreduce_host_max(long v) {
 void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
   require_alive();
   if (backend == NONE) return;
+  bytes_allreduce += 4.0 * (double)n;
   if (backend == RCCL) { NCCL_CHECK(rccl.AllReduce(dev, dev, n, ncclInt32, ncclMax, (ncclComm_t)rccl_comm, st)); return; }
   std::vector<int> h(n), all((size_t)world * n);
   HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -391,8 +392,22 @@ void Comm::allreduce_int_max(hipStream_t st, int *dev, int n) {
   HIP_CHECK(hipMemcpyAsync(dev, h.data(), n * sizeof(int), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));
 }
+void Comm::allreduce_u32_sum(hipStream_t st, unsigned *dev, size_t n) {
+  require_alive();
+  if (backend == NONE) return;
+  bytes_allreduce += 4.0 * (double)n;
+  if (backend == RCCL) { NCCL_CHECK(rccl.AllReduce(dev, dev, n, ncclUint32, ncclSum, (ncclComm_t)rccl_comm, st)); return; }
+  std::vector<unsigned> h(n), all((size_t)world * n);
+  HIP_CHECK(hipMemcpyAsync(h.data(), dev, n * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  allgather_host(h.data(), all.data(), n * sizeof(unsigned));
+  for (size_t k = 0; k < n; k++) { unsigned s = 0; for (int r = 0; r < world; r++) s += all[(size_t)r * n + k]; h[k] = s; }
+  HIP_CHECK(hipMemcpyAsync(dev, h.data(), n * sizeof(unsigned), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+}
 void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_t bytes) {
   require_alive();
+  bytes_allgather += (double)bytes;
   if (backend == NONE) { HIP_CHECK(hipMemcpyAsync(recv_dev, send_dev, bytes, hipMemcpyDeviceToDevice, st)); return; }
   if (backend == RCCL) { NCCL_CHECK(rccl.AllGather(send_dev, recv_dev, bytes, ncclInt8, (ncclComm_t)rccl_comm, st)); return; }
   if (backend == LOCAL) {

@@ -36,6 +36,10 @@ struct Comm {
   // device buffers
   void exchange(hipStream_t st, const std::vector<Msg> &sends, const std::vector<Msg> &recvs);
   void allreduce_int_max(hipStream_t st, int *dev, int n);
+  // element-wise sum of n 32-bit words; used for bit masks whose bits have exactly one owner each (sum = OR, no carries)
+  void allreduce_u32_sum(hipStream_t st, unsigned *dev, size_t n);
+  // bytes this rank contributed to device collectives since init (what a firing of the LE fixes moves: lammps_le_stat)
+  double bytes_allgather = 0.0, bytes_allreduce = 0.0;
   void allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
   // host buffers (rebuild-time counts, thermo sums)
   void exchange_host(const std::vector<Msg> &sends, const std::vector<Msg> &recvs);

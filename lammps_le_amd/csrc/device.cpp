@@ -94,7 +94,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.xht, nt);
   for (int k = 0; k < 16; k++) dalloc(d.le_i[k], nt);
   for (int k = 0; k < 2; k++) dalloc(d.le_d[k], nt);
-  dalloc(d.le_bits, nt / 64 + 16);
+  dalloc(d.le_bits, 3 * (nt / 64 + 16));     // three masks: base / accepted pairs, partner below, partner above
   dalloc(d.le_rng_state, LE_MAX_FIXES * 100);
   dalloc(d.le_draws, nt);
   dalloc(d.le_list, 4 * nt);

@@ -268,5 +268,9 @@ void publish_flags(DeviceState &d, unsigned reset_mask = 0);   // the same witho
 void wait_flags(DeviceState &d);                               // ... and the wait for the last publish
 void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);
 void dd_alloc(DeviceState &d, int world);
+// Decomposed runs, canonical visit order (local index = ID - 1, newton_pair off): the LE fixes work from owner-computed
+// bits and O(extruders) position records instead of an all-gather of every bead's (tag, x, xhold) (kernels_dd.hip
+// dd_gather_needed, kernels_le.hip launch_ex_load).  Other visit orders keep the whole-system gather.
+inline bool dd_le_fast(const DeviceState &d) { return d.dd && d.ident_order && !d.newton_pair && !getenv("LAMMPS_LE_DD_FULL_GATHER"); }
 
 }  // namespace lmp_le

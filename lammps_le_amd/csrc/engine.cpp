@@ -72,6 +72,12 @@ void Engine::halo_exchange() {
   dd_halo(*dev, *comm);
 }
 
+void Engine::halo_exchange_once() {
+  if (world <= 1 || halo_step == ntimestep) return;
+  halo_exchange();
+  halo_step = ntimestep;
+}
+
 void Engine::say(const std::string &s) {
   if (screen) { fputs(s.c_str(), screen); fflush(screen); }
   if (logfile) { fputs(s.c_str(), logfile); fflush(logfile); }
@@ -730,7 +736,7 @@ void Engine::iterate(long nsteps) {
       stamp(T_NEIGH);
     } else {
       stamp();
-      halo_exchange();     // ghosts follow their owners (CommBrick::forward_comm)
+      halo_exchange_once();     // ghosts follow their owners (CommBrick::forward_comm)
       stamp(T_COMM);
     }
     stamp();
@@ -986,6 +992,7 @@ void Engine::run(long nsteps) {
   dev->bond_pack_dirty = true;
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
+  halo_step = -1;
   host_current = false;
   double t0 = 0.0;
   try {

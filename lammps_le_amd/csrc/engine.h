@@ -320,6 +320,8 @@ class Engine {
   int world = 1, rank = 0;
   void comm_init(const std::string &backend, int rank, int world, const void *unique_id, const std::string &session);
   void halo_exchange();
+  void halo_exchange_once();          // ... unless this step's ghosts are already current (an LE fix asked first)
+  long halo_step = -1;
 
   // ---- device ----
   DeviceState *dev = nullptr;

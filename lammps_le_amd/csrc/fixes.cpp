@@ -9,6 +9,7 @@
 namespace lmp_le {
 
 void dd_gather_positions(DeviceState &d, Comm &comm);
+void dd_gather_needed(DeviceState &d, Comm &comm, int btype, bool with_nbrs);
 
 static void need_all(const std::vector<std::string> &arg) {
   if (arg[1] != "all") throw LammpsError("MI355X engine: fix group must be 'all' (got " + arg[1] + ")");
@@ -225,7 +226,11 @@ void FixExtrusion::post_integrate() {
   int slot = le_slot(eng, this);
   if (slot >= LE_MAX_FIXES) throw LammpsError("MI355X engine supports at most " + std::to_string(LE_MAX_FIXES) + " extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
-  if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
+  if (eng->world > 1) {
+    // stored coordinates of the extruder ends and the beads they can step to: O(extruders) rows (dd_gather_needed); every
+    // bead's (tag, x, xhold) only when the visit order is not the canonical one
+    if (dd_le_fast(d)) dd_gather_needed(d, *eng->comm, btype, true); else dd_gather_positions(d, *eng->comm);
+  }
   ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob};
   launch_extrusion(d, p, slot);
   d.topo_dirty = true;
@@ -249,7 +254,10 @@ void FixExLoad::post_integrate() {
     if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // current positions by tag (ghost slots lag one step here)
     launch_bond_create(d, p, slot, bondcount.data(), (int)bondcount.size(), eng->comm);
   } else {
-    if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
+    if (eng->world > 1) {
+      // canonical order: every rank decides the pairs whose storing bead it owns from its own list and (current) ghosts
+      if (dd_le_fast(d)) eng->halo_exchange_once(); else dd_gather_positions(d, *eng->comm);
+    }
     launch_ex_load(d, p, slot, eng->comm);
   }
   d.topo_dirty = true;
@@ -269,7 +277,9 @@ void FixExUnload::post_integrate() {
   int slot = le_slot(eng, this);
   if (slot >= LE_MAX_FIXES) throw LammpsError("MI355X engine supports at most " + std::to_string(LE_MAX_FIXES) + " extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
-  if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // replicated LE kernels need every bead's x / xhold
+  if (eng->world > 1) {
+    if (dd_le_fast(d)) dd_gather_needed(d, *eng->comm, btype, false); else dd_gather_positions(d, *eng->comm);
+  }
   ExUnloadParams p{btype, cutsq, fraction};
   launch_ex_unload(d, p, slot);
   d.topo_dirty = true;

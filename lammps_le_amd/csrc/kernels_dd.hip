@@ -288,7 +288,12 @@ __global__ __launch_bounds__(BLOCK) void k_dd_scatter_xt(long total, const doubl
 static void ensure_gather(DeviceState &d, size_t doubles_per_rank, int world) {
   size_t need = doubles_per_rank * (size_t)(world + 1);
   if (need > d.gather_cap) {
-    if (d.gather_send) (void)hipFree(d.gather_send);
+    // Regrow: no stream of this process may still touch the old buffer.  A peer rank that is a thread of this process copies
+    // out of it on ITS stream (comm.cpp local_exchange); the sender's host has seen that copy enqueued (the acknowledgement)
+    // but not finished, so the whole device is drained before the buffer goes.  (The round-1 crash record
+    // gpurun_out/prof_ov2.log - hipMemcpyAsync <- local_exchange on a pointer HIP no longer knew as device memory - is what a
+    // free under such a copy looks like; this is the one buffer of a decomposed run that is re-allocated while a run is live.)
+    if (d.gather_send) { HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(d.gather_send); }
     HIP_CHECK(hipMalloc(&d.gather_send, need * sizeof(double)));
     d.gather_cap = need;
   }
@@ -670,6 +675,65 @@ void dd_gather_positions(DeviceState &d, Comm &comm) {
   long total = (long)stride * comm.world;
   hipLaunchKernelGGL(k_dd_scatter_xt, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, total,
                      d.gather_recv, d.xt, d.xht);
+}
+
+// ---- what a firing of fix extrusion / ex_unload needs instead of every bead's position (canonical visit order) ----
+// The replicated kernels of these two fixes read stored coordinates only at the ends of the extruder bonds of the last
+// bond list (table 0) and, for extrusion, at their chain neighbours t - 1 / t + 1 (the beads an end can step to,
+// fix_extrusion.cpp:406-515).  The bond tables are replicated, so every rank knows which tags those are; each packs
+// (tag, x, type, xhold) of the ones it OWNS, the variable-length lists are all-gathered (padded to the longest; a padding
+// row has tag 0) and scattered into xt / xht by tag: O(extruders) rows of 64 bytes instead of N.  The shape of the
+// reference's own pack / unpack of touched atoms, src/USER-LE/fix_extrusion.cpp:1147-1419.
+__global__ __launch_bounds__(BLOCK) void k_dd_need_pack(int n, int T, int bpa, int btype, int with_nbrs, int cap,
+                                                        const int *__restrict__ tag, const int *__restrict__ num_bond0,
+                                                        const int *__restrict__ bond_type0, const double4 *__restrict__ pos,
+                                                        const double4 *__restrict__ xhold, double *__restrict__ out,
+                                                        int *__restrict__ counter) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  bool need = false;
+  int t = 0;
+  if (p < n) {
+    t = tag[p];
+    auto has = [&](int u) {          // (tags 0 and T + 1 are sentinels with no bonds)
+      if (u < 1 || u > T) return false;
+      const int nb = num_bond0[u];
+      for (int m = 0; m < nb; m++) if (bond_type0[(size_t)u * bpa + m] == btype) return true;
+      return false;
+    };
+    need = has(t) || (with_nbrs && (has(t - 1) || has(t + 1)));
+  }
+  const int slot = wave_append(need, counter);
+  if (need && slot < cap) {
+    double *b = out + (size_t)slot * GATH_LE_W;
+    const double4 r = pos[p], h = xhold[p];
+    b[0] = (double)t; b[1] = r.x; b[2] = r.y; b[3] = r.z; b[4] = r.w; b[5] = h.x; b[6] = h.y; b[7] = h.z;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_dd_need_pad(int from, int to, double *__restrict__ out) {
+  int i = from + blockIdx.x * BLOCK + threadIdx.x;
+  if (i < to) out[(size_t)i * GATH_LE_W] = 0.0;
+}
+void dd_gather_needed(DeviceState &d, Comm &comm, int btype, bool with_nbrs) {
+  dd_halo_wait(d);
+  hipStream_t st = d.stream;
+  // room for every owned bead: allocated once per system size (no regrow under a copy another rank's stream may still run)
+  ensure_gather(d, (size_t)d.npad * GATH_LE_W / std::max(1, comm.world) + (size_t)4096 * GATH_LE_W, comm.world);
+  const int cap = (int)((d.gather_recv - d.gather_send) / GATH_LE_W);
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_AUX, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_dd_need_pack, dim3(std::max(1, (d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.n, d.maxtag, d.bpa, btype,
+                     with_nbrs ? 1 : 0, cap, d.tag, d.num_bond0, d.bond_type0, d.pos, d.xhold, d.gather_send, d.flags + FLAG_AUX);
+  sync_flags(d);
+  const long mine = d.flags_h[FLAG_AUX];
+  const long most = comm.allreduce_host_max(mine);
+  if (most > cap) throw LammpsError("more extruder beads on one rank than the gather buffer holds (" + std::to_string(most) + ")");
+  if (most == 0) return;
+  if (mine < most)
+    hipLaunchKernelGGL(k_dd_need_pad, dim3((unsigned)((most - mine + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, (int)mine, (int)most,
+                       d.gather_send);
+  comm.allgather(st, d.gather_send, d.gather_recv, (size_t)most * GATH_LE_W * sizeof(double));
+  const long total = most * comm.world;
+  hipLaunchKernelGGL(k_dd_scatter_xt, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, total, d.gather_recv, d.xt,
+                     d.xht);
 }
 
 // host download of the whole system: rows of GATH_W doubles for every bead of every rank

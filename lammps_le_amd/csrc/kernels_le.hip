@@ -357,6 +357,52 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
   unsigned long long m = __ballot(base);
   if ((threadIdx.x & 63) == 0) bits[a >> 6] = m;
 }
+// Decomposed, canonical order: base(a) from what THIS rank holds.  Only the owner of the storing bead a (the lower local
+// index) has a's pair list, so only it can say whether (a, a+2) is an entry; it also has a+2's current position - an
+// entry of a's list is an owned bead or a ghost of the pair shell, and the halo was exchanged before the fix fired.  The
+// rank sets the bit of the pairs it decides, the masks of the ranks are summed (every bit has one owner: sum = or).
+// rsq of a pair is stored whenever both beads are here and one is owned: the owner of bead t later compares the two
+// pairs t belongs to (closest-wins), and computes the same double from the same two operands as the pair's own owner.
+__global__ __launch_bounds__(BLOCK) void k_exload_base_dd(Topo tp, ExLoadParams P, const double4 *__restrict__ pos,
+                                                          const int *__restrict__ bc, PairListView V,
+                                                          unsigned long long *__restrict__ bits,
+                                                          double *__restrict__ rsq_out) {
+  int a = blockIdx.x * BLOCK + threadIdx.x;
+  bool base = false;
+  if (a >= 1 && a + 2 <= tp.T) {
+    const int i = a, j = a + 2, mid = a + 1;
+    const int pa = V.map[i], pb = V.map[j];
+    if (pa >= 0 && pb >= 0 && (pa < V.n_owned || pb < V.n_owned)) {
+      int itype = tp.type_t[i], jtype = tp.type_t[j];
+      bool possible = false;
+      if (itype == P.iatomtype && jtype == P.jatomtype) {
+        if ((P.imaxbond == 0 || bc[i] < P.imaxbond) && (P.jmaxbond == 0 || bc[j] < P.jmaxbond)) possible = true;
+      } else if (itype == P.jatomtype && jtype == P.iatomtype) {
+        if ((P.jmaxbond == 0 || bc[i] < P.jmaxbond) && (P.imaxbond == 0 || bc[j] < P.imaxbond)) possible = true;
+      }
+      if (possible && tp.num_bond[i] == 2 && tp.num_bond[j] == 2 && tp.num_bond[mid] == 2) {
+        const int *sl = tp.special + (size_t)i * tp.ms;
+        int n1 = tp.nspecial[3 * (size_t)i];
+        for (int k = 0; k < n1; k++) if (sl[k] == j) possible = false;
+        if (possible) {
+          double rsq = d2(pos[pa], pos[pb]);   // a ghost is an unshifted copy of its owner's stored coordinates
+          rsq_out[a] = rsq;
+          base = rsq < P.cutsq;
+        }
+      }
+      if (base) {
+        base = false;
+        if (pa < V.n_owned) {
+          const int w = V.numneigh[pa], nn = w & NN_COUNT_MASK;
+          for (int k = (w >> NN_BOND_SHIFT) & NN_NBOND_MASK; k < nn; k++)
+            if ((V.neigh[(size_t)k * V.npad + pa] & NEIGH_MASK) == pb) { base = true; break; }
+        }
+      }
+    }
+  }
+  unsigned long long m = __ballot(base);
+  if ((threadIdx.x & 63) == 0) bits[a >> 6] = m;
+}
 __global__ __launch_bounds__(BLOCK) void k_exload_bits(int nt, const int *__restrict__ base_i,
                                                        unsigned long long *__restrict__ bits) {
   int a = blockIdx.x * BLOCK + threadIdx.x;
@@ -437,6 +483,37 @@ __global__ __launch_bounds__(BLOCK) void k_exload_partner(int T, const unsigned 
   partner[t] = p;
   haspartner[t] = p != 0;
 }
+// decomposed: the owner of bead t picks t's partner (it holds the distances of both pairs t can belong to) and publishes
+// the choice as one bit in one of two masks (partner below / above), which are summed over the ranks like the base bits
+__global__ __launch_bounds__(BLOCK) void k_exload_partner_dd(int T, int n_owned, const int *__restrict__ map,
+                                                             const unsigned long long *__restrict__ bits,
+                                                             const double *__restrict__ rsq,
+                                                             unsigned long long *__restrict__ m_lo,
+                                                             unsigned long long *__restrict__ m_hi) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  bool clo = false, chi = false;
+  if (t >= 1 && t <= T) {
+    const int p = map[t];
+    if (p >= 0 && p < n_owned) {
+      bool lo = (t >= 3) && accepted_at(bits, t - 2);
+      bool hi = (t + 2 <= T) && accepted_at(bits, t);
+      clo = lo;
+      if (hi && (!lo || rsq[t] < rsq[t - 2])) { chi = true; clo = false; }
+    }
+  }
+  unsigned long long a = __ballot(clo), b = __ballot(chi);
+  if ((threadIdx.x & 63) == 0) { m_lo[t >> 6] = a; m_hi[t >> 6] = b; }
+}
+__global__ __launch_bounds__(BLOCK) void k_exload_partner_unpack(int T, const unsigned long long *__restrict__ m_lo,
+                                                                 const unsigned long long *__restrict__ m_hi,
+                                                                 int *__restrict__ partner, int *__restrict__ haspartner) {
+  int t = blockIdx.x * BLOCK + threadIdx.x;
+  if (t > T + 1) return;
+  int p = 0;
+  if (t >= 1 && t <= T) { if (bit_at(m_lo, t)) p = t - 2; else if (bit_at(m_hi, t)) p = t + 2; }
+  partner[t] = p;
+  haspartner[t] = p != 0;
+}
 __global__ __launch_bounds__(BLOCK) void k_exload_create(Topo tp, ExLoadParams P, const int *__restrict__ partner,
                                                          const int *__restrict__ didx,
                                                          const uint32_t *__restrict__ draws, int *__restrict__ bc,
@@ -491,7 +568,16 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
                  {d.ref_nbin[0], d.ref_nbin[1], d.ref_nbin[2]}, d.xht};
   int *tmp_a = d.le_i[I_F], *tmp_b = d.le_i[I_G];
   const bool id_order_scan = d.ident_order && !d.newton_pair;
-  if (d.dd && id_order_scan) {
+  if (dd_le_fast(d)) {
+    // owner-computed bits instead of every bead's position: two mask reductions of N / 8 and N / 4 bytes per rank
+    const size_t words = (size_t)nt / 64 + 16;
+    unsigned long long *m_lo = d.le_bits + words, *m_hi = d.le_bits + 2 * words;
+    hipLaunchKernelGGL(k_exload_base_dd, dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.pos, bc, V, d.le_bits, d.le_d[0]);
+    comm->allreduce_u32_sum(st, (unsigned *)d.le_bits, 2 * (size_t)(nbw * BLOCK / 64));
+    hipLaunchKernelGGL(k_exload_partner_dd, dim3(nbw), dim3(BLOCK), 0, st, T, d.n, d.map, d.le_bits, d.le_d[0], m_lo, m_hi);
+    comm->allreduce_u32_sum(st, (unsigned *)m_lo, 2 * 2 * words);
+    hipLaunchKernelGGL(k_exload_partner_unpack, dim3(nb), dim3(BLOCK), 0, st, T, m_lo, m_hi, partner, has);
+  } else if (d.dd && id_order_scan) {
     int *base_i = d.le_i[I_E];
     hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
     comm->allreduce_int_max(st, base_i, nt);       // the owner of bead a knows whether (a, a+2) is in its list
