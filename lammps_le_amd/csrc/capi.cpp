@@ -264,6 +264,9 @@ double lammps_le_stat(void *handle, const char *name) {
     return e->loop_time - all;
   }
   if (k == "comm_nranks") return e->comm ? (double)e->comm->nranks() : 1.0;
+  if (k == "rng_late_generations") return (double)e->rng_late_count;
+  if (k == "rng_segments_held") return e->dev ? (double)rng_segments_held(*e->dev) : 0.0;
+  if (k == "rng_segments") return e->dev ? (double)e->dev->rng_nseg : 0.0;
   if (k == "comm_bytes_allgather") return e->comm ? e->comm->bytes_allgather : 0.0;
   if (k == "comm_bytes_allreduce") return e->comm ? e->comm->bytes_allreduce : 0.0;
   if (k == "halo_window_mismatches") return e->dev ? (double)dd_halo_mismatches(*e->dev) : 0.0;   // LAMMPS_LE_FAST_HALO_VERIFY

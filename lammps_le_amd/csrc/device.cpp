@@ -83,8 +83,8 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.partial, (size_t)d.nred_blocks * 16);
   HIP_CHECK(hipHostMalloc((void **)&d.partial_h, (size_t)d.nred_blocks * 16 * sizeof(double)));
   dalloc(d.flags, NFLAGS);
-  HIP_CHECK(hipHostMalloc((void **)&d.flags_h, (NFLAGS + 16) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
-  for (int k = 0; k < NFLAGS + 16; k++) d.flags_h[k] = 0;
+  HIP_CHECK(hipHostMalloc((void **)&d.flags_h, (FLAG_SEQ_SLOT + 16) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+  for (int k = 0; k < FLAG_SEQ_SLOT + 16; k++) d.flags_h[k] = 0;
   d.flags_seq = 0;
   d.bins_ready = false;
   d.cell_count_dirty = false;    // (freshly allocated arrays are zeroed)
@@ -156,7 +156,7 @@ __global__ void k_publish_flags(int *__restrict__ flags, int *__restrict__ host,
     if ((reset >> k) & 1u) flags[k] = 0;
   }
   __syncthreads();
-  if (k == 0) __hip_atomic_store(&host[NFLAGS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (k == 0) __hip_atomic_store(&host[FLAG_SEQ_SLOT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void stream_sync(DeviceState &d) {
   if (d.comm_watch) d.comm_watch->wait_stream(d.stream);
@@ -178,10 +178,10 @@ void wait_flags(DeviceState &d) {
     volatile int *h = d.flags_h;
     auto t0 = std::chrono::steady_clock::now();
     long it = 0;
-    while (h[NFLAGS] != seq) {
+    while (h[FLAG_SEQ_SLOT] != seq) {
       if ((++it & 0xFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;   // long-running
     }                                                                            // work (or a fault): block instead
-    if (h[NFLAGS] == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }   // pairs with the release store
+    if (h[FLAG_SEQ_SLOT] == seq) { std::atomic_thread_fence(std::memory_order_acquire); return; }   // pairs with the release store
   }
   stream_sync(d);
 }

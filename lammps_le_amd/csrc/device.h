@@ -39,8 +39,10 @@ enum FlagSlot {
   FLAG_RECV_DN = 13,
   FLAG_SEND_BOTH = 14,
   FLAG_GHOST_MIXED = 15, // decomposition: ghosts from below and above are not two separate blocks of the cell order  // decomposition: some bead is in both send lists (slab barely two shells thick)   // some bead's 1-2 list lost an entry its partner still has (see dev_special_remove12)
-  NFLAGS = 16
+  FLAG_RNG_MISS = 16,    // decomposition: an owned bead's Langevin draws lie in a stream segment this rank skipped (kernels_rng.hip)
+  NFLAGS = 24
 };
+constexpr int FLAG_SEQ_SLOT = 32;   // the publish sequence number in the mapped host page: a 64-byte sector of its own
 enum DevErr {
   ERR_NONE = 0, ERR_BAD_FENE = 1, ERR_BOND_MISSING = 2, ERR_EXT_MULTI = 3, ERR_BPA = 4,
   ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8, ERR_GHOST_ORDER = 9,
@@ -140,7 +142,13 @@ struct DeviceState {
   long long rng_total = 0;         // draws per call = 3 * beads in the system
   int rng_nseg = 1;                // batch generator: segments per call (one wavefront each) and their length
   long long rng_seglen = 0;
-  uint32_t *rng_wstate = nullptr;  // [W][97] window in front of each wave's next call
+  uint32_t *rng_wstate = nullptr;  // [3][W * S][97] windows in front of each (call, segment) of a batch: batch b reads copy b % 3, writes (b + 1) % 3
+  long long rng_batch_no[2] = {0, 0};          // number of the batch each pool holds (selects the window copy it started from)
+  // decomposed runs: a rank generates only the stream segments that hold draws of beads it owns or ghosts (kernels_rng.hip)
+  int *rng_need = nullptr;         // [S] segments wanted by the batch about to be launched
+  int *rng_gen[2] = {nullptr, nullptr};        // [S] segments each pool holds
+  int *rng_late = nullptr;         // [2][S] segments the validation found missing (generated late, from the kept windows)
+  bool rng_skip = false;           // segment skipping is on (decomposed, batch mode)
   uint32_t *rng_pool[2] = {nullptr, nullptr};   // [W][3N]
   uint64_t rng_batch_raw[2] = {0, 0};           // raw index of the first draw held by each pool (0 = empty)
   int rng_pool_cur = 0;
@@ -235,6 +243,12 @@ void sort_scratch_free(DeviceState &d);
 void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms);
 void launch_rng_langevin(DeviceState &d, uint64_t first_raw);
 void rng_langevin_consumed(DeviceState &d);
+// decomposed runs, after every change of ownership or of the canonical ranks (rebuild with migration, Atom::sort): do the
+// pools hold the draws of every owned bead?  Enqueues the check; rng_late_generate() (after the flags reached the host)
+// produces what was missing before the next step consumes it
+void rng_validate_owned(DeviceState &d);
+void rng_late_generate(DeviceState &d);
+int rng_segments_held(DeviceState &d);
 void launch_ranmars_gen(DeviceState &d, int slot, const int *count_ptr, uint32_t *out, int maxout);
 
 // LE fixes (kernels_le.hip)

@@ -405,12 +405,14 @@ void Engine::reneighbor(bool defer_check) {
   // FLAG_MOVED / NEIGH_OVERFLOW / MAXNEIGH are zero here: they are reset by the publish kernel that reports them
   if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);
   else launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
+  if (d.dd) rng_validate_owned(d);               // beads that migrated in: are their Langevin draws in this rank's pools?
   if (defer_check && !d.dd) {
     publish_flags(d, 1u << FLAG_MOVED);          // NEIGH_OVERFLOW stays set on the device: the step kernel reads it
     reneigh_pending = true;
   } else {
     sync_flags(d, 1u << FLAG_MOVED);
     check_device_error(this, d);
+    if (d.flags_h[FLAG_RNG_MISS]) { rng_late_generate(d); rng_late_count++; }
     if (d.flags_h[FLAG_NEIGH_OVERFLOW]) regrow_lists();
   }
   if (d.le_snapshot && d.topo_dirty) {   // NTopoBond::build: the bond list the LE fixes will see until the next reneighbor
@@ -498,6 +500,11 @@ void Engine::emulate_atom_sort() {
   if (world > 1) dd_gather_positions(*dev, *comm);      // decomposed: the one-rank order from everybody's wrapped positions
   launch_atom_sort(*dev, nb, binv, world > 1);
   crank_on_device = true;
+  if (world > 1) {        // the canonical ranks changed: so did the stream segments this rank draws from
+    rng_validate_owned(*dev);
+    sync_flags(*dev);
+    if (dev->flags_h[FLAG_RNG_MISS]) { rng_late_generate(*dev); rng_late_count++; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

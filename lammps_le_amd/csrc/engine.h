@@ -265,6 +265,7 @@ class Engine {
   std::vector<ThermoRow> thermo_log;
   double loop_time = 0.0;
   long neigh_builds = 0, neigh_dangerous = 0;
+  long rng_late_count = 0;     // decomposed runs: late generations of skipped Langevin stream segments (lammps_le_stat)
   int ago = 0;
   // Timer sections of the loop (src/timer.h:25-28); wall clock between stamps as src/timer.cpp:100-135.  The GPU runs
   // asynchronously behind the host, so without `timer sync` a section holds the time the HOST spent in it (waits for

@@ -70,9 +70,15 @@ __global__ __launch_bounds__(64) void k_rng_langevin(int B, long long total, uns
 // latency-bound trickle (one wave per block, ~1 KB LDS) that runs on rng_stream underneath the step kernels of
 // the previous batch; per consumed call nothing is launched at all.
 // ring index of y_i (i = draw index within this wave's call) is (i + 97) & 255.
+// Decomposed runs (`need` != nullptr): a segment none of this rank's owned or ghost beads draws from is SKIPPED - its
+// window is moved W calls ahead with x^(W * total) straight from the segment's start (96 recurrence values + the same
+// 97 x 97 products), nothing is generated or stored.  `st_out` == nullptr: late generation of segments a validation found
+// missing (a bead migrated in from beyond the ghost shell): generate from the kept input windows, leave the state alone.
 __global__ __launch_bounds__(64) void k_rng_calls(long long total, long long seglen, int nseg,
-                                                  unsigned long long base_raw, uint32_t *__restrict__ wstate,
-                                                  const uint32_t *__restrict__ jump, uint32_t *__restrict__ pool) {
+                                                  unsigned long long base_raw, const uint32_t *__restrict__ wstate,
+                                                  uint32_t *__restrict__ st_out_all,
+                                                  const uint32_t *__restrict__ jump, uint32_t *__restrict__ pool,
+                                                  const int *__restrict__ need, int *__restrict__ genmask) {
   __shared__ uint32_t ring[256];
   __shared__ uint32_t a[97];
   const int CM = 16777213, STEP64 = (int)((64ull * 7654321ull) % 16777213ull);
@@ -82,8 +88,32 @@ __global__ __launch_bounds__(64) void k_rng_calls(long long total, long long seg
   const int w = blockIdx.x / nseg, sg = blockIdx.x % nseg, lane = threadIdx.x;
   const long long seg0 = (long long)sg * seglen;
   const long long len = min(seglen, total - seg0);             // draws of this segment
-  uint32_t *st = wstate + (size_t)blockIdx.x * 97;
+  const uint32_t *st = wstate + (size_t)blockIdx.x * 97;
+  uint32_t *st_out = st_out_all ? st_out_all + (size_t)blockIdx.x * 97 : nullptr;
   uint32_t *out = pool + (size_t)w * total + seg0;
+  const bool gen = need == nullptr || need[sg] != 0;
+  if (!st_out && gen && w == 0 && lane == 0) genmask[sg] = 1;     // late generation: the pool now holds this segment too
+  if (!gen) {
+    if (!st_out) return;
+    // skip: y_0 .. y_95 behind the window (three steps of the plain recurrence), then the window W calls later
+    for (int k = lane; k < 97; k += 64) { ring[k] = st[k]; a[k] = jump[2 * 97 + k]; }
+    __syncthreads();
+    for (int base = 0; base < 96; base += 33) {
+      const int i = base + lane;
+      if (lane < 33 && i < 96) ring[97 + i] = (ring[i] - ring[i + 64]) & M24;
+      __syncthreads();
+    }
+    uint32_t s0 = 0, s1 = 0;
+    const int j1 = lane + 64;
+    for (int j = 0; j < 97; j++) {
+      const uint32_t aj = a[j];
+      s0 += aj * ring[lane + j];
+      if (j1 < 97) s1 += aj * ring[j1 + j];
+    }
+    st_out[lane] = s0 & M24;
+    if (j1 < 97) st_out[j1] = s1 & M24;
+    return;
+  }
   unsigned long long raw0 = base_raw + (unsigned long long)w * (unsigned long long)total + (unsigned long long)seg0;
   const uint32_t *jp = jump + (sg == nseg - 1 ? 97 : 0);        // the last segment is shorter: its own jump distance
   for (int k = lane; k < 97; k += 64) { ring[k] = st[k]; a[k] = jp[k]; }
@@ -116,13 +146,41 @@ __global__ __launch_bounds__(64) void k_rng_calls(long long total, long long seg
     acc0 += aj * ring[(t0 + lane + j) & 255];
     if (i1 < 97) acc1 += aj * ring[(t0 + i1 + j) & 255];
   }
-  st[lane] = acc0 & M24;
-  if (i1 < 97) st[i1] = acc1 & M24;
+  if (st_out) {
+    st_out[lane] = acc0 & M24;
+    if (i1 < 97) st_out[i1] = acc1 & M24;
+  }
+}
+
+// segments that hold draws of the beads in [0, m) (owned, then ghosts): 3 draws per bead at 3 * canonical rank
+__global__ __launch_bounds__(256) void k_rng_mark(int m, const int *__restrict__ tag, const int *__restrict__ crank,
+                                                  long long seglen, int *__restrict__ need) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= m) return;
+  const int t = tag[p];
+  const long long r = crank ? crank[t] : t - 1;
+  need[(int)((3 * r) / seglen)] = 1;
+}
+// owned beads whose segment a live pool does not hold: wanted[pool][seg] = 1, FLAG_RNG_MISS
+__global__ __launch_bounds__(256) void k_rng_validate(int n, const int *__restrict__ tag, const int *__restrict__ crank,
+                                                      long long seglen, int nseg, const int *__restrict__ gen0,
+                                                      const int *__restrict__ gen1, int live0, int live1,
+                                                      int *__restrict__ late, int *__restrict__ flags) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int t = tag[p];
+  const long long r = crank ? crank[t] : t - 1;
+  const int sg = (int)((3 * r) / seglen);
+  if (live0 && !gen0[sg]) { late[sg] = 1; flags[FLAG_RNG_MISS] = 1; }
+  if (live1 && !gen1[sg]) { late[nseg + sg] = 1; flags[FLAG_RNG_MISS] = 1; }
 }
 
 static void rng_free_batch(DeviceState &d) {
   for (int k = 0; k < 2; k++) if (d.rng_pool[k]) { (void)hipFree(d.rng_pool[k]); d.rng_pool[k] = nullptr; }
   if (d.rng_wstate) { (void)hipFree(d.rng_wstate); d.rng_wstate = nullptr; }
+  if (d.rng_need) { (void)hipFree(d.rng_need); d.rng_need = nullptr; }
+  if (d.rng_late) { (void)hipFree(d.rng_late); d.rng_late = nullptr; }
+  for (int k = 0; k < 2; k++) if (d.rng_gen[k]) { (void)hipFree(d.rng_gen[k]); d.rng_gen[k] = nullptr; }
   d.rng_batch_raw[0] = d.rng_batch_raw[1] = 0;
 }
 
@@ -154,7 +212,11 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
     long long w = pool_cap / (8 * total);
     int W = (int)std::min<long long>(512, std::max<long long>(8, w));
     if (getenv("LAMMPS_LE_RNG_W")) W = std::max(2, atoi(getenv("LAMMPS_LE_RNG_W")));
-    if (W != d.rng_W || total != d.rng_total) {
+    // decomposed runs cut a call into segments of <= 65535 draws and generate only the ones that hold draws of owned or
+    // ghost beads (the rest of the stream is jumped over); one GPU generates everything, in ~1024 wavefronts per batch
+    const bool skip = d.dd && !getenv("LAMMPS_LE_RNG_NO_SKIP");
+    if (W != d.rng_W || total != d.rng_total || skip != d.rng_skip) {
+      d.rng_skip = skip;
       rng_free_batch(d);
       d.rng_W = W; d.rng_total = total;
       // segments per call: ~1024 wavefronts per batch, segments no shorter than 64k draws (measured: 8M beads 1389 / 1430 /
@@ -164,15 +226,24 @@ void rng_langevin_setup(DeviceState &d, RanMarsInt &host_rng, int natoms) {
       if ((long long)S * 256 > total) S = 1;
       d.rng_nseg = S;
       d.rng_seglen = (total + S - 1) / S;
+      if (skip && !getenv("LAMMPS_LE_RNG_SEGMENTS")) { d.rng_seglen = std::min<long long>(65535, total); d.rng_nseg = S = (int)((total + d.rng_seglen - 1) / d.rng_seglen); }
+      d.rng_seglen = (d.rng_seglen + 2) / 3 * 3;       // a bead's three draws never straddle two segments
+      d.rng_nseg = S = (int)((total + d.rng_seglen - 1) / d.rng_seglen);
       for (int k = 0; k < 2; k++) HIP_CHECK(hipMalloc(&d.rng_pool[k], (size_t)W * total * sizeof(uint32_t)));
-      HIP_CHECK(hipMalloc(&d.rng_wstate, (size_t)W * S * 97 * sizeof(uint32_t)));
+      HIP_CHECK(hipMalloc(&d.rng_wstate, 3 * (size_t)W * S * 97 * sizeof(uint32_t)));
+      HIP_CHECK(hipMalloc(&d.rng_need, 2 * (size_t)S * sizeof(int)));      // one per pool
+      HIP_CHECK(hipMalloc(&d.rng_late, 2 * (size_t)S * sizeof(int)));
+      for (int k = 0; k < 2; k++) HIP_CHECK(hipMalloc(&d.rng_gen[k], (size_t)S * sizeof(int)));
+      HIP_CHECK(hipMemset(d.rng_late, 0, 2 * (size_t)S * sizeof(int)));
       if (d.rng_jump) { (void)hipFree(d.rng_jump); d.rng_jump = nullptr; }
-      HIP_CHECK(hipMalloc(&d.rng_jump, 2 * 97 * sizeof(uint32_t)));
-      // a segment's window goes from the end of the segment to the start of the same segment W calls later
-      uint32_t a[2 * 97];
+      HIP_CHECK(hipMalloc(&d.rng_jump, 3 * 97 * sizeof(uint32_t)));
+      // a segment's window goes from the end of the segment to the start of the same segment W calls later; a skipped
+      // segment's from its start (third polynomial)
+      uint32_t a[3 * 97];
       const long long len_last = total - (long long)(S - 1) * d.rng_seglen;
       ranmars_jump_poly((uint64_t)total * (uint64_t)W - (uint64_t)d.rng_seglen, a);
       ranmars_jump_poly((uint64_t)total * (uint64_t)W - (uint64_t)len_last, a + 97);
+      ranmars_jump_poly((uint64_t)total * (uint64_t)W, a + 2 * 97);
       HIP_CHECK(hipMemcpyAsync(d.rng_jump, a, sizeof a, hipMemcpyHostToDevice, d.stream));
       HIP_CHECK(hipStreamSynchronize(d.stream));
     }
@@ -219,12 +290,65 @@ static void rng_generate(DeviceState &d, int buf, uint64_t first_raw) {
                      (unsigned long long)first_raw, d.rng_state, d.rng_jump, d.rng_buf[buf]);
   HIP_CHECK(hipEventRecord(d.rng_done[buf], d.rng_stream));
 }
-static void rng_gen_batch(DeviceState &d, int pool, uint64_t base_raw, bool wait_consumed) {
+static hipEvent_t rng_mark_event() {
+  static thread_local hipEvent_t ev = nullptr;
+  if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  return ev;
+}
+// `batch_no`: 0, 1, 2, .. since the last seeding; batch b starts from window copy b % 3 and leaves copy (b + 1) % 3, so
+// the input windows of the two live batches survive for a late generation
+static void rng_gen_batch(DeviceState &d, int pool, uint64_t base_raw, bool wait_consumed, long long batch_no) {
+  const size_t copy = (size_t)d.rng_W * d.rng_nseg * 97;
+  int *need = d.rng_need + (size_t)pool * d.rng_nseg;
+  if (d.rng_skip) {
+    // what this rank will draw from, as of now: owned beads and ghosts (a bead beyond the ghost shell that arrives while
+    // the batch is live is caught by rng_validate_owned at the rebuild that brings it).  The pool's previous batch has
+    // been consumed, i.e. the main stream is past it: its `need` / `gen` words are free.  gen is written on the MAIN
+    // stream, where the validation reads it (the batch itself runs on rng_stream for milliseconds).
+    HIP_CHECK(hipMemsetAsync(need, 0, (size_t)d.rng_nseg * sizeof(int), d.stream));
+    const int m = d.n + d.nghost;
+    hipLaunchKernelGGL(k_rng_mark, dim3(std::max(1, (m + 255) / 256)), dim3(256), 0, d.stream, m, d.tag,
+                       d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, need);
+    HIP_CHECK(hipMemcpyAsync(d.rng_gen[pool], need, (size_t)d.rng_nseg * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
+    HIP_CHECK(hipEventRecord(rng_mark_event(), d.stream));
+    HIP_CHECK(hipStreamWaitEvent(d.rng_stream, rng_mark_event(), 0));
+  }
   if (wait_consumed) HIP_CHECK(hipStreamWaitEvent(d.rng_stream, d.rng_consumed[pool], 0));
   hipLaunchKernelGGL(k_rng_calls, dim3(d.rng_W * d.rng_nseg), dim3(64), 0, d.rng_stream, d.rng_total, d.rng_seglen, d.rng_nseg,
-                     (unsigned long long)base_raw, d.rng_wstate, d.rng_jump, d.rng_pool[pool]);
+                     (unsigned long long)base_raw, d.rng_wstate + (size_t)(batch_no % 3) * copy,
+                     d.rng_wstate + (size_t)((batch_no + 1) % 3) * copy, d.rng_jump, d.rng_pool[pool],
+                     d.rng_skip ? need : (const int *)nullptr, (int *)nullptr);
   HIP_CHECK(hipEventRecord(d.rng_done[pool], d.rng_stream));
   d.rng_batch_raw[pool] = base_raw;
+  d.rng_batch_no[pool] = batch_no;
+}
+int rng_segments_held(DeviceState &d) {     // segments of a call the current pool holds (= all of them unless skipping)
+  if (!d.rng_skip || !d.rng_gen[0]) return d.rng_nseg;
+  std::vector<int> g((size_t)d.rng_nseg);
+  HIP_CHECK(hipStreamSynchronize(d.stream));
+  HIP_CHECK(hipMemcpy(g.data(), d.rng_gen[d.rng_pool_cur], g.size() * sizeof(int), hipMemcpyDeviceToHost));
+  int c = 0;
+  for (int v : g) c += v != 0;
+  return c;
+}
+void rng_validate_owned(DeviceState &d) {
+  if (!d.rng_skip || d.rng_mode != 1 || !d.rng_gen[0] || (!d.rng_batch_raw[0] && !d.rng_batch_raw[1])) return;
+  hipLaunchKernelGGL(k_rng_validate, dim3(std::max(1, (d.n + 255) / 256)), dim3(256), 0, d.stream, d.n, d.tag,
+                     d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, d.rng_nseg, d.rng_gen[0], d.rng_gen[1],
+                     d.rng_batch_raw[0] ? 1 : 0, d.rng_batch_raw[1] ? 1 : 0, d.rng_late, d.flags);
+}
+void rng_late_generate(DeviceState &d) {
+  // (rare: a bead reached this slab from beyond the ghost shell within the life of a batch, or the canonical ranks changed)
+  const size_t copy = (size_t)d.rng_W * d.rng_nseg * 97;
+  for (int pool = 0; pool < 2; pool++) {
+    if (!d.rng_batch_raw[pool]) continue;
+    HIP_CHECK(hipStreamWaitEvent(d.stream, d.rng_done[pool], 0));
+    hipLaunchKernelGGL(k_rng_calls, dim3(d.rng_W * d.rng_nseg), dim3(64), 0, d.stream, d.rng_total, d.rng_seglen, d.rng_nseg,
+                       (unsigned long long)d.rng_batch_raw[pool], d.rng_wstate + (size_t)(d.rng_batch_no[pool] % 3) * copy,
+                       (uint32_t *)nullptr, d.rng_jump, d.rng_pool[pool], d.rng_late + (size_t)pool * d.rng_nseg, d.rng_gen[pool]);
+  }
+  HIP_CHECK(hipMemsetAsync(d.rng_late, 0, 2 * (size_t)d.rng_nseg * sizeof(int), d.stream));
+  HIP_CHECK(hipMemsetAsync(d.flags + FLAG_RNG_MISS, 0, sizeof(int), d.stream));
 }
 // wave windows in front of calls first_raw + w*3N, w = 0..W-1, from the host generator; then two batches
 static void rng_seed_batches(DeviceState &d, uint64_t first_raw) {
@@ -261,8 +385,8 @@ static void rng_seed_batches(DeviceState &d, uint64_t first_raw) {
   HIP_CHECK(hipMemcpyAsync(d.rng_wstate, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice, d.rng_stream));
   HIP_CHECK(hipStreamSynchronize(d.rng_stream));
   uint64_t span = (uint64_t)d.rng_total * (uint64_t)d.rng_W;
-  rng_gen_batch(d, 0, first_raw, false);
-  rng_gen_batch(d, 1, first_raw + span, false);
+  rng_gen_batch(d, 0, first_raw, false, 0);
+  rng_gen_batch(d, 1, first_raw + span, false, 1);
   d.rng_pool_cur = 0;
   HIP_CHECK(hipStreamWaitEvent(d.stream, d.rng_done[0], 0));
 }
@@ -279,7 +403,7 @@ void launch_rng_langevin(DeviceState &d, uint64_t first_raw) {
       if (inside(q)) {
         // every consumer of pool p is already enqueued on d.stream: refill it with the batch after q
         HIP_CHECK(hipEventRecord(d.rng_consumed[p], d.stream));
-        rng_gen_batch(d, p, d.rng_batch_raw[q] + span, true);
+        rng_gen_batch(d, p, d.rng_batch_raw[q] + span, true, d.rng_batch_no[q] + 1);
         HIP_CHECK(hipStreamWaitEvent(d.stream, d.rng_done[q], 0));
         d.rng_pool_cur = p = q;
       } else {
