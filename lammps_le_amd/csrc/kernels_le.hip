@@ -594,13 +594,19 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
     hipLaunchKernelGGL((k_exload_base<1>), dim3(nbw), dim3(BLOCK), 0, st, tp, P, d.xt, bc, V, d.le_bits, d.le_d[0], base_i);
     if (d.dd) comm->allreduce_int_max(st, base_i, nt);   // (keys and everything after are functions of replicated data: same rounds on every rank)
     hipLaunchKernelGGL(k_exload_greedy_init, dim3(nb), dim3(BLOCK), 0, st, nt, base_i, state);
-    for (int batch = 0; batch < 4096; batch++) {
+    // rounds per host look: a round decides at least the pair with the smallest key of every undecided run, so a batch
+    // grows with the rounds already spent (8, 16, 32, .. 256) instead of one host round trip per 8 rounds
+    bool settled = false;
+    for (int batch = 0, rounds = 8; batch < 4096 && !settled; batch++, rounds = std::min(2 * rounds, 256)) {
       HIP_CHECK(hipMemsetAsync(d.flags + FLAG_AUX, 0, sizeof(int), st));
-      for (int r = 0; r < 8; r++)
+      for (int r = 0; r < rounds; r++)
         hipLaunchKernelGGL(k_exload_greedy_round, dim3(nb), dim3(BLOCK), 0, st, T, key, state, d.flags + FLAG_AUX);
       sync_flags(d);
-      if (!d.flags_h[FLAG_AUX]) break;
+      // FLAG_AUX = some pair changed state in this batch: one more batch is needed to see a batch without changes
+      settled = !d.flags_h[FLAG_AUX];
     }
+    // never drop undecided pairs silently: the topology would differ from the reference's without any sign
+    if (!settled) throw LammpsError("fix ex_load: the acceptance rounds did not converge (internal error)");
     hipLaunchKernelGGL(k_exload_accept_bits, dim3(nbw), dim3(BLOCK), 0, st, nt, state, d.le_bits);
     hipLaunchKernelGGL((k_exload_partner<true>), dim3(nb), dim3(BLOCK), 0, st, T, d.le_bits, d.le_d[0], key, partner, has);
   }
