@@ -25,6 +25,7 @@ typedef struct {
   leo_ranmars rng;
   /* LE common */
   int nevery, btype;
+  int atype;                 /* ex_load: angle type created with every new bond (0 = none), fix_ex_load.cpp:855-954 */
   int phase;                 /* fires when ntimestep % nevery == phase */
   long next_reneighbor;
   double cutsq, fraction;
@@ -57,6 +58,15 @@ struct leo {
   double special_lj[4], special_coul[4];   /* src/force.cpp:47-49: coul defaults 0 0 0 (no Coulomb here; only the list flags use it) */
   /* bonds */
   int *bstyle; double *bp0, *bp1, *bp2, *bp3;
+  /* angles (newton_bond off: each of the three atoms stores the angle, src/atom.cpp:1290-1353) */
+  int nangletypes, apa;                 /* angle types, angles per atom */
+  int *num_angle, *angle_type, *angle_a1, *angle_a2, *angle_a3;      /* [n], [n * apa] local-index order, atoms as tags */
+  int *astyle; double *ak, *atheta0;    /* per type: 1 harmonic (k, theta0 in radians), 2 cosine (k) */
+  long nangles;
+  int unload_angleflag;                 /* FixExUnload::init: angles exist -> broken bonds take their angles with them */
+  int nanglelist, maxanglelist; int *al_i; signed char *al_s;        /* anglelist: 4 ints (i1 i2 i3 type) + 9 image shifts per entry */
+  double eangle, vangle[6];
+  int *nve_mask;                        /* by tag: 1 = integrated by fix nve (nullptr: group all) */
   /* neighbor */
   double skin, cutneighmax, triggersq; int every, delay, check, ago;
   int newton_pair;        /* `newton on|off [bond]`: who stores an owned-owned pair (half/bin/newton vs newtoff); bonds are always newton off */
@@ -190,6 +200,8 @@ void leo_free(leo_t *s) {
   free(s->thermo_hist);
   free(s->bondcount); free(s->ia); free(s->ib); free(s->ic); free(s->id); free(s->ie);
   free(s->da); free(s->db); free(s->copy);
+  free(s->num_angle); free(s->angle_type); free(s->angle_a1); free(s->angle_a2); free(s->angle_a3);
+  free(s->astyle); free(s->ak); free(s->atheta0); free(s->al_i); free(s->al_s); free(s->nve_mask);
   free(s);
 }
 /* src/update.cpp:132-200 (set_units) */
@@ -312,6 +324,61 @@ void leo_bond_coeff(leo_t *s, int bt, int style, double p0, double p1, double p2
   s->bstyle[bt] = style; s->bp0[bt] = p0; s->bp1[bt] = p1; s->bp2[bt] = p2; s->bp3[bt] = p3;
 }
 /* src/pair_lj_cut.cpp:512-569 init_one ; mixing src/pair.cpp mix_energy/mix_distance */
+/* Angles section of a data file (src/atom.cpp:1290-1353, newton_bond off): stored with atom2 first, then atom1, then atom3.
+   apa = the largest count over the atoms + extra_angle ("extra angle per atom").  Call after leo_set_atoms. */
+void leo_set_angles(leo_t *s, int nangletypes, int nangles, const int *atype, const int *a1, const int *a2, const int *a3,
+                    int extra_angle) {
+  int n = s->n;
+  int *count = calloc(n, sizeof(int)), apa = 0;
+  for (int k = 0; k < nangles; k++) { count[map_(s, a1[k])]++; count[map_(s, a2[k])]++; count[map_(s, a3[k])]++; }
+  for (int i = 0; i < n; i++) if (count[i] > apa) apa = count[i];
+  free(count);
+  apa += extra_angle;
+  if (apa < 1) apa = 1;
+  s->apa = apa; s->nangletypes = nangletypes; s->nangles = nangles;
+  free(s->num_angle); free(s->angle_type); free(s->angle_a1); free(s->angle_a2); free(s->angle_a3);
+  s->num_angle = calloc(n, sizeof(int)); s->angle_type = calloc((size_t)n * apa, sizeof(int));
+  s->angle_a1 = calloc((size_t)n * apa, sizeof(int)); s->angle_a2 = calloc((size_t)n * apa, sizeof(int));
+  s->angle_a3 = calloc((size_t)n * apa, sizeof(int));
+  free(s->astyle); free(s->ak); free(s->atheta0);
+  s->astyle = calloc(nangletypes + 1, sizeof(int)); s->ak = calloc(nangletypes + 1, sizeof(double));
+  s->atheta0 = calloc(nangletypes + 1, sizeof(double));
+  for (int k = 0; k < nangles; k++) {
+    const int order[3] = { a2[k], a1[k], a3[k] };
+    for (int q = 0; q < 3; q++) {
+      int m = map_(s, order[q]), c = s->num_angle[m]++;
+      s->angle_type[(size_t)m * apa + c] = atype[k];
+      s->angle_a1[(size_t)m * apa + c] = a1[k]; s->angle_a2[(size_t)m * apa + c] = a2[k]; s->angle_a3[(size_t)m * apa + c] = a3[k];
+    }
+  }
+}
+/* angle_coeff: style 1 = harmonic (K theta0[degrees], src/MOLECULE/angle_harmonic.cpp:170-196), 2 = cosine (K, angle_cosine.cpp:124-146) */
+void leo_angle_coeff(leo_t *s, int type, int style, double k, double theta0_deg) {
+  s->astyle[type] = style; s->ak[type] = k; s->atheta0[type] = theta0_deg / 180.0 * 3.14159265358979323846;
+}
+/* fix nve on a group: flag by tag (1 = integrated).  The reference's group mask, fix_nve.cpp:82 */
+void leo_nve_group(leo_t *s, const int *flag_by_tag) {
+  free(s->nve_mask);
+  s->nve_mask = malloc(((size_t)s->maxtag + 1) * sizeof(int));
+  s->nve_mask[0] = 0;
+  memcpy(s->nve_mask + 1, flag_by_tag, (size_t)s->maxtag * sizeof(int));
+}
+void leo_ex_load_atype(leo_t *s, int fix_index, int atype) { s->fix[fix_index].atype = atype; }
+long leo_nangles(leo_t *s) { return s->nangles; }
+int leo_angle_per_atom(leo_t *s) { return s->apa; }
+void leo_get_angles(leo_t *s, int *na, int *at, int *a1, int *a2, int *a3) {      /* tag order */
+  for (int i = 0; i < s->n; i++) {
+    size_t t = (size_t)(s->tag[i] - 1);
+    na[t] = s->num_angle ? s->num_angle[i] : 0;
+    for (int m = 0; m < s->apa; m++) {
+      at[t * s->apa + m] = s->angle_type[(size_t)i * s->apa + m]; a1[t * s->apa + m] = s->angle_a1[(size_t)i * s->apa + m];
+      a2[t * s->apa + m] = s->angle_a2[(size_t)i * s->apa + m]; a3[t * s->apa + m] = s->angle_a3[(size_t)i * s->apa + m];
+    }
+  }
+}
+double leo_angle_energy(leo_t *s) { return s->eangle; }
+void leo_angle_virial(leo_t *s, double *o) { memcpy(o, s->vangle, sizeof s->vangle); }
+
 static void pair_init(leo_t *s) {
   int nt = s->ntypes + 1;
   s->cutneighmax = 0.0;
@@ -467,6 +534,10 @@ static void atom_sort(leo_t *s) {
   swap_perm_d(s->x, perm, n, 3); swap_perm_d(s->v, perm, n, 3); swap_perm_d(s->f, perm, n, 3);
   swap_perm_i(s->num_bond, perm, n, 1); swap_perm_i(s->bond_type, perm, n, s->bpa); swap_perm_i(s->bond_atom, perm, n, s->bpa);
   swap_perm_i(s->nspecial, perm, n, 3); swap_perm_i(s->special, perm, n, s->maxspecial);
+  if (s->apa) {
+    swap_perm_i(s->num_angle, perm, n, 1); swap_perm_i(s->angle_type, perm, n, s->apa);
+    swap_perm_i(s->angle_a1, perm, n, s->apa); swap_perm_i(s->angle_a2, perm, n, s->apa); swap_perm_i(s->angle_a3, perm, n, s->apa);
+  }
   for (int i = 0; i < n; i++) s->map[s->tag[i]] = i;
   free(binhead); free(next); free(perm);
 }
@@ -518,6 +589,150 @@ static void build_bondlist(leo_t *s) {
       }
     }
 }
+/* src/ntopo_angle_all.cpp:37-93 with newton_bond off: the copy stored on atom i is listed if i <= every one of its three
+   atoms, each taken as the image closest to i (Domain::closest_image; a periodic image is a ghost, index >= nlocal, so it
+   never blocks the listing): an angle inside the box is listed once, from its lowest local index; one that straddles a
+   face is listed from every atom that sees the others as images, and each listing only moves its owned atoms. */
+static void build_anglelist(leo_t *s) {
+  s->nanglelist = 0;
+  if (!s->apa || !s->num_angle) return;
+  for (int i = 0; i < s->n; i++)
+    for (int m = 0; m < s->num_angle[i]; m++) {
+      const int tg[3] = { s->angle_a1[(size_t)i * s->apa + m], s->angle_a2[(size_t)i * s->apa + m], s->angle_a3[(size_t)i * s->apa + m] };
+      int idx[3]; signed char sh[9]; int listed = 1;
+      for (int q = 0; q < 3; q++) {
+        idx[q] = map_(s, tg[q]);
+        if (idx[q] < 0) { seterr(s, "Angle atoms missing"); return; }
+        double d[3] = { s->x[3 * i] - s->x[3 * idx[q]], s->x[3 * i + 1] - s->x[3 * idx[q] + 1], s->x[3 * i + 2] - s->x[3 * idx[q] + 2] };
+        minimg(s, d, sh + 3 * q);
+        int ghost = sh[3 * q] || sh[3 * q + 1] || sh[3 * q + 2];
+        if (!ghost && idx[q] < i) listed = 0;
+      }
+      if (!listed) continue;
+      if (s->nanglelist == s->maxanglelist) {
+        s->maxanglelist = s->maxanglelist ? 2 * s->maxanglelist : 1024;
+        s->al_i = realloc(s->al_i, 4 * (size_t)s->maxanglelist * sizeof(int)); s->al_s = realloc(s->al_s, 9 * (size_t)s->maxanglelist);
+      }
+      int k = s->nanglelist++;
+      s->al_i[4 * k] = idx[0]; s->al_i[4 * k + 1] = idx[1]; s->al_i[4 * k + 2] = idx[2]; s->al_i[4 * k + 3] = s->angle_type[(size_t)i * s->apa + m];
+      memcpy(s->al_s + 9 * k, sh, 9);
+    }
+}
+/* src/MOLECULE/angle_harmonic.cpp:53-147, angle_cosine.cpp:49-121; tallies as Angle::ev_tally (src/angle.cpp:164-250) with
+   newton_bond off: a third of the energy / virial per OWNED atom of the listing */
+#define ANGLE_SMALL 0.001
+static int angle_compute(leo_t *s, int eflag) {
+  if (eflag) { s->eangle = 0.0; memset(s->vangle, 0, sizeof s->vangle); }
+  const double *x = s->x; double *f = s->f;
+  for (int n = 0; n < s->nanglelist; n++) {
+    const int i1 = s->al_i[4 * n], i2 = s->al_i[4 * n + 1], i3 = s->al_i[4 * n + 2], type = s->al_i[4 * n + 3];
+    const signed char *sh = s->al_s + 9 * n;
+    if (type <= 0 || s->astyle[type] == 0) continue;
+    double p1[3], p2[3], p3[3];
+    for (int d = 0; d < 3; d++) {
+      p1[d] = x[3 * i1 + d] + sh[d] * s->prd[d]; p2[d] = x[3 * i2 + d] + sh[3 + d] * s->prd[d]; p3[d] = x[3 * i3 + d] + sh[6 + d] * s->prd[d];
+    }
+    const int own1 = !(sh[0] || sh[1] || sh[2]), own2 = !(sh[3] || sh[4] || sh[5]), own3 = !(sh[6] || sh[7] || sh[8]);
+    double delx1 = p1[0] - p2[0], dely1 = p1[1] - p2[1], delz1 = p1[2] - p2[2];
+    double rsq1 = delx1 * delx1 + dely1 * dely1 + delz1 * delz1, r1 = sqrt(rsq1);
+    double delx2 = p3[0] - p2[0], dely2 = p3[1] - p2[1], delz2 = p3[2] - p2[2];
+    double rsq2 = delx2 * delx2 + dely2 * dely2 + delz2 * delz2, r2 = sqrt(rsq2);
+    double c = delx1 * delx2 + dely1 * dely2 + delz1 * delz2;
+    c /= r1 * r2;
+    if (c > 1.0) c = 1.0;
+    if (c < -1.0) c = -1.0;
+    double a, eangle = 0.0;
+    if (s->astyle[type] == 1) {
+      double sn = sqrt(1.0 - c * c);
+      if (sn < ANGLE_SMALL) sn = ANGLE_SMALL;
+      sn = 1.0 / sn;
+      double dtheta = acos(c) - s->atheta0[type], tk = s->ak[type] * dtheta;
+      if (eflag) eangle = tk * dtheta;
+      a = -2.0 * tk * sn;
+    } else {
+      if (eflag) eangle = s->ak[type] * (1.0 + c);
+      a = s->ak[type];
+    }
+    double a11 = a * c / rsq1, a12 = -a / (r1 * r2), a22 = a * c / rsq2;
+    double f1[3] = { a11 * delx1 + a12 * delx2, a11 * dely1 + a12 * dely2, a11 * delz1 + a12 * delz2 };
+    double f3[3] = { a22 * delx2 + a12 * delx1, a22 * dely2 + a12 * dely1, a22 * delz2 + a12 * delz1 };
+    if (own1) { f[3 * i1] += f1[0]; f[3 * i1 + 1] += f1[1]; f[3 * i1 + 2] += f1[2]; }
+    if (own2) { f[3 * i2] -= f1[0] + f3[0]; f[3 * i2 + 1] -= f1[1] + f3[1]; f[3 * i2 + 2] -= f1[2] + f3[2]; }
+    if (own3) { f[3 * i3] += f3[0]; f[3 * i3 + 1] += f3[1]; f[3 * i3 + 2] += f3[2]; }
+    if (eflag) {
+      const double third = 1.0 / 3.0;
+      double v[6] = { delx1 * f1[0] + delx2 * f3[0], dely1 * f1[1] + dely2 * f3[1], delz1 * f1[2] + delz2 * f3[2],
+                      delx1 * f1[1] + delx2 * f3[1], delx1 * f1[2] + delx2 * f3[2], dely1 * f1[2] + dely2 * f3[2] };
+      for (int o = 0; o < 3; o++) {
+        if (!(o == 0 ? own1 : o == 1 ? own2 : own3)) continue;
+        s->eangle += third * eangle;
+        for (int q = 0; q < 6; q++) s->vangle[q] += third * v[q];
+      }
+    }
+  }
+  return 0;
+}
+/* FixExLoad::create_angles (fix_ex_load.cpp:855-954, newton_bond off) for local atom m; `created`: this firing's new bonds */
+static int create_angles(leo_t *s, leo_fix *fx, int m, int ncreate, const int *created, long *nangles) {
+  const int apa = s->apa, ms = s->maxspecial;
+  int num = s->num_angle[m];
+  int *at = s->angle_type + (size_t)m * apa, *a1 = s->angle_a1 + (size_t)m * apa, *a2 = s->angle_a2 + (size_t)m * apa, *a3 = s->angle_a3 + (size_t)m * apa;
+  int overflow = 0;
+#define NEWBOND(I1, I2, I3) ({ int n_; for (n_ = 0; n_ < ncreate; n_++) { \
+    if (created[2 * n_] == (I1) && created[2 * n_ + 1] == (I2)) break; if (created[2 * n_] == (I2) && created[2 * n_ + 1] == (I1)) break; \
+    if (created[2 * n_] == (I2) && created[2 * n_ + 1] == (I3)) break; if (created[2 * n_] == (I3) && created[2 * n_ + 1] == (I2)) break; } n_ < ncreate; })
+  /* atom M central: pairs of its 1-2 neighbours */
+  int i2 = s->tag[m], n2 = s->nspecial[3 * m];
+  const int *s2list = s->special + (size_t)m * ms;
+  for (int i = 0; i < n2; i++)
+    for (int j = i + 1; j < n2; j++) {
+      int i1 = s2list[i], i3 = s2list[j];
+      if (!NEWBOND(i1, i2, i3)) continue;
+      if (num < apa) { at[num] = fx->atype; a1[num] = i1; a2[num] = i2; a3[num] = i3; num++; (*nangles)++; }
+      else overflow = 1;
+    }
+  /* atom M as atom 1 of the angle */
+  int i1 = s->tag[m], n1 = s->nspecial[3 * m];
+  const int *s1list = s->special + (size_t)m * ms;
+  for (int i = 0; i < n1; i++) {
+    i2 = s1list[i];
+    int i2local = map_(s, i2);
+    if (i2local < 0) return seterr(s, "Fix ex_load needs ghost atoms from further away");
+    const int *sl2 = s->special + (size_t)i2local * ms;
+    n2 = s->nspecial[3 * i2local];
+    for (int j = 0; j < n2; j++) {
+      int i3 = sl2[j];
+      if (i3 == i1) continue;
+      if (!NEWBOND(i1, i2, i3)) continue;
+      if (num < apa) { at[num] = fx->atype; a1[num] = i1; a2[num] = i2; a3[num] = i3; num++; (*nangles)++; }
+      else overflow = 1;
+    }
+  }
+#undef NEWBOND
+  s->num_angle[m] = num;
+  return overflow ? seterr(s, "Fix ex_load induced too many angles/dihedrals/impropers per atom") : 0;
+}
+/* FixExUnload::break_angles (fix_ex_unload.cpp:551-582) */
+static void break_angles(leo_t *s, int m, int id1, int id2, long *nangles) {
+  const int apa = s->apa;
+  int num = s->num_angle[m];
+  int *at = s->angle_type + (size_t)m * apa, *a1 = s->angle_a1 + (size_t)m * apa, *a2 = s->angle_a2 + (size_t)m * apa, *a3 = s->angle_a3 + (size_t)m * apa;
+  int i = 0;
+  while (i < num) {
+    int found = 0;
+    if (a1[i] == id1 && a2[i] == id2) found = 1;
+    else if (a2[i] == id1 && a3[i] == id2) found = 1;
+    else if (a1[i] == id2 && a2[i] == id1) found = 1;
+    else if (a2[i] == id2 && a3[i] == id1) found = 1;
+    if (!found) i++;
+    else {
+      for (int j = i; j < num - 1; j++) { at[j] = at[j + 1]; a1[j] = a1[j + 1]; a2[j] = a2[j + 1]; a3[j] = a3[j + 1]; }
+      num--; (*nangles)++;
+    }
+  }
+  s->num_angle[m] = num;
+}
+
 /* Which end of an owned-owned pair stores it in the half list (positions = those of the build, s->xhold).
    newton_pair off, npair_half_bin_newtoff.cpp:90: the lower local index.
    newton_pair on,  npair_half_bin_newton.cpp:84-149: atoms of one bin -> the one earlier in the bin's list (= lower local
@@ -549,7 +764,7 @@ static void neigh_build(leo_t *s) {
   s->npairs = 0;
   double cutneighsq = s->cutneighmax * s->cutneighmax;
   int nc[3]; s->brute = 0;
-  if (!s->pair_on || s->cutneighmax <= 0.0) { build_bondlist(s); return; }
+  if (!s->pair_on || s->cutneighmax <= 0.0) { build_bondlist(s); build_anglelist(s); return; }
   for (int d = 0; d < 3; d++) {
     nc[d] = (int)(s->prd[d] / s->cutneighmax);
     if (nc[d] < 3) s->brute = 1;
@@ -571,7 +786,7 @@ static void neigh_build(leo_t *s) {
           signed char sh[3] = { (signed char)sx, (signed char)sy, (signed char)sz };
           push_pair(s, i, j, which, sh);
         }
-    build_bondlist(s);
+    build_bondlist(s); build_anglelist(s);
     return;
   }
   /* cell list, cells >= cutneigh, 27-cell stencil, minimum image (box >= 3 cells per dim) */
@@ -616,7 +831,7 @@ static void neigh_build(leo_t *s) {
   }
   s->firstneigh[n] = (int)s->npairs;
   free(head); free(cellof); free(order);
-  build_bondlist(s);
+  build_bondlist(s); build_anglelist(s);
 }
 
 /* src/neighbor.cpp:1933-1948 decide + :1962-2014 check_distance */
@@ -757,6 +972,7 @@ static int bond_compute(leo_t *s, int eflag) {
 static void nve_initial(leo_t *s) {
   double dtv = s->dt, dtf = 0.5 * s->dt * s->ftm2v;
   for (int i = 0; i < s->n; i++) {
+    if (s->nve_mask && !s->nve_mask[s->tag[i]]) continue;          /* group mask, fix_nve.cpp:82 */
     double dtfm = dtf / s->mass[s->type[i]];
     for (int d = 0; d < 3; d++) { s->v[3 * i + d] += dtfm * s->f[3 * i + d]; s->x[3 * i + d] += dtv * s->v[3 * i + d]; }
   }
@@ -764,6 +980,7 @@ static void nve_initial(leo_t *s) {
 static void nve_final(leo_t *s) {
   double dtf = 0.5 * s->dt * s->ftm2v;
   for (int i = 0; i < s->n; i++) {
+    if (s->nve_mask && !s->nve_mask[s->tag[i]]) continue;
     double dtfm = dtf / s->mass[s->type[i]];
     for (int d = 0; d < 3; d++) s->v[3 * i + d] += dtfm * s->f[3 * i + d];
   }
@@ -834,24 +1051,35 @@ static int rebuild_special_one(leo_t *s, int m) {
   return 0;
 }
 /* influence rule for broken bonds: fix_extrusion.cpp:940-969 / fix_ex_unload.cpp:417-483 */
-static int topo_broken(leo_t *s, int nbreak, const int *broken) {
+/* angles: 1 = FixExUnload::update_topology (break_angles for every broken bond that influences the atom, :445-460; the
+   angle count goes down by a third of the removed copies, :466-472); 0 = FixExtrusion::update_topology, which leaves angles alone */
+static int topo_broken(leo_t *s, int nbreak, const int *broken, int angles) {
+  long nang = 0;
   for (int i = 0; i < s->n; i++) {
     int influenced = 0; const int *slist = s->special + (size_t)i * s->maxspecial;
-    for (int j = 0; j < nbreak && !influenced; j++) {
-      int id1 = broken[2 * j], id2 = broken[2 * j + 1];
-      if (s->tag[i] == id1 || s->tag[i] == id2) influenced = 1;
+    for (int j = 0; j < nbreak && (angles || !influenced); j++) {
+      int id1 = broken[2 * j], id2 = broken[2 * j + 1], influence = 0;
+      if (s->tag[i] == id1 || s->tag[i] == id2) influence = 1;
       else {
         int n = s->nspecial[3 * i + 2], found = 0;
         for (int k = 0; k < n; k++) if (slist[k] == id1 || slist[k] == id2) found++;
-        if (found == 2) influenced = 1;
+        if (found == 2) influence = 1;
       }
+      if (!influence) continue;
+      influenced = 1;
+      if (angles) break_angles(s, i, id1, id2, &nang);
     }
     if (influenced && rebuild_special_one(s, i)) return 1;
   }
+  s->nangles -= nang / 3;
   return 0;
 }
 /* influence rule for created bonds: fix_extrusion.cpp:971-1001 / fix_ex_load.cpp:720-753 */
-static int topo_created(leo_t *s, int ncreate, const int *created) {
+static int create_angles(leo_t *s, leo_fix *fx, int m, int ncreate, const int *created, long *nangles);
+/* fx != NULL with fx->atype and an angle style: FixExLoad::update_topology creates the angles the new bonds induce */
+static int topo_created(leo_t *s, int ncreate, const int *created, leo_fix *fx) {
+  long nang = 0;
+  const int angleflag = fx && fx->atype > 0 && s->apa > 0 && s->astyle;
   for (int i = 0; i < s->n; i++) {
     int influenced = 0; const int *slist = s->special + (size_t)i * s->maxspecial;
     for (int j = 0; j < ncreate && !influenced; j++) {
@@ -863,7 +1091,9 @@ static int topo_created(leo_t *s, int ncreate, const int *created) {
       }
     }
     if (influenced && rebuild_special_one(s, i)) return 1;
+    if (influenced && angleflag && create_angles(s, fx, i, ncreate, created, &nang)) return 1;
   }
+  s->nangles += nang / 3;
   return 0;
 }
 /* delete bond to `partner` from atom i by shifting: fix_extrusion.cpp:656-668 */
@@ -1047,7 +1277,7 @@ static int fire_extrusion(leo_t *s, leo_fix *fx) {
     int j = map_(s, final_to_add[i]);
     if (j < 0 || tag[i] < tag[j]) { created[2 * ncr] = tag[i]; created[2 * ncr + 1] = final_to_add[i]; ncr++; }
   }
-  int rc = topo_broken(s, nb, broken) || topo_created(s, ncr, created);
+  int rc = topo_broken(s, nb, broken, 0) || topo_created(s, ncr, created, NULL);
   free(broken); free(created);
   return rc;
 }
@@ -1139,7 +1369,7 @@ static int fire_ex_load(leo_t *s, leo_fix *fx) {
     int j = map_(s, finalpartner[i]);
     if (j < 0 || tag[i] < tag[j]) { created[2 * nc] = tag[i]; created[2 * nc + 1] = finalpartner[i]; nc++; }
   }
-  int rc = topo_created(s, nc, created);
+  int rc = topo_created(s, nc, created, fx);
   free(created);
   return rc;
 }
@@ -1217,7 +1447,7 @@ static int fire_bond_create(leo_t *s, leo_fix *fx) {
     int j = map_(s, finalpartner[i]);
     if (j < 0 || tag[i] < tag[j]) { created[2 * nc] = tag[i]; created[2 * nc + 1] = finalpartner[i]; nc++; }
   }
-  int rc = topo_created(s, nc, created);
+  int rc = topo_created(s, nc, created, fx);
   free(created);
   return rc;
 }
@@ -1268,7 +1498,7 @@ static int fire_ex_unload(leo_t *s, leo_fix *fx) {
     int j = map_(s, finalpartner[i]);
     if (j < 0 || tag[i] < tag[j]) { broken[2 * nb] = tag[i]; broken[2 * nb + 1] = finalpartner[i]; nb++; }
   }
-  int rc = topo_broken(s, nb, broken);
+  int rc = topo_broken(s, nb, broken, s->unload_angleflag);     /* fix_ex_unload.cpp:149-152: set in init() */
   free(broken);
   return rc;
 }
@@ -1296,11 +1526,12 @@ static void thermo_eval(leo_t *s, double *out) {
   double norm = (s->units == 0) ? (double)n : 1.0;               /* thermo_modify norm default: lj yes */
   double ke = temp * 0.5 * dof * s->boltz;                        /* src/thermo.cpp compute_ke */
   double vol = s->prd[0] * s->prd[1] * s->prd[2];
-  double vir = s->vpair[0] + s->vpair[1] + s->vpair[2] + s->vbond[0] + s->vbond[1] + s->vbond[2];
+  double vir = s->vpair[0] + s->vpair[1] + s->vpair[2] + s->vbond[0] + s->vbond[1] + s->vbond[2] + s->vangle[0] + s->vangle[1] + s->vangle[2];
+  const double emol = s->ebond + s->eangle;                       /* thermo keyword emol = ebond + eangle (+ ...) src/thermo.cpp */
   double press = (dof * s->boltz * temp + vir) / 3.0 / vol * s->nktv2p;   /* src/compute_pressure.cpp:228-236 */
-  out[0] = temp; out[1] = s->evdwl / norm; out[2] = s->ebond / norm; out[3] = (ke + s->evdwl + s->ebond) / norm;
+  out[0] = temp; out[1] = s->evdwl / norm; out[2] = emol / norm; out[3] = (ke + s->evdwl + emol) / norm;
   out[4] = press; out[5] = ke / norm; out[6] = s->evdwl; out[7] = s->ebond;
-  for (int k = 0; k < 6; k++) out[8 + k] = s->vpair[k] + s->vbond[k];
+  for (int k = 0; k < 6; k++) out[8 + k] = s->vpair[k] + s->vbond[k] + s->vangle[k];
 }
 static void thermo_record(leo_t *s) {
   if (s->nthermo == s->maxthermo) {
@@ -1322,6 +1553,7 @@ static int run_init(leo_t *s) {
   pair_init(s);
   s->triggersq = 0.25 * s->skin * s->skin;                        /* src/neighbor.cpp:240- init */
   for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_init(s, &s->fix[k]);
+  s->unload_angleflag = s->nangles > 0;
   if (!s->num_bond) { int z = 0; leo_set_bonds(s, 0, &z, &z, &z); }
   if (!s->special) leo_special_build(s, s->special_lj[1], s->special_lj[2], s->special_lj[3]);
   return 0;
@@ -1336,6 +1568,7 @@ static int verlet_setup(leo_t *s) {
   memset(s->f, 0, 3 * (size_t)s->n * sizeof(double));
   pair_compute(s, 1);
   if (bond_compute(s, 1)) return 1;
+  angle_compute(s, 1);
   /* modify->setup: FixLangevin::setup -> post_force (src/fix_langevin.cpp:372-373) */
   for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_post_force(s, &s->fix[k]);
   for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_BOND_CREATE) bond_create_setup(s, &s->fix[k]);
@@ -1349,7 +1582,8 @@ int leo_setup_forces(leo_t *s) {
   if (s->errflag) return 1;
   memset(s->f, 0, 3 * (size_t)s->n * sizeof(double));
   pair_compute(s, 1);
-  return bond_compute(s, 1);
+  if (bond_compute(s, 1)) return 1;
+  return angle_compute(s, 1);
 }
 /* ===================== run_style respa (src/respa.cpp) ===================== */
 static void copy_flevel_f(leo_t *s, int l) {                       /* :793-815 */
@@ -1495,7 +1729,7 @@ int leo_run(leo_t *s, int nsteps) {
     }
     memset(s->f, 0, 3 * (size_t)s->n * sizeof(double));
     t0 = now(); pair_compute(s, eflag); s->t_pair += now() - t0;
-    t0 = now(); if (bond_compute(s, eflag)) return 1; s->t_bond += now() - t0;
+    t0 = now(); if (bond_compute(s, eflag)) return 1; angle_compute(s, eflag); s->t_bond += now() - t0;
     t0 = now();
     for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_post_force(s, &s->fix[k]);
     for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_final(s);

@@ -9,7 +9,9 @@
  *
  * PARITY PINNING (see DESIGN.md "Oracle"):
  *  - pinned by reference-owned vectors: LJ (unittest mol-pair-lj_cut.yaml),
- *    FENE / harmonic bonds (bond-fene.yaml, bond-harmonic.yaml), NVE + RanMars +
+ *    FENE / harmonic / hybrid(+morse) bonds (bond-fene.yaml, bond-harmonic.yaml, bond-hybrid.yaml),
+ *    harmonic / cosine angles (angle-harmonic.yaml, angle-cosine.yaml), fix nve on a group with
+ *    pair + bond + angle forces (fix-timestep-nve.yaml), NVE + RanMars +
  *    Langevin + Atom::sort + thermo (bench/log.6Oct16.chain.fixed.icc.1:48-49).
  *  - USER-LE fixes (extrusion / ex_load / ex_unload): PARITY UNPINNED — the
  *    reference holds no test, example or log for them and the reference cannot
@@ -60,6 +62,21 @@ void   leo_pair_lj_cut(leo_t *s, double cut_global, int shift, int mix);
 void   leo_pair_coeff(leo_t *s, int i, int j, double eps, double sigma, double cut /* <0: global */);
 /* bond styles per bond type: 1 = fene (K R0 eps sigma), 2 = harmonic (K r0), 3 = morse (D alpha r0) */
 void   leo_bond_coeff(leo_t *s, int btype, int style, double p0, double p1, double p2, double p3);
+
+/* angles (newton_bond off: stored on all three atoms): Angles section rows + "extra angle per atom"; call after leo_set_atoms */
+void   leo_set_angles(leo_t *s, int nangletypes, int nangles, const int *atype, const int *a1, const int *a2, const int *a3,
+                      int extra_angle);
+/* angle_coeff: style 1 = harmonic (K, theta0 in degrees), 2 = cosine (K) */
+void   leo_angle_coeff(leo_t *s, int type, int style, double k, double theta0_deg);
+/* fix ID group nve with a group other than all: flag_by_tag[t-1] = 1 for integrated atoms */
+void   leo_nve_group(leo_t *s, const int *flag_by_tag);
+/* fix ex_load ... atype N (fix_ex_load.cpp:855-954): angles of type N are created around every new bond */
+void   leo_ex_load_atype(leo_t *s, int fix_index, int atype);
+long   leo_nangles(leo_t *s);
+int    leo_angle_per_atom(leo_t *s);
+void   leo_get_angles(leo_t *s, int *num_angle, int *angle_type, int *a1, int *a2, int *a3);   /* tag order, [n], [n*apa] */
+double leo_angle_energy(leo_t *s);
+void   leo_angle_virial(leo_t *s, double *out6);
 
 /* ---- settings ---- */
 void   leo_timestep(leo_t *s, double dt);

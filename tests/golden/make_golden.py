@@ -14,6 +14,12 @@ Sources (relative to /root/reference):
   unittest/force-styles/tests/bond-fene.yaml                -> bond_fene.json
   unittest/force-styles/tests/bond-harmonic.yaml            -> bond_harmonic.json
   unittest/force-styles/tests/bond-hybrid.yaml              -> bond_hybrid.json (hybrid harmonic morse: per-type dispatch)
+  unittest/force-styles/tests/angle-harmonic.yaml           -> angle_harmonic.json
+  unittest/force-styles/tests/angle-cosine.yaml             -> angle_cosine.json
+  unittest/force-styles/tests/fix-timestep-nve.yaml         -> fix_nve.json (positions / velocities after 8 steps of
+                                                               `fix nve` on the group of molecules 1-2, with the harness'
+                                                               lj/cut + harmonic bonds + harmonic angles; values of that
+                                                               force field as set by test_fix_timestep.cpp:115-135)
   bench/data.chain                                          -> chain32k.npz (system)
   bench/log.6Oct16.chain.fixed.icc.1:48-49,68-76            -> chain32k_thermo.json
 """
@@ -77,7 +83,7 @@ def yaml_scalar(text, key):
 def known_answers(path, ekey):
     text = open(path).read()
     out = {"epsilon": yaml_scalar(text, "epsilon")}
-    coeff_key = "pair_coeff" if "pair_coeff" in text else "bond_coeff"
+    coeff_key = "pair_coeff" if "pair_coeff" in text else "bond_coeff" if "bond_coeff" in text else "angle_coeff"
     m = re.search(r"^%s: ! \|[-0-9]*\n((?:[ \t]+.*\n)+)" % re.escape(coeff_key), text, re.M)
     rows = [r.split() for r in m.group(1).strip().split("\n")]
     # hybrid styles name the sub-style in front of the numbers: keep it as a string
@@ -104,6 +110,8 @@ def main():
         "image": [[int(r[7]), int(r[8]), int(r[9])] for r in atoms],
         "vel": {r[0]: [float(r[1]), float(r[2]), float(r[3])] for r in sec["Velocities"]},
         "bonds": [[int(r[1]), int(r[2]), int(r[3])] for r in sec["Bonds"]],
+        "nangletypes": hdr["angle types"],
+        "angles": [[int(r[1]), int(r[2]), int(r[3]), int(r[4])] for r in sec["Angles"]],
         # settings of the harness the known answers were generated with (values only):
         "units": "real", "timestep": 0.1, "special_lj": [0.10, 0.25, 0.50],
         "neigh_modify": {"delay": 2, "every": 2, "check": 0},
@@ -115,6 +123,21 @@ def main():
     json.dump(known_answers(ft + "bond-fene.yaml", "energy"), open(OUT + "/bond_fene.json", "w"))
     json.dump(known_answers(ft + "bond-harmonic.yaml", "energy"), open(OUT + "/bond_harmonic.json", "w"))
     json.dump(known_answers(ft + "bond-hybrid.yaml", "energy"), open(OUT + "/bond_hybrid.json", "w"))
+    json.dump(known_answers(ft + "angle-harmonic.yaml", "energy"), open(OUT + "/angle_harmonic.json", "w"))
+    json.dump(known_answers(ft + "angle-cosine.yaml", "energy"), open(OUT + "/angle_cosine.json", "w"))
+    text = open(ft + "fix-timestep-nve.yaml").read()
+    nve = {
+        "epsilon": yaml_scalar(text, "epsilon"),
+        "run_pos": [r[1:] for r in sorted(yaml_block(text, "run_pos"))],
+        "run_vel": [r[1:] for r in sorted(yaml_block(text, "run_vel"))],
+        # the force field and run protocol of the harness (values only)
+        "pair_style": "lj/cut", "cut_global": 8.0, "mix": "geometric",
+        "pair_coeff": [[1, 1, 0.02, 2.5], [2, 2, 0.005, 1.0], [2, 4, 0.005, 0.5], [3, 3, 0.02, 3.2], [4, 4, 0.015, 3.1], [5, 5, 0.015, 3.1]],
+        "bond_coeff": [[1, 250.0, 1.5], [2, 300.0, 1.1], [3, 350.0, 1.3], [4, 650.0, 1.2], [5, 450.0, 1.0]],
+        "angle_coeff": [[1, 75.0, 110.1], [2, 45.0, 111.0], [3, 50.0, 120.0], [4, 100.0, 108.5]],
+        "group_molecules": [1, 2], "timestep": 0.25, "nsteps": 8,
+    }
+    json.dump(nve, open(OUT + "/fix_nve.json", "w"))
 
     hdr, sec = parse_data(REF + "/bench/data.chain")
     a = np.array(sec["Atoms"], dtype=object)  # id mol type x y z ix iy iz  (atom_style bond)

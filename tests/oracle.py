@@ -33,8 +33,9 @@ def lib():
         L.leo_new.restype = C.c_void_p
         L.leo_new.argtypes = [C.c_int] * 5
         L.leo_error.restype = C.c_char_p
-        for name in ("leo_ntimestep", "leo_nbonds", "leo_neigh_builds", "leo_neigh_pairs", "leo_fene_warnings"):
+        for name in ("leo_ntimestep", "leo_nbonds", "leo_neigh_builds", "leo_neigh_pairs", "leo_fene_warnings", "leo_nangles"):
             getattr(L, name).restype = C.c_long
+        L.leo_angle_energy.restype = C.c_double
     return _lib
 
 
@@ -93,6 +94,51 @@ class Oracle:
         b = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 3)
         bt, a1, a2 = (np.ascontiguousarray(b[:, k]) for k in range(3))
         self.L.leo_set_bonds(self.h, C.c_int(len(b)), _ip(bt), _ip(a1), _ip(a2))
+
+    def angles(self, nangletypes, angles, extra_angle=0):
+        """Angles section rows (type, atom1, atom2, atom3); `extra angle per atom` as extra_angle."""
+        a = np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, 4)
+        cols = [np.ascontiguousarray(a[:, k]) for k in range(4)]
+        self.L.leo_set_angles(self.h, C.c_int(nangletypes), C.c_int(len(a)), _ip(cols[0]), _ip(cols[1]), _ip(cols[2]), _ip(cols[3]),
+                              C.c_int(extra_angle))
+
+    def angle_coeff(self, t, style, k, theta0=0.0):
+        self.L.leo_angle_coeff(self.h, C.c_int(t), C.c_int({"harmonic": 1, "cosine": 2}[style]), C.c_double(k), C.c_double(theta0))
+
+    def nve_group(self, flag_by_tag):
+        f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
+        self.L.leo_nve_group(self.h, _ip(f))
+
+    def ex_load_atype(self, fix_id, atype):
+        self.L.leo_ex_load_atype(self.h, C.c_int(self.fix_ids[fix_id]), C.c_int(atype))
+
+    def nangles(self):
+        return int(self.L.leo_nangles(self.h))
+
+    def angle_energy(self):
+        return float(self.L.leo_angle_energy(self.h))
+
+    def angle_virial(self):
+        o = np.zeros(6)
+        self.L.leo_angle_virial(self.h, _dp(o))
+        return o
+
+    def angle_table(self):
+        apa = int(self.L.leo_angle_per_atom(self.h))
+        na = np.zeros(self.n, dtype=np.int32)
+        arr = [np.zeros((self.n, max(apa, 1)), dtype=np.int32) for _ in range(4)]
+        self.L.leo_get_angles(self.h, _ip(na), *[_ip(a) for a in arr])
+        return na, arr[0], arr[1], arr[2], arr[3]
+
+    def angle_set(self):
+        """{(type, a1, a2, a3)} of the copies stored on the CENTRAL atom (one per angle), ends ordered."""
+        na, at, a1, a2, a3 = self.angle_table()
+        out = set()
+        for i in np.nonzero(na)[0]:
+            for m in range(na[i]):
+                if a2[i, m] == i + 1:
+                    out.add((int(at[i, m]), int(min(a1[i, m], a3[i, m])), int(a2[i, m]), int(max(a1[i, m], a3[i, m]))))
+        return out
 
     def special_bonds(self, w1, w2, w3, coul=(0.0, 0.0, 0.0)):
         """special_bonds lj w1 w2 w3 [coul c1 c2 c3]; `fene` = lj 0 1 1 coul 0 1 1 (src/force.cpp:748-826)."""
