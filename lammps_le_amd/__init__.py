@@ -154,7 +154,7 @@ class lammps(object):
 
     # -- numpy conveniences (python/lammps.py has the same idea in lammps.numpy) --
     def gather(self, name):
-        ints = {"type": 1, "id": 1, "mask": 1, "molecule": 1, "image": 3, "num_bond": 1, "nspecial": 3}
+        ints = {"type": 1, "id": 1, "mask": 1, "molecule": 1, "image": 3, "num_bond": 1, "nspecial": 3, "num_angle": 1}
         n = self.get_natoms()
         if name in ("x", "v", "f"):
             return np.ctypeslib.as_array(self.gather_atoms(name, 1, 3)).reshape(n, 3).copy()
@@ -162,6 +162,8 @@ class lammps(object):
             w = self.extract_setting("bond_per_atom")
         elif name == "special":
             w = self.extract_setting("maxspecial")
+        elif name in ("angle_type", "angle_atom1", "angle_atom2", "angle_atom3"):
+            w = self.extract_setting("angle_per_atom")
         else:
             w = ints[name]
         a = np.ctypeslib.as_array(self.gather_atoms(name, 0, w)).reshape(n, w).copy()
@@ -180,6 +182,19 @@ class lammps(object):
             for m in range(nb[i]):
                 a, b = int(i) + 1, int(ba[i, m])
                 out.add((int(bt[i, m]), min(a, b), max(a, b)))
+        return out
+
+    def angle_set(self):
+        """{(type, a1, a2, a3)} of the copies the CENTRAL atoms store (one per angle), ends ordered."""
+        na, at = self.gather("num_angle"), self.gather("angle_type")
+        a1, a2, a3 = self.gather("angle_atom1"), self.gather("angle_atom2"), self.gather("angle_atom3")
+        if at.ndim == 1:
+            at, a1, a2, a3 = (v.reshape(-1, 1) for v in (at, a1, a2, a3))
+        out = set()
+        for i in np.nonzero(na)[0]:
+            for m in range(na[i]):
+                if a2[i, m] == i + 1:
+                    out.add((int(at[i, m]), int(min(a1[i, m], a3[i, m])), int(a2[i, m]), int(max(a1[i, m], a3[i, m]))))
         return out
 
     def has_style(self, category, name):

@@ -66,6 +66,7 @@ double lammps_get_thermo(void *handle, const char *keyword) {
     else if (k == "ke") val = r.ke;
     else if (k == "pe") val = r.pe;
     else if (k == "bonds") val = (double)e->nbonds;
+    else if (k == "angles") val = (double)e->nangles;
     else if (k == "atoms") val = (double)e->natoms;
     else if (k == "vol") val = e->box.prd[0] * e->box.prd[1] * e->box.prd[2];
     else if (k == "dt") val = e->dt;
@@ -97,6 +98,9 @@ int lammps_extract_setting(void *handle, const char *keyword) {
   if (k == "ntypes") return e->ntypes;
   if (k == "nbondtypes") return e->nbondtypes;
   if (k == "bond_per_atom") return e->bpa;
+  if (k == "angle_per_atom") return e->apa;
+  if (k == "nangles") return (int)e->nangles;
+  if (k == "nangletypes") return e->nangletypes;
   if (k == "maxspecial") return e->maxspecial;
   if (k == "newton_bond") return 0;
   if (k == "molecule_flag") return e->atom_style != "atomic";
@@ -169,6 +173,8 @@ static int topo_width(Engine *e, const std::string &k) {
   if (k == "bond_type" || k == "bond_atom") return e->bpa;
   if (k == "nspecial") return 3;
   if (k == "special") return e->maxspecial;
+  if (k == "num_angle") return e->apa > 0 ? 1 : 0;
+  if (k == "angle_type" || k == "angle_atom1" || k == "angle_atom2" || k == "angle_atom3") return e->apa;
   return 0;
 }
 
@@ -192,7 +198,10 @@ void lammps_gather_atoms(void *handle, char *name, int type, int count, void *da
         for (int i = 0; i < n; i++) out[i] = lammps_encode_image_flags(e->image[3 * i], e->image[3 * i + 1], e->image[3 * i + 2]);
       else if (topo_width(e, k) == count && count > 0) {
         const std::vector<int> &src = (k == "num_bond") ? e->num_bond : (k == "bond_type") ? e->bond_type :
-                                      (k == "bond_atom") ? e->bond_atom : (k == "nspecial") ? e->nspecial : e->special;
+                                      (k == "bond_atom") ? e->bond_atom : (k == "nspecial") ? e->nspecial :
+                                      (k == "num_angle") ? e->num_angle : (k == "angle_type") ? e->angle_type :
+                                      (k == "angle_atom1") ? e->angle_a1 : (k == "angle_atom2") ? e->angle_a2 :
+                                      (k == "angle_atom3") ? e->angle_a3 : e->special;
         memcpy(out, src.data(), (size_t)n * count * sizeof(int));
       } else throw LammpsError("lammps_gather_atoms: unknown property name " + k);
     }

@@ -55,6 +55,12 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.num_bond, nt); dalloc(d.bond_type, nt * bpa); dalloc(d.bond_atom, nt * bpa);
   dalloc(d.nspecial, nt * 3); dalloc(d.special, nt * (size_t)maxspecial);
   dalloc(d.num_bond0, nt); dalloc(d.bond_type0, nt * bpa); dalloc(d.bond_atom0, nt * bpa);
+  if (d.apa > 0) {
+    dalloc(d.num_angle, nt); dalloc(d.angle_type, nt * d.apa); dalloc(d.angle_a1, nt * d.apa); dalloc(d.angle_a2, nt * d.apa);
+    dalloc(d.angle_a3, nt * d.apa);
+    d.ecap = d.apa + 8;
+    dalloc(d.eff_n, nt); dalloc(d.eff_rec, nt * (size_t)d.ecap * 4);
+  }
   if (maxtag >= (1 << BOND_TYPE_SHIFT)) throw LammpsError("MI355X engine: atom IDs must stay below 2^26");
   d.bond_pack_stride = ((1 + bpa) + 3) & ~3;
   dalloc(d.bond_pack, nt * (size_t)d.bond_pack_stride);
@@ -81,6 +87,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.pairtab, (size_t)6 * (ntypes + 1) * (ntypes + 1));
   d.nred_blocks = (n + 255) / 256 + 8;
   dalloc(d.partial, (size_t)d.nred_blocks * 16);
+  dalloc(d.partial_a, (size_t)d.nred_blocks * 8);
   HIP_CHECK(hipHostMalloc((void **)&d.partial_h, (size_t)d.nred_blocks * 16 * sizeof(double)));
   dalloc(d.flags, NFLAGS);
   HIP_CHECK(hipHostMalloc((void **)&d.flags_h, (FLAG_SEQ_SLOT + 16) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
@@ -117,7 +124,8 @@ void dev_free(DeviceState &d) {
   dfree(d.map); dfree(d.type_t); dfree(d.crank);
   dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special); dfree(d.num_bond0); dfree(d.bond_type0); dfree(d.bond_atom0); dfree(d.bond_pack);
   dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
-  dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial);
+  dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial); dfree(d.partial_a);
+  dfree(d.num_angle); dfree(d.angle_type); dfree(d.angle_a1); dfree(d.angle_a2); dfree(d.angle_a3); dfree(d.eff_n); dfree(d.eff_rec);
   if (d.partial_h) (void)hipHostFree(d.partial_h);
   d.partial_h = nullptr;
   dfree(d.flags);

@@ -46,7 +46,7 @@ constexpr int FLAG_SEQ_SLOT = 32;   // the publish sequence number in the mapped
 enum DevErr {
   ERR_NONE = 0, ERR_BAD_FENE = 1, ERR_BOND_MISSING = 2, ERR_EXT_MULTI = 3, ERR_BPA = 4,
   ERR_SPECIAL = 5, ERR_COUNT_MISMATCH = 6, ERR_NONFINITE = 7, ERR_SPECIAL_SCRATCH = 8, ERR_GHOST_ORDER = 9,
-  ERR_HALO_TIMEOUT = 10
+  ERR_HALO_TIMEOUT = 10, ERR_ANGLES = 11
 };
 
 // Neighbor cells are cutneigh wide in y and z and cutneigh / CELL_XSPLIT wide in x (the fastest index of the cell
@@ -78,6 +78,16 @@ struct DeviceState {
   int *crank = nullptr;                          // [maxtag+2] canonical (reference local) index
   int *num_bond = nullptr, *bond_type = nullptr, *bond_atom = nullptr;   // [(maxtag+2)], [*bpa]
   int *nspecial = nullptr, *special = nullptr;                            // [*3], [*maxspecial]
+  // angles by tag (apa = 0: none): every atom holds a copy of each angle it is part of, atoms as IDs
+  int apa = 0;
+  int *num_angle = nullptr, *angle_type = nullptr, *angle_a1 = nullptr, *angle_a2 = nullptr, *angle_a3 = nullptr;
+  double *partial_a = nullptr;     // [nblocks][8] angle energy + virial block sums
+  // the angle LIST of the last reneighbor as every bead sees it (NTopoAngleAll::build, src/ntopo_angle_all.cpp:37-93): an
+  // angle acts - on all three of its atoms - iff the one with the lowest local index holds a copy of it, whatever copies
+  // the other two hold (copies go out of step when fix ex_unload's influence rule spares one atom).  eff_*[t]: the listed
+  // angles bead t is part of, sorted, so that the force kernel is a per-bead gather with a fixed summation order.
+  int ecap = 0;
+  int *eff_n = nullptr, *eff_rec = nullptr;      // [maxtag+2], [maxtag+2][ecap][4] = type a1 a2 a3
   // bond tables as of the last reneighbor = the reference's neighbor->bondlist, which the LE fixes loop over
   // even when another LE fix changed the topology earlier in the same step (fix_ex_unload.cpp:223, fix_extrusion.cpp:368)
   int *num_bond0 = nullptr, *bond_type0 = nullptr, *bond_atom0 = nullptr;
@@ -227,6 +237,10 @@ void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4]
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt);
 void launch_ke(DeviceState &d, const TypeTables &tt);
+// angle forces added to f (after launch_force); eflag: energy / virial thirds into partial_a (reduce_angle_partials)
+void launch_angle(DeviceState &d, const AngleTable &at, bool eflag);
+void launch_angle_list(DeviceState &d);       // at every reneighbor of a run with an angle style
+void reduce_angle_partials(DeviceState &d, double *out8);
 // reductions: returns sums of `partial` columns on the host (synchronises the stream)
 void reduce_partials(DeviceState &d, double *out16);
 
@@ -255,10 +269,12 @@ void launch_ranmars_gen(DeviceState &d, int slot, const int *count_ptr, uint32_t
 struct ExLoadParams {
   int iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype;
   double cutsq, fraction;
+  int atype;        // angle type created around every new bond (0: none)
 };
 struct ExUnloadParams {
   int btype;
   double cutsq, fraction;
+  int angleflag;    // angles exist: a broken bond takes the angles it is part of with it (fix_ex_unload.cpp:149-152)
 };
 struct ExtrusionParams {
   int neutral, ctcf_left, ctcf_right, ctcf_lr, btype;

@@ -160,7 +160,7 @@ void Engine::upload() {
   }
   DeviceState &d = *dev;
   d.bins_ready = false;      // the device arrays are about to be replaced (tag order): bins of the old arrays are void
-  bool realloc = (d.ntotal != natoms || d.bpa != bpa || d.maxspecial != maxspecial || d.ntypes != ntypes || !d.pos);
+  bool realloc = (d.ntotal != natoms || d.bpa != bpa || d.maxspecial != maxspecial || d.ntypes != ntypes || !d.pos || d.apa != apa);
   double cellcut = cutneighmax > 0.0 ? cutneighmax : std::max({box.prd[0], box.prd[1], box.prd[2]}) / 3.0;
   if (world > 1) {
     // z-slab decomposition: rank r owns z in [lo + r*w, lo + (r+1)*w); ghost shell = max(neighbor cutoff, comm cutoff)
@@ -181,6 +181,7 @@ void Engine::upload() {
     }
   if (realloc) {
     if (d.pos) dev_free(d);
+    d.apa = apa;
     dev_alloc(d, natoms, natoms, ntypes, bpa, maxspecial, box, cellcut);
     if (comm) comm->main_stream = d.stream;
     if (d.dd) { dd_alloc(d, world); dd_fast_halo_setup(d, *comm); }
@@ -244,6 +245,19 @@ void Engine::upload() {
   up(d.bond_atom, ba.data(), nt * bpa * sizeof(int));
   up(d.nspecial, ns.data(), nt * 3 * sizeof(int));
   up(d.special, sp.data(), nt * (size_t)maxspecial * sizeof(int));
+  std::vector<int> an, ag[4];
+  if (apa > 0) {
+    an.assign(nt, 0);
+    std::copy(num_angle.begin(), num_angle.end(), an.begin() + 1);
+    up(d.num_angle, an.data(), nt * sizeof(int));
+    const std::vector<int> *src[4] = {&angle_type, &angle_a1, &angle_a2, &angle_a3};
+    int *dst[4] = {d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3};
+    for (int q = 0; q < 4; q++) {
+      ag[q].assign(nt * apa, 0);
+      std::copy(src[q]->begin(), src[q]->end(), ag[q].begin() + apa);
+      up(dst[q], ag[q].data(), nt * apa * sizeof(int));
+    }
+  }
   int ntp = ntypes + 1;
   std::vector<double> tab(6 * (size_t)ntp * ntp, 0.0);
   if (pair_lj)
@@ -347,7 +361,19 @@ void Engine::download() {
   down(ba.data(), d.bond_atom, nt * bpa * sizeof(int));
   down(ns.data(), d.nspecial, nt * 3 * sizeof(int));
   down(sp.data(), d.special, nt * (size_t)maxspecial * sizeof(int));
+  std::vector<int> an, ag[4];
+  if (apa > 0) {
+    an.resize(nt);
+    down(an.data(), d.num_angle, nt * sizeof(int));
+    const int *src[4] = {d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3};
+    for (int q = 0; q < 4; q++) { ag[q].resize(nt * apa); down(ag[q].data(), src[q], nt * apa * sizeof(int)); }
+  }
   HIP_CHECK(hipStreamSynchronize(d.stream));
+  if (apa > 0) {
+    std::copy(an.begin() + 1, an.begin() + 1 + n, num_angle.begin());
+    std::vector<int> *dst[4] = {&angle_type, &angle_a1, &angle_a2, &angle_a3};
+    for (int q = 0; q < 4; q++) std::copy(ag[q].begin() + apa, ag[q].begin() + apa + (size_t)n * apa, dst[q]->begin());
+  }
   for (int p = 0; p < n; p++) {
     int i = tg[p] - 1;
     x[3 * i] = pos[p].x; x[3 * i + 1] = pos[p].y; x[3 * i + 2] = pos[p].z;
@@ -387,6 +413,7 @@ static void check_device_error(Engine *e, DeviceState &d) {
     case ERR_NONFINITE: msg = "Non-numeric atom coords - simulation unstable"; break;
     case ERR_HALO_TIMEOUT: msg = "a neighbouring rank did not deliver its halo in time (peer window exchange)"; break;
     case ERR_SPECIAL_SCRATCH: msg = "Special list size exceeded in fix bond/create"; break;
+    case ERR_ANGLES: msg = "Fix ex_load induced too many angles/dihedrals/impropers per atom"; break;
     case ERR_GHOST_ORDER: msg = "internal: ghost blocks of a slab interleave (slab thinner than two ghost shells?)"; break;
   }
   (void)e;
@@ -415,6 +442,7 @@ void Engine::reneighbor(bool defer_check) {
     if (d.flags_h[FLAG_RNG_MISS]) { rng_late_generate(d); rng_late_count++; }
     if (d.flags_h[FLAG_NEIGH_OVERFLOW]) regrow_lists();
   }
+  if (angles_active()) launch_angle_list(d);     // NTopoAngle::build
   if (d.le_snapshot && d.topo_dirty) {   // NTopoBond::build: the bond list the LE fixes will see until the next reneighbor
     d.topo_dirty = false;
     launch_topo_snapshot(d);
@@ -559,8 +587,14 @@ static bool timed_begin(Engine *e) {
   return true;
 }
 
+bool Engine::angles_active() const {
+  if (apa <= 0 || angle_style_name.empty() || angle_style_name == "none" || angle_style_name == "zero") return false;
+  for (int a = 1; a <= nangletypes; a++) if (angtab.style[a]) return true;
+  return false;
+}
 void Engine::compute_forces(bool eflag) {
   launch_force(*dev, bondtab, special_lj, eflag, pair_lj);
+  if (angles_active()) launch_angle(*dev, angtab, eflag);     // Angle::compute follows Bond::compute (src/verlet.cpp:298-302)
 }
 
 double Engine::stat_neigh_pairs() {
@@ -611,6 +645,12 @@ ThermoRow Engine::eval_thermo() {
   double ke = r.temp * 0.5 * dof * boltz;
   r.evdwl = s[0]; r.ebond = s[1];
   for (int k = 0; k < 6; k++) r.virial[k] = s[2 + k] + s[8 + k];
+  if (angles_active()) {       // thermo's emol = ebond + eangle (src/thermo.cpp), the pressure's virial includes the angles'
+    double a8[8];
+    reduce_angle_partials(d, a8);
+    r.ebond += a8[0];
+    for (int k = 0; k < 6; k++) r.virial[k] += a8[1 + k];
+  }
   double vol = box.prd[0] * box.prd[1] * box.prd[2];
   r.press = (dof * boltz * r.temp + r.virial[0] + r.virial[1] + r.virial[2]) / 3.0 / vol * nktv2p;
   r.epair = r.evdwl / norm; r.emol = r.ebond / norm;
@@ -707,6 +747,8 @@ void Engine::iterate(long nsteps) {
   // bond morse (the reference's unit-test partner of bond hybrid, not a style of the chromatin model) lives in the
   // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
   for (int b = 1; b <= nbondtypes; b++) if (bondtab.style[b] == 3) fusable = false;
+  // angles (semiflexible chains) are a kernel of their own behind the force kernel: unfused steps
+  if (angles_active()) fusable = false;
   bool ident = d.ident_order;
   bool pre_integrated = false;
   // halo/compute overlap issues the per-step halo on a second stream.  With RCCL that means two streams feeding ONE
@@ -960,6 +1002,10 @@ void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
+  if (angles_active() && (world > 1 || respa_levels > 0))
+    throw LammpsError("MI355X engine: angle styles run on one GPU with run_style verlet only");
+  for (int a = 1; a <= nangletypes && apa > 0 && nangles > 0 && !angle_style_name.empty() && angle_style_name != "none" && angle_style_name != "zero"; a++)
+    if (!angtab.style[a]) throw LammpsError("All angle coeffs are not set");
   // a run that ended in an error tore the communicator down (below); halo sequence numbers and arrival counters of the
   // ranks may disagree from then on, so nothing decomposed runs on this handle again
   if (comm && world > 1) comm->require_alive();

@@ -78,6 +78,11 @@ struct BondTable {  // by-value kernel argument
   double p0[MAXTYPES + 1], p1[MAXTYPES + 1], p2[MAXTYPES + 1], p3[MAXTYPES + 1];
 };
 
+struct AngleTable {  // by-value kernel argument: angle_style harmonic | cosine (src/MOLECULE/angle_harmonic.cpp, angle_cosine.cpp)
+  int style[MAXTYPES + 1];     // 0 none/zero, 1 harmonic, 2 cosine
+  double k[MAXTYPES + 1], theta0[MAXTYPES + 1];   // theta0 in radians
+};
+
 struct DeviceState;  // defined in device.h (HIP side)
 struct Comm;         // defined in comm.h
 
@@ -129,6 +134,7 @@ struct FixExtrusion : Fix {
 
 struct FixExLoad : Fix {    // also the stock `bond/create` (src/MC/fix_bond_create.cpp), the style ex_load was derived from
   int nevery, iatomtype, jatomtype, btype, imaxbond = 0, inewtype, jmaxbond = 0, jnewtype;
+  int atype = 0;             // `atype N`: angles of type N around every new bond, if an angle style is defined (fix_ex_load.cpp:236-254, :855-954)
   bool stock = false;        // bond/create: candidates = every pair of the pair list (not only (i, i+2)), fires at step % N == 0,
   int phase = 3;             //   bonds of btype per bead counted at the first setup and from then on only incremented
   std::vector<int> bondcount;   // [natoms + 2] by tag (stock only)
@@ -148,6 +154,8 @@ struct FixExLoad : Fix {    // also the stock `bond/create` (src/MC/fix_bond_cre
 
 struct FixExUnload : Fix {   // also the stock `bond/break` (src/MC/fix_bond_break.cpp), which differs only in the firing step
   int nevery, btype;
+  int angleflag = 0;         // set in init(): the system has angles, broken bonds take theirs along (fix_ex_unload.cpp:149-152)
+  void init() override;
   int phase = 2;             // fires when ntimestep % nevery == phase: 2 for ex_unload, 0 for bond/break
   double cutsq, fraction = 1.0;
   int seed = 12345;
@@ -217,6 +225,13 @@ class Engine {
   std::vector<int> type, image, molecule;          // image: 3 ints per atom
   std::vector<int> num_bond, bond_type, bond_atom; // [natoms], [natoms*bpa]
   std::vector<int> nspecial, special;              // [natoms*3], [natoms*maxspecial]
+  // angles: stored with all three atoms (newton_bond off, src/atom.cpp:1290-1353), atoms as IDs
+  int nangletypes = 0, extra_angle = 0, apa = 0;   // apa = angles per atom (0: the system has no angle storage)
+  long nangles = 0;
+  std::vector<int> num_angle, angle_type, angle_a1, angle_a2, angle_a3;   // [natoms], [natoms*apa]
+  std::string angle_style_name;                    // "", "harmonic", "cosine", "zero", "none"
+  AngleTable angtab{};
+  bool angles_active() const;                      // an angle style with coefficients and angle storage exist
   std::vector<int> crank;                          // canonical (reference local) index of tag t-1
   // the reference's local index of a bead is its ID - 1: true while no Atom::sort ran and the data file listed the atoms
   // in ID order.  Then the order-sensitive kernels index by tag directly instead of through crank[].

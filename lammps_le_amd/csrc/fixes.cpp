@@ -122,10 +122,11 @@ FixExLoad::FixExLoad(Engine *e, const std::vector<std::string> &arg) {
     } else if (arg[iarg] == "atype" || arg[iarg] == "dtype" || arg[iarg] == "itype") {
       if (iarg + 2 > arg.size()) throw LammpsError(ill);
       // fix_ex_load.cpp:108-122 parse the type; :236-254 (and MC/fix_bond_create.cpp:256-270) switch the creation of angles /
-      // dihedrals / impropers on only `if (atype && force->angle)`, i.e. when the script defined such a style.  This engine
-      // has no angle / dihedral / improper styles (the commands are refused), so the flag stays 0 exactly as in the reference
-      // for a script without them: the keyword is accepted and has no effect.
+      // dihedrals / impropers on only `if (atype && force->angle)`, i.e. when the script defined such a style.  Angles are
+      // created (kernels_le.hip dev_create_angles); this engine has no dihedral / improper styles, so dtype / itype stay
+      // without effect exactly as in the reference for a script without such styles.
       if (inumeric(arg[iarg + 1]) < 0) throw LammpsError(ill);
+      if (arg[iarg] == "atype") atype = inumeric(arg[iarg + 1]);
       iarg += 2;
     } else throw LammpsError(ill);
   }
@@ -189,6 +190,7 @@ FixExUnload::FixExUnload(Engine *e, const std::vector<std::string> &arg) {
   force_reneighbor = true;
   has_post_integrate = true;
 }
+void FixExUnload::init() { angleflag = (eng->apa > 0 && eng->nangles > 0) ? 1 : 0; }
 double FixExUnload::compute_vector(int n) { return n == 0 ? (double)last_break : (double)total_break; }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,6 +218,7 @@ static void check_le_error(DeviceState &d, const char *style) {
     case ERR_SPECIAL: throw LammpsError("New bond exceeded special list size in fix " + st);
     case ERR_COUNT_MISMATCH: throw LammpsError("Numbers of created and broken bonds are not equal");
     case ERR_SPECIAL_SCRATCH: throw LammpsError("Special list size exceeded in fix bond/create");
+    case ERR_ANGLES: throw LammpsError("Fix " + st + " induced too many angles/dihedrals/impropers per atom");
     default: throw LammpsError("device error in fix " + st);
   }
 }
@@ -249,7 +252,10 @@ void FixExLoad::post_integrate() {
   int slot = le_slot(eng, this);
   if (slot >= LE_MAX_FIXES) throw LammpsError("MI355X engine supports at most " + std::to_string(LE_MAX_FIXES) + " extrusion/ex_load/ex_unload fixes");
   if (!rng_on_device) { le_rng_upload(d, slot, rng); rng_on_device = true; }
-  ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction};
+  // angles around new bonds only `if (atype && force->angle)` (fix_ex_load.cpp:236-240)
+  const int angle_type_new = (atype > 0 && eng->angles_active()) ? atype : 0;
+  if (angle_type_new > eng->nangletypes) throw LammpsError("Fix " + style + " angle type is invalid");
+  ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction, angle_type_new};
   if (stock) {
     if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // current positions by tag (ghost slots lag one step here)
     launch_bond_create(d, p, slot, bondcount.data(), (int)bondcount.size(), eng->comm);
@@ -267,6 +273,7 @@ void FixExLoad::post_integrate() {
   last_create = d.flags_h[FLAG_COUNT_A];
   total_create += last_create;
   eng->nbonds += last_create;
+  if (angle_type_new) eng->nangles += d.flags_h[FLAG_COUNT_B] / 3;     // copies on three atoms each (fix_ex_load.cpp:760-765)
   if (last_create) eng->le_reneigh_step[fix_index(eng, this)] = eng->ntimestep;
   if (stock && last_create) bond_create_counts(d, bondcount.data(), (int)bondcount.size());
 }
@@ -280,7 +287,7 @@ void FixExUnload::post_integrate() {
   if (eng->world > 1) {
     if (dd_le_fast(d)) dd_gather_needed(d, *eng->comm, btype, false); else dd_gather_positions(d, *eng->comm);
   }
-  ExUnloadParams p{btype, cutsq, fraction};
+  ExUnloadParams p{btype, cutsq, fraction, angleflag};
   launch_ex_unload(d, p, slot);
   d.topo_dirty = true;
   d.bond_pack_dirty = true;
@@ -289,6 +296,7 @@ void FixExUnload::post_integrate() {
   last_break = d.flags_h[FLAG_COUNT_A];
   total_break += last_break;
   eng->nbonds -= last_break;
+  if (angleflag) eng->nangles -= d.flags_h[FLAG_COUNT_B] / 3;
   if (last_break) eng->le_reneigh_step[fix_index(eng, this)] = eng->ntimestep;
 }
 

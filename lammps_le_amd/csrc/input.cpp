@@ -450,6 +450,29 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
         bondtab.p0[b] = numeric(arg[a0]); bondtab.p1[b] = numeric(arg[a0 + 1]); bondtab.p2[b] = numeric(arg[a0 + 2]);
       } else bondtab.style[b] = 0;
     }
+  } else if (cmd == "angle_style") {
+    // src/MOLECULE/angle_harmonic.cpp, angle_cosine.cpp (semiflexible chains); other styles are out of scope
+    need(1);
+    if (atom_style == "atomic" || atom_style == "bond") throw LammpsError("Angle_style command when no angles allowed");
+    if (arg[0] != "harmonic" && arg[0] != "cosine" && arg[0] != "zero" && arg[0] != "none")
+      throw LammpsError("Unknown angle style " + arg[0]);
+    angle_style_name = arg[0];
+    for (int a = 0; a <= MAXTYPES; a++) angtab.style[a] = 0;
+  } else if (cmd == "angle_coeff") {
+    need(1);
+    if (!box_exist) throw LammpsError("Angle_coeff command before simulation box is defined");
+    if (angle_style_name.empty() || angle_style_name == "none") throw LammpsError("Angle_coeff command before angle_style is defined");
+    int lo, hi;
+    bounds(arg[0], nangletypes, lo, hi);
+    for (int a = lo; a <= hi; a++) {
+      if (angle_style_name == "harmonic") {        // K theta0[degrees] (angle_harmonic.cpp:170-196: stored in radians)
+        if (arg.size() != 3) throw LammpsError("Incorrect args for angle coefficients");
+        angtab.style[a] = 1; angtab.k[a] = numeric(arg[1]); angtab.theta0[a] = numeric(arg[2]) / 180.0 * 3.14159265358979323846;
+      } else if (angle_style_name == "cosine") {   // K (angle_cosine.cpp:124-146)
+        if (arg.size() != 2) throw LammpsError("Incorrect args for angle coefficients");
+        angtab.style[a] = 2; angtab.k[a] = numeric(arg[1]); angtab.theta0[a] = 0.0;
+      } else angtab.style[a] = 0;
+    }
   } else if (cmd == "pair_style") {
     need(1);
     pair_lj = pair_zero = false;
@@ -850,7 +873,7 @@ void Engine::read_data(const std::string &path) {
   if (!in) throw LammpsError("Cannot open file " + path);
   std::string line;
   std::getline(in, line);   // title
-  long nb_hdr = 0;
+  long nb_hdr = 0, nang_hdr = 0;
   int na = 0;
   bool have[3] = {false, false, false};
   static const char *sections[] = {"Masses", "Atoms", "Velocities", "Bonds", "Angles", "Dihedrals", "Impropers",
@@ -881,13 +904,16 @@ void Engine::read_data(const std::string &path) {
     };
     if (ends("atoms")) na = inumeric(w[0]);
     else if (ends("bonds")) nb_hdr = atol(w[0].c_str());
-    else if (ends("angles") || ends("dihedrals") || ends("impropers")) {}
+    else if (ends("angles")) nang_hdr = atol(w[0].c_str());
+    else if (ends("dihedrals") || ends("impropers")) {}
     else if (ends("atom types")) ntypes = inumeric(w[0]);
     else if (ends("bond types")) nbondtypes = inumeric(w[0]);
-    else if (ends("angle types") || ends("dihedral types") || ends("improper types")) {}
+    else if (ends("angle types")) nangletypes = inumeric(w[0]);
+    else if (ends("dihedral types") || ends("improper types")) {}
     else if (ends("extra bond per atom")) extra_bond = inumeric(w[0]);
     else if (ends("extra special per atom")) extra_special = inumeric(w[0]);
-    else if (ends("extra angle per atom") || ends("extra dihedral per atom") || ends("extra improper per atom")) {}
+    else if (ends("extra angle per atom")) extra_angle = inumeric(w[0]);
+    else if (ends("extra dihedral per atom") || ends("extra improper per atom")) {}
     else if (ends("xlo xhi")) { box.lo[0] = numeric(w[0]); box.hi[0] = numeric(w[1]); have[0] = true; }
     else if (ends("ylo yhi")) { box.lo[1] = numeric(w[0]); box.hi[1] = numeric(w[1]); have[1] = true; }
     else if (ends("zlo zhi")) { box.lo[2] = numeric(w[0]); box.hi[2] = numeric(w[1]); have[2] = true; }
@@ -909,7 +935,7 @@ void Engine::read_data(const std::string &path) {
   type.assign(natoms, 0); molecule.assign(natoms, 0); image.assign(3 * (size_t)natoms, 0);
   crank.resize(natoms);
   for (int i = 0; i < natoms; i++) crank[i] = -1;
-  std::vector<int> b_t, b_1, b_2;
+  std::vector<int> b_t, b_1, b_2, g_t, g_1, g_2, g_3;
   bool atoms_read = false;
   int file_rank = 0;
   bool full = (atom_style == "full"), has_mol = (atom_style != "atomic");
@@ -955,6 +981,13 @@ void Engine::read_data(const std::string &path) {
           throw LammpsError("Invalid atom ID in Bonds section of data file");
         if (bt <= 0 || bt > nbondtypes) throw LammpsError("Invalid bond type in Bonds section of data file");
         b_t.push_back(bt); b_1.push_back(a1); b_2.push_back(a2);
+      } else if (cur == "Angles") {          // src/atom.cpp:1290-1353
+        if (w.size() != 5) throw LammpsError("Incorrect format of Angles section in data file");
+        int at = inumeric(w[1]), a1 = inumeric(w[2]), a2 = inumeric(w[3]), a3 = inumeric(w[4]);
+        if (a1 <= 0 || a1 > natoms || a2 <= 0 || a2 > natoms || a3 <= 0 || a3 > natoms || a1 == a2 || a1 == a3 || a2 == a3)
+          throw LammpsError("Invalid atom ID in Angles section of data file");
+        if (at <= 0 || at > nangletypes) throw LammpsError("Invalid angle type in Angles section of data file");
+        g_t.push_back(at); g_1.push_back(a1); g_2.push_back(a2); g_3.push_back(a3);
       }  // other sections are read and ignored
     }
   }
@@ -985,6 +1018,28 @@ void Engine::read_data(const std::string &path) {
     m = b_2[b] - 1;
     bond_type[(size_t)m * bpa + num_bond[m]] = b_t[b]; bond_atom[(size_t)m * bpa + num_bond[m]] = b_1[b]; num_bond[m]++;
   }
+  // angles: with atom2 first, then atom1, then atom3 (newton_bond off: all three store it, src/atom.cpp:1319-1350)
+  if ((long)g_t.size() != nang_hdr) throw LammpsError("Angles assigned incorrectly");
+  nangles = (long)g_t.size();
+  apa = 0;
+  if (nangletypes > MAXTYPES) throw LammpsError("MI355X engine handles at most " + std::to_string(MAXTYPES) + " angle types");
+  if (nangletypes > 0 && atom_style != "bond" && atom_style != "atomic") {
+    std::vector<int> ca(natoms, 0);
+    for (size_t k = 0; k < g_t.size(); k++) { ca[g_1[k] - 1]++; ca[g_2[k] - 1]++; ca[g_3[k] - 1]++; }
+    int ma = 0;
+    for (int c : ca) ma = std::max(ma, c);
+    apa = std::max(1, ma + extra_angle);
+    num_angle.assign(natoms, 0);
+    angle_type.assign((size_t)natoms * apa, 0); angle_a1 = angle_a2 = angle_a3 = angle_type;
+    for (size_t k = 0; k < g_t.size(); k++) {
+      const int order[3] = {g_2[k], g_1[k], g_3[k]};
+      for (int q = 0; q < 3; q++) {
+        const int m = order[q] - 1;
+        const size_t c = (size_t)m * apa + num_angle[m]++;
+        angle_type[c] = g_t[k]; angle_a1[c] = g_1[k]; angle_a2[c] = g_2[k]; angle_a3[c] = g_3[k];
+      }
+    }
+  } else if (!g_t.empty()) throw LammpsError("Angles section in data file for an atom_style without angles");
   int nt = ntypes + 1;
   pc_eps.assign(nt * nt, 0.0); pc_sig = pc_cut = pc_eps; pc_set.assign(nt * nt, 0);
   special_built = false;
@@ -1362,6 +1417,8 @@ void Engine::write_data(const std::string &path) {
   if (!fp) throw LammpsError("Cannot open data file " + path);
   fprintf(fp, "LAMMPS data file via write_data, MI355X engine, timestep = %ld\n\n", ntimestep);
   fprintf(fp, "%d atoms\n%d atom types\n%ld bonds\n%d bond types\n", natoms, ntypes, nbonds, nbondtypes);
+  if (apa) fprintf(fp, "%ld angles\n%d angle types\n", nangles, nangletypes);
+  if (apa && extra_angle) fprintf(fp, "%d extra angle per atom\n", extra_angle);
   if (extra_bond) fprintf(fp, "%d extra bond per atom\n", extra_bond);
   if (extra_special) fprintf(fp, "%d extra special per atom\n", extra_special);
   fprintf(fp, "\n%.17g %.17g xlo xhi\n%.17g %.17g ylo yhi\n%.17g %.17g zlo zhi\n\nMasses\n\n", box.lo[0], box.hi[0], box.lo[1],
@@ -1385,6 +1442,15 @@ void Engine::write_data(const std::string &path) {
       for (int m = 0; m < num_bond[i]; m++) {
         int u = bond_atom[(size_t)i * bpa + m];
         if (i + 1 < u) fprintf(fp, "%ld %d %d %d\n", ++k, bond_type[(size_t)i * bpa + m], i + 1, u);
+      }
+  }
+  if (apa && nangles) {        // one row per angle: the copy its central atom stores (src/atom_vec.cpp pack_angle, newton_bond off)
+    fprintf(fp, "\nAngles\n\n");
+    long k = 0;
+    for (int i = 0; i < natoms; i++)
+      for (int m = 0; m < num_angle[i]; m++) {
+        const size_t c = (size_t)i * apa + m;
+        if (angle_a2[c] == i + 1) fprintf(fp, "%ld %d %d %d %d\n", ++k, angle_type[c], angle_a1[c], angle_a2[c], angle_a3[c]);
       }
   }
   fclose(fp);
@@ -1558,6 +1624,7 @@ void Engine::write_periodic_restart(long step) {
 
 void Engine::write_restart(const std::string &path) {
   if (!box_exist) throw LammpsError("Write_restart command before simulation box is defined");   // src/write_restart.cpp:62
+  if (apa) throw LammpsError("MI355X engine: restart files do not hold angles yet (use write_data)");
   download();
   // the LE fixes' generators live on the device while a run has used them
   int slot = 0;

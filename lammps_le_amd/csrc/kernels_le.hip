@@ -32,10 +32,12 @@ struct Topo {   // tag-indexed topology views
   int T, bpa, ms;
   int *num_bond, *bond_type, *bond_atom, *nspecial, *special, *type_t;
   const int *num_bond0, *bond_type0, *bond_atom0;   // bond tables at the last reneighbor (= neighbor->bondlist)
+  int apa;                                           // angles per atom (0: no angle storage)
+  int *num_angle, *angle_type, *angle_a1, *angle_a2, *angle_a3;
 };
 static Topo topo_of(DeviceState &d) {
   return Topo{d.maxtag, d.bpa, d.maxspecial, d.num_bond, d.bond_type, d.bond_atom, d.nspecial, d.special, d.type_t,
-              d.num_bond0, d.bond_type0, d.bond_atom0};
+              d.num_bond0, d.bond_type0, d.bond_atom0, d.apa, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -201,8 +203,63 @@ __device__ void dev_rebuild_special_one(const Topo &tp, int m, int *__restrict__
   tp.nspecial[3 * (size_t)m + 2] = cn3;
   for (int i = cn1; i < cn3; i++) slist[i] = copy[i];
 }
+// FixExUnload::break_angles (fix_ex_unload.cpp:551-582) for every broken bond (id1, id2 = fin[id1]) that influences atom i:
+// an angle copy goes if one of its two bonds is that bond.  The reference walks the broken bonds in list order and
+// deletes by shifting; the copies that remain, and their order, do not depend on that order.  `fin[t]` = the partner t lost
+// its bond to in this firing (each bead loses at most one bond per firing), 0 otherwise.
+__device__ void dev_break_angles(const Topo &tp, int i, const int *__restrict__ fin, int *__restrict__ flags) {
+  const int *sl = tp.special + (size_t)i * tp.ms;
+  const int n3 = tp.nspecial[3 * (size_t)i + 2];
+  auto influences = [&](int id1, int id2) {           // fix_ex_unload.cpp:445-455: the atom is one end, or lists both ends
+    if (i == id1 || i == id2) return true;
+    int found = 0;
+    for (int k = 0; k < n3; k++) if (sl[k] == id1 || sl[k] == id2) found++;
+    return found == 2;
+  };
+  int num = tp.num_angle[i], w = 0, removed = 0;
+  int *at = tp.angle_type + (size_t)i * tp.apa, *a1 = tp.angle_a1 + (size_t)i * tp.apa, *a2 = tp.angle_a2 + (size_t)i * tp.apa,
+      *a3 = tp.angle_a3 + (size_t)i * tp.apa;
+  for (int m = 0; m < num; m++) {
+    const int t1 = a1[m], t2 = a2[m], t3 = a3[m];
+    const bool gone = (fin[t1] == t2 && influences(t1, t2)) || (fin[t2] == t3 && influences(t2, t3));
+    if (gone) { removed++; continue; }
+    if (w != m) { at[w] = at[m]; a1[w] = t1; a2[w] = t2; a3[w] = t3; }
+    w++;
+  }
+  tp.num_angle[i] = w;
+  if (removed) atomicAdd(&flags[FLAG_COUNT_B], removed);
+}
+// FixExLoad::create_angles (fix_ex_load.cpp:855-954, newton_bond off) for atom m.  `fin[t]` = the partner of t's new bond
+// of this firing (0: none): bond (a, b) is new iff fin[a] == b.  Reads only 1-2 blocks of the special lists, which the
+// concurrent rebuilds of other atoms do not touch.
+__device__ void dev_create_angles(const Topo &tp, int m, int atype, const int *__restrict__ fin, int *__restrict__ flags) {
+  const int ms = tp.ms, apa = tp.apa;
+  int num = tp.num_angle[m], made = 0;
+  int *at = tp.angle_type + (size_t)m * apa, *a1 = tp.angle_a1 + (size_t)m * apa, *a2 = tp.angle_a2 + (size_t)m * apa,
+      *a3 = tp.angle_a3 + (size_t)m * apa;
+  bool overflow = false;
+  auto add = [&](int i1, int i2, int i3) {
+    if (!(fin[i1] == i2 || fin[i2] == i3)) return;     // a new bond must be one of the angle's two bonds
+    if (num < apa) { at[num] = atype; a1[num] = i1; a2[num] = i2; a3[num] = i3; num++; made++; }
+    else overflow = true;
+  };
+  const int *s2 = tp.special + (size_t)m * ms;
+  const int n2 = tp.nspecial[3 * (size_t)m];
+  for (int i = 0; i < n2; i++)                          // atom m central: pairs of its 1-2 neighbours
+    for (int j = i + 1; j < n2; j++) add(s2[i], m, s2[j]);
+  for (int i = 0; i < n2; i++) {                        // atom m as atom 1 of the angle
+    const int i2 = s2[i];
+    const int *sl2 = tp.special + (size_t)i2 * ms;
+    const int nn = tp.nspecial[3 * (size_t)i2];
+    for (int j = 0; j < nn; j++) { const int i3 = sl2[j]; if (i3 != m) add(m, i2, i3); }
+  }
+  tp.num_angle[m] = num;
+  if (made) atomicAdd(&flags[FLAG_COUNT_B], made);
+  if (overflow) flags[FLAG_ERROR] = ERR_ANGLES;
+}
 // influence rules of update_topology: broken (fix_extrusion.cpp:940-969), created (:971-1001)
-__global__ __launch_bounds__(64) void k_topo_broken(Topo tp, const int *__restrict__ fin, int *__restrict__ flags) {
+// `angles`: fix ex_unload / bond/break with angles in the system (extrusion leaves angles alone, fix_extrusion.cpp:924-1002)
+__global__ __launch_bounds__(64) void k_topo_broken(Topo tp, const int *__restrict__ fin, int angles, int *__restrict__ flags) {
   int i = blockIdx.x * 64 + threadIdx.x + 1;
   if (i > tp.T) return;
   bool influenced = fin[i] != 0;
@@ -215,9 +272,11 @@ __global__ __launch_bounds__(64) void k_topo_broken(Topo tp, const int *__restri
         for (int q = 0; q < n; q++) if (sl[q] == p) { influenced = true; break; }
     }
   }
+  if (influenced && angles && tp.apa > 0) dev_break_angles(tp, i, fin, flags);     // before the rebuild, as the reference
   if (influenced) dev_rebuild_special_one(tp, i, flags);
 }
-__global__ __launch_bounds__(64) void k_topo_created(Topo tp, const int *__restrict__ fin, int *__restrict__ flags) {
+// `atype` > 0: fix ex_load / bond/create with an angle style defined - angles around the new bonds
+__global__ __launch_bounds__(64) void k_topo_created(Topo tp, const int *__restrict__ fin, int atype, int *__restrict__ flags) {
   int i = blockIdx.x * 64 + threadIdx.x + 1;
   if (i > tp.T) return;
   bool influenced = fin[i] != 0;
@@ -227,6 +286,7 @@ __global__ __launch_bounds__(64) void k_topo_created(Topo tp, const int *__restr
     for (int k = 0; k < n; k++) if (fin[sl[k]]) { influenced = true; break; }
   }
   if (influenced) dev_rebuild_special_one(tp, i, flags);
+  if (influenced && atype > 0 && tp.apa > 0) dev_create_angles(tp, i, atype, fin, flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -616,7 +676,7 @@ void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm)
   }
   hipLaunchKernelGGL(k_exload_create, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, bc, fin, d.pos,
                      d.map, d.flags);
-  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, d.flags);
+  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, P.atype, d.flags);
 }
 
 // ========================================= bond/create =========================================
@@ -699,7 +759,7 @@ void launch_bond_create(DeviceState &d, const ExLoadParams &P, int slot, const i
   }
   hipLaunchKernelGGL(k_exload_create, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, bc, fin, d.pos,
                      d.map, d.flags);
-  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, d.flags);
+  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, P.atype, d.flags);
 }
 void bond_create_counts(DeviceState &d, int *bondcount, int nt) {
   HIP_CHECK(hipMemcpyAsync(bondcount, d.le_i[I_BC], (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, d.stream));
@@ -776,7 +836,7 @@ void launch_ex_unload(DeviceState &d, const ExUnloadParams &P, int slot) {
     launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
   }
   hipLaunchKernelGGL(k_exunload_break, dim3(nb), dim3(BLOCK), 0, st, tp, P, partner, didx, d.le_draws, fin, d.flags);
-  hipLaunchKernelGGL(k_topo_broken, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, d.flags);
+  hipLaunchKernelGGL(k_topo_broken, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin, P.angleflag, d.flags);
 }
 
 // ========================================= extrusion ==========================================
@@ -1007,8 +1067,8 @@ void launch_extrusion(DeviceState &d, const ExtrusionParams &P, int slot) {
   hipLaunchKernelGGL(k_ext_losers, dim3(nb), dim3(BLOCK), 0, st, T, to_add, tr0, tr1);
   hipLaunchKernelGGL(k_ext_remove, dim3(nb), dim3(BLOCK), 0, st, tp, tr1, to_add, fin_rm, d.flags);
   hipLaunchKernelGGL(k_ext_create, dim3(nb), dim3(BLOCK), 0, st, tp, P.btype, tr1, to_add, bc, fin_add, d.flags);
-  hipLaunchKernelGGL(k_topo_broken, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin_rm, d.flags);
-  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin_add, d.flags);
+  hipLaunchKernelGGL(k_topo_broken, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin_rm, 0, d.flags);
+  hipLaunchKernelGGL(k_topo_created, dim3((T + 63) / 64), dim3(64), 0, st, tp, fin_add, 0, d.flags);
 }
 
 }  // namespace lmp_le

@@ -784,6 +784,175 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   if (next && swap_buffers) std::swap(d.pos, d.pos_tmp);
 }
 
+// ------------------------------------------------------------------------------------------
+// Angle forces (angle_style harmonic | cosine): AngleHarmonic::compute / AngleCosine::compute (src/MOLECULE/
+// angle_harmonic.cpp:53-147, angle_cosine.cpp:49-121) as one thread per bead over the LISTED angles the bead is part of
+// (k_angle_list above).  A bead evaluates every such angle and keeps
+// only its own share - f1 as atom 1, -(f1 + f3) as the centre, f3 as atom 3 - so no atomics are needed and the order of
+// a bead's sum is fixed; the two other atoms are found through map[] (tag -> index).  Energy and virial: a third of each
+// per stored copy, which is Angle::ev_tally with newton_bond off (src/angle.cpp:164-250).  The two arms are taken by
+// minimum image (they are a bond long; the reference uses the images closest to the listing atom at the last reneighbor).
+// The angle list (NTopoAngleAll::build with newton_bond off, src/ntopo_angle_all.cpp:55-76): the copy atom i stores is
+// listed iff i has the lowest local index of the three atoms, and a listed angle moves all three.  One thread per atom
+// appends its listed copies to the three atoms' records; a second kernel sorts each atom's records (central atom, ends,
+// type), so that what a bead sums, and in which order, depends on nothing but the topology.  (An angle across a periodic
+// face is listed once here and moves all three atoms, which is what the reference's per-image listings add up to as long
+// as all three atoms hold their copies.)
+__global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, const int *__restrict__ crank,
+                                                      const int *__restrict__ num_angle, const int *__restrict__ angle_type,
+                                                      const int *__restrict__ a1, const int *__restrict__ a2,
+                                                      const int *__restrict__ a3, int *__restrict__ eff_n,
+                                                      int *__restrict__ eff_rec, int *__restrict__ flags) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x + 1;
+  if (i > T) return;
+  const int na = num_angle[i];
+  const int li = crank ? crank[i] : i;
+  for (int m = 0; m < na; m++) {
+    const size_t c = (size_t)i * apa + m;
+    const int t[3] = {a1[c], a2[c], a3[c]};
+    bool listed = true;
+    for (int q = 0; q < 3; q++) listed = listed && li <= (crank ? crank[t[q]] : t[q]);
+    if (!listed) continue;
+    for (int q = 0; q < 3; q++) {
+      const int slot = atomicAdd(&eff_n[t[q]], 1);
+      if (slot >= ecap) { flags[FLAG_ERROR] = ERR_ANGLES; continue; }
+      int *r = eff_rec + ((size_t)t[q] * ecap + slot) * 4;
+      r[0] = angle_type[c]; r[1] = t[0]; r[2] = t[1]; r[3] = t[2];
+    }
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_angle_sort(int T, int ecap, int *__restrict__ eff_n, int *__restrict__ eff_rec) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x + 1;
+  if (i > T) return;
+  const int n = min(eff_n[i], ecap);
+  eff_n[i] = n;
+  int *r = eff_rec + (size_t)i * ecap * 4;
+  auto less = [](const int *x, const int *y) {
+    const int xl = min(x[1], x[3]), xh = max(x[1], x[3]), yl = min(y[1], y[3]), yh = max(y[1], y[3]);
+    if (x[2] != y[2]) return x[2] < y[2];
+    if (xl != yl) return xl < yl;
+    if (xh != yh) return xh < yh;
+    return x[0] < y[0];
+  };
+  for (int a = 1; a < n; a++) {
+    int key[4] = {r[4 * a], r[4 * a + 1], r[4 * a + 2], r[4 * a + 3]};
+    int b = a - 1;
+    while (b >= 0 && less(key, r + 4 * b)) { for (int q = 0; q < 4; q++) r[4 * (b + 1) + q] = r[4 * b + q]; b--; }
+    for (int q = 0; q < 4; q++) r[4 * (b + 1) + q] = key[q];
+  }
+}
+void launch_angle_list(DeviceState &d) {
+  if (d.apa <= 0) return;
+  const int T = d.maxtag, nb = std::max(1, (T + BLOCK - 1) / BLOCK);
+  HIP_CHECK(hipMemsetAsync(d.eff_n, 0, ((size_t)T + 2) * sizeof(int), d.stream));
+  hipLaunchKernelGGL(k_angle_list, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, d.ecap, d.ident_order ? (const int *)nullptr : d.crank,
+                     d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, d.eff_rec, d.flags);
+  hipLaunchKernelGGL(k_angle_sort, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.ecap, d.eff_n, d.eff_rec);
+}
+
+#define ANGLE_SMALL 0.001
+template <bool EFLAG>
+__global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, AngleTable at, const double4 *__restrict__ pos,
+                                                 const int *__restrict__ tag, const int *__restrict__ map,
+                                                 const int *__restrict__ num_angle, const int *__restrict__ rec,
+                                                 double *__restrict__ fx,
+                                                 double *__restrict__ fy, double *__restrict__ fz,
+                                                 double *__restrict__ partial_a, int *__restrict__ flags) {
+  const int p = blockIdx.x * BLOCK + threadIdx.x;
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc[k] = 0.0;
+  if (p < n) {
+    const int t = tag[p];
+    const int na = num_angle[t];
+    double f0 = 0.0, f1v = 0.0, f2 = 0.0;
+    for (int m = 0; m < na; m++) {
+      const int *r = rec + ((size_t)t * ecap + m) * 4;
+      const int type = r[0];
+      if (type <= 0 || at.style[type] == 0) continue;
+      const int t1 = r[1], t2 = r[2], t3 = r[3];
+      const int p1 = map[t1], p2 = map[t2], p3 = map[t3];
+      if (p1 < 0 || p2 < 0 || p3 < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
+      const double4 r1 = pos[p1], r2 = pos[p2], r3 = pos[p3];
+      double delx1 = r1.x - r2.x, dely1 = r1.y - r2.y, delz1 = r1.z - r2.z;
+      double delx2 = r3.x - r2.x, dely2 = r3.y - r2.y, delz2 = r3.z - r2.z;
+      const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
+      if (delx1 > hx) delx1 -= box.prd[0]; else if (delx1 < -hx) delx1 += box.prd[0];
+      if (dely1 > hy) dely1 -= box.prd[1]; else if (dely1 < -hy) dely1 += box.prd[1];
+      if (delz1 > hz) delz1 -= box.prd[2]; else if (delz1 < -hz) delz1 += box.prd[2];
+      if (delx2 > hx) delx2 -= box.prd[0]; else if (delx2 < -hx) delx2 += box.prd[0];
+      if (dely2 > hy) dely2 -= box.prd[1]; else if (dely2 < -hy) dely2 += box.prd[1];
+      if (delz2 > hz) delz2 -= box.prd[2]; else if (delz2 < -hz) delz2 += box.prd[2];
+      const double rsq1 = delx1 * delx1 + dely1 * dely1 + delz1 * delz1, ra = sqrt(rsq1);
+      const double rsq2 = delx2 * delx2 + dely2 * dely2 + delz2 * delz2, rb = sqrt(rsq2);
+      double cs = delx1 * delx2 + dely1 * dely2 + delz1 * delz2;
+      cs /= ra * rb;
+      if (cs > 1.0) cs = 1.0;
+      if (cs < -1.0) cs = -1.0;
+      double a, eangle = 0.0;
+      if (at.style[type] == 1) {
+        double sn = sqrt(1.0 - cs * cs);
+        if (sn < ANGLE_SMALL) sn = ANGLE_SMALL;
+        sn = 1.0 / sn;
+        const double dtheta = acos(cs) - at.theta0[type], tk = at.k[type] * dtheta;
+        if (EFLAG) eangle = tk * dtheta;
+        a = -2.0 * tk * sn;
+      } else {
+        if (EFLAG) eangle = at.k[type] * (1.0 + cs);
+        a = at.k[type];
+      }
+      const double a11 = a * cs / rsq1, a12 = -a / (ra * rb), a22 = a * cs / rsq2;
+      const double f1x = a11 * delx1 + a12 * delx2, f1y = a11 * dely1 + a12 * dely2, f1z = a11 * delz1 + a12 * delz2;
+      const double f3x = a22 * delx2 + a12 * delx1, f3y = a22 * dely2 + a12 * dely1, f3z = a22 * delz2 + a12 * delz1;
+      if (t == t1) { f0 += f1x; f1v += f1y; f2 += f1z; }
+      else if (t == t2) { f0 -= f1x + f3x; f1v -= f1y + f3y; f2 -= f1z + f3z; }
+      else { f0 += f3x; f1v += f3y; f2 += f3z; }
+      if (EFLAG) {
+        const double third = 1.0 / 3.0;
+        acc[0] += third * eangle;
+        acc[1] += third * (delx1 * f1x + delx2 * f3x); acc[2] += third * (dely1 * f1y + dely2 * f3y);
+        acc[3] += third * (delz1 * f1z + delz2 * f3z); acc[4] += third * (delx1 * f1y + delx2 * f3y);
+        acc[5] += third * (delx1 * f1z + delx2 * f3z); acc[6] += third * (dely1 * f1z + dely2 * f3z);
+      }
+    }
+    fx[p] += f0; fy[p] += f1v; fz[p] += f2;
+  }
+  if (EFLAG) {
+    __shared__ double red[BLOCK / 64][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      double v = acc[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      double v = 0.0;
+      for (int w = 0; w < BLOCK / 64; w++) v += red[w][threadIdx.x];
+      partial_a[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
+    }
+  }
+}
+void launch_angle(DeviceState &d, const AngleTable &at, bool eflag) {
+  if (d.apa <= 0) return;
+  const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
+  if (eflag)
+    hipLaunchKernelGGL((k_angle<true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.tag, d.map, d.eff_n,
+                       d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
+  else
+    hipLaunchKernelGGL((k_angle<false>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.tag, d.map, d.eff_n,
+                       d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
+}
+void reduce_angle_partials(DeviceState &d, double *out8) {
+  const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
+  std::vector<double> h((size_t)nb * 8);
+  HIP_CHECK(hipMemcpyAsync(h.data(), d.partial_a, h.size() * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  stream_sync(d);
+  for (int k = 0; k < 8; k++) out8[k] = 0.0;
+  for (int b = 0; b < nb; b++) for (int k = 0; k < 8; k++) out8[k] += h[(size_t)b * 8 + k];
+}
+
 // sum the per-block partials on the host in block order (deterministic)
 void reduce_partials(DeviceState &d, double *out16) {
   int nb = (d.n + BLOCK - 1) / BLOCK;

@@ -46,6 +46,10 @@ def write_data(path, s):
     with open(path, "w") as fh:
         fh.write("synthetic bead-spring system\n\n")
         fh.write("%d atoms\n%d atom types\n%d bonds\n%d bond types\n" % (n, s["ntypes"], len(s["bonds"]), s["nbondtypes"]))
+        if s.get("nangletypes"):
+            fh.write("%d angles\n%d angle types\n" % (len(s.get("angles", [])), s["nangletypes"]))
+            if s.get("extra_angle"):
+                fh.write("%d extra angle per atom\n" % s["extra_angle"])
         if s.get("extra_bond"):
             fh.write("%d extra bond per atom\n" % s["extra_bond"])
         if s.get("extra_special"):
@@ -70,6 +74,10 @@ def write_data(path, s):
             fh.write("\nBonds\n\n")
             for k, (bt, a, b) in enumerate(s["bonds"]):
                 fh.write("%d %d %d %d\n" % (k + 1, bt, a, b))
+        if s.get("nangletypes") and len(s.get("angles", [])):
+            fh.write("\nAngles\n\n")
+            for k, (at, a, b, c) in enumerate(s["angles"]):
+                fh.write("%d %d %d %d %d\n" % (k + 1, at, a, b, c))
 
 
 def wrap_into_box(s):
@@ -124,6 +132,8 @@ class OracleScript:
         tag = (np.asarray(order) + 1).astype(np.int32)
         o.atoms(tag, s["type"][order], x[order], s["v"][order], img[order])
         o.bonds(s["bonds"])
+        if s.get("nangletypes"):
+            o.angles(s["nangletypes"], s.get("angles", np.zeros((0, 4), dtype=np.int32)), s.get("extra_angle", 0))
         o.special_bonds(*self.special, coul=self.special_coul)
         self.o = o
 
@@ -194,6 +204,12 @@ class OracleScript:
             kw = dict(zip(a[::2], a[1::2]))
             o.neighbor(every=int(kw.get("every", 0)), delay=int(kw.get("delay", -1)),
                        check={"yes": 1, "no": 0, None: -1}[kw.get("check")])
+        elif c == "angle_style":
+            self.angle_style = a[0]
+        elif c == "angle_coeff":
+            types = range(1, self.sys["nangletypes"] + 1) if a[0] == "*" else [int(a[0])]
+            for at in types:
+                o.angle_coeff(at, self.angle_style, *[float(v) for v in a[1:]])
         elif c == "bond_style":
             self.bond_style = a[0]
             self.hybrid = a[1:]
@@ -238,6 +254,7 @@ class OracleScript:
                                 int(p[6]) if len(p) > 6 else -1, fid)
             elif style in ("ex_load", "bond/create"):
                 kw = dict(imax=0, inew=None, jmax=0, jnew=None, fraction=1.0, seed=12345)
+                atype = 0
                 k = 5
                 while k < len(p):
                     if p[k] == "iparam":
@@ -247,12 +264,16 @@ class OracleScript:
                     elif p[k] == "prob":
                         kw["fraction"], kw["seed"] = float(p[k + 1]), int(p[k + 2])
                     elif p[k] in ("atype", "dtype", "itype"):
-                        # fix_ex_load.cpp:236-254: effective only `if (atype && force->angle)`; these scripts define no
-                        # angle / dihedral / improper style, so the keyword has no effect in the reference either
+                        # fix_ex_load.cpp:236-254: effective only `if (atype && force->angle)`: angles when the script
+                        # defined an angle style; no dihedral / improper styles here, so dtype / itype have no effect
+                        if p[k] == "atype" and getattr(self, "angle_style", None) in ("harmonic", "cosine"):
+                            atype = int(p[k + 1])
                         k += 2
                         continue
                     k += 3
                 (o.fix_ex_load if style == "ex_load" else o.fix_bond_create)(int(p[0]), int(p[1]), int(p[2]), float(p[3]), int(p[4]), fid=fid, **kw)
+                if atype:
+                    o.ex_load_atype(fid, atype)
             elif style in ("ex_unload", "bond/break"):
                 kw = dict(fraction=1.0, seed=12345)
                 if len(p) > 3 and p[3] == "prob":
