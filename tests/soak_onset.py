@@ -5,6 +5,10 @@ keeping the complete state (x, v, image, type, bond tables, step) of the START o
 in which `FENE bond too long` warnings appear it writes that state plus the warning counts of this and the next chunks
 to gpurun_out/soak_onset.npz and stops.
 
+`soak_onset.py both NBEADS MAXSTEPS PLOAD PUNLOAD [QUIET] [CHUNKS]` does both in one process without writing the state (an
+8M-bead state does not fit the 64 MiB that travel back from the GPU box): GPU run to the first warning chunk, then the
+oracle replay of CHUNKS chunks on the same box's host cores.
+
 CPU part (`soak_onset.py replay [file]`): rebuilds the oracle from the saved state (same step number, so the LE fixes
 fire at the same steps) and runs the same chunks.  Over a few hundred steps the two trajectories agree to ~1e-10, so
 the oracle must report the SAME number of warnings in the same chunks if the warnings are reference behaviour and not
@@ -39,7 +43,7 @@ def bonds_rows(nb, bt, ba):
     return np.stack([bt[keep], own[keep], ba[keep]], axis=1).astype(np.int32)
 
 
-def gpu(n, maxsteps, pload, punload):
+def gpu(n, maxsteps, pload, punload, quiet_steps=None, save=True):
     from lammps_le_amd import lammps
     sysd, script = make(n, pload, punload)
     data = os.path.join(tempfile.mkdtemp(), "data")
@@ -53,7 +57,7 @@ def gpu(n, maxsteps, pload, punload):
                     num_bond=lmp.gather("num_bond"), bond_type=lmp.gather("bond_type"), bond_atom=lmp.gather("bond_atom"),
                     step=int(lmp.get_thermo("step")))
     # the first 40 000 steps never warned in any run: skip the per-chunk state copies there
-    quiet = min(40000, maxsteps // 2)
+    quiet = min(40000, maxsteps // 2) if quiet_steps is None else quiet_steps
     lmp.command("run %d" % quiet)
     prev, warn_prev, found = state(), int(lmp.stat("fene_warnings")), None
     counts = []
@@ -74,16 +78,19 @@ def gpu(n, maxsteps, pload, punload):
             print("step %d extruders %d, no warnings yet" % (prev["step"], lmp.get_thermo("bonds") - (n - 1)), flush=True)
     if found is None:
         print("no FENE warnings up to step %d" % prev["step"])
-        return
+        return None
+    lmp.close()
+    if not save:
+        return dict(n=n, pload=pload, punload=punload, counts=np.array(counts), **found)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     out = os.path.join(ROOT, "gpurun_out", "soak_onset.npz")
     np.savez_compressed(out, n=n, pload=pload, punload=punload, counts=np.array(counts), **found)
     print("saved", out, "counts per chunk", counts)
 
 
-def replay(path):
+def replay(path, nchunks=None):
     from systems import OracleScript
-    d = np.load(path)
+    d = path if isinstance(path, dict) else np.load(path)
     n, pload, punload = int(d["n"]), float(d["pload"]), float(d["punload"])
     sysd, script = make(n, pload, punload)
     s2 = dict(sysd)
@@ -96,7 +103,7 @@ def replay(path):
     step = int(d["step"])
     osc.line("reset_timestep %d" % step)
     o = osc.o
-    want = list(d["counts"])
+    want = list(d["counts"])[:nchunks]
     print("state of step %d, %d beads, %d extruders; product warnings per %d-step chunk: %s" %
           (step, n, len(s2["bonds"]) - (n - 1), CHUNK, want))
     got = []
@@ -127,7 +134,12 @@ def replay(path):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "gpu":
+    if sys.argv[1] == "both":
+        st = gpu(int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5]),
+                 quiet_steps=int(sys.argv[6]) if len(sys.argv) > 6 else None, save=False)
+        if st is not None:
+            replay(st, nchunks=int(sys.argv[7]) if len(sys.argv) > 7 else 1)
+    elif sys.argv[1] == "gpu":
         gpu(int(sys.argv[2]) if len(sys.argv) > 2 else 250000, int(sys.argv[3]) if len(sys.argv) > 3 else 120000,
             float(sys.argv[4]) if len(sys.argv) > 4 else 0.01, float(sys.argv[5]) if len(sys.argv) > 5 else 0.01)
     else:
