@@ -75,6 +75,9 @@ WORKLOADS = {
     "walk1m": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
     "walk100k": (100000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
     "walk8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5, "walk", 0.01),        # chain8m from the scrambled start (the one that survives long runs)
+    # semiflexible chain: walk1m + angle_style cosine on every backbone triple, ex_load ... atype 2.  Takes the
+    # unfused step (force kernel, angle kernel, Langevin / integrate kernels), so `roofline` is not reported for it
+    "walk1m_angles": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
 }
 
 
@@ -179,12 +182,20 @@ def main():
         sysd = scrambled_chains(nbeads, nchains=nchains, seed=1, barrier_every=bar)
     else:
         sysd = lattice_chains(nbeads, nchains=nchains, seed=1, barrier_every=bar)
+    angles = args.workload.endswith("_angles")
+    if angles:
+        from lammps_le_amd.synth import add_backbone_angles
+        add_backbone_angles(sysd, nchains=nchains)
     ntypes = sysd["ntypes"]
     tmp = tempfile.mkdtemp(prefix="le_bench_")
     data = os.path.join(tmp, "data.r%d" % rank)
     write_data(data, sysd)
     left, right, lr = (2, 3, "4") if ntypes == 4 else (1, 1, "")
     script = CHAIN_INPUT.format(data=data, n1=n1, left=left, right=right, tp=tp, lr=lr, nload=nload, pload=pload, punload=punload)
+    if angles:
+        script = script.replace("atom_style bond", "atom_style molecular") \
+            .replace("pair_style lj/cut", "angle_style cosine\nangle_coeff * 2.0\npair_style lj/cut") \
+            .replace("iparam 1 1 jparam 1 1", "iparam 1 1 jparam 1 1 atype 2")
 
     lmp = lammps(cmdargs=["-screen", "none"])
     rccl_nranks = 1

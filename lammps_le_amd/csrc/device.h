@@ -233,12 +233,12 @@ void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4
 void launch_flevel_copy(DeviceState &d, double *flevel, bool to_level, bool add);
 void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start = nullptr,
-                 hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true);
+                 hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true, bool angle_forces = false);
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt);
 void launch_ke(DeviceState &d, const TypeTables &tt);
 // angle forces added to f (after launch_force); eflag: energy / virial thirds into partial_a (reduce_angle_partials)
-void launch_angle(DeviceState &d, const AngleTable &at, bool eflag);
+void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwrite = false);
 void launch_angle_list(DeviceState &d);       // at every reneighbor of a run with an angle style
 void reduce_angle_partials(DeviceState &d, double *out8);
 // reductions: returns sums of `partial` columns on the host (synchronises the stream)

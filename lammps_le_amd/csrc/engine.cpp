@@ -747,8 +747,9 @@ void Engine::iterate(long nsteps) {
   // bond morse (the reference's unit-test partner of bond hybrid, not a style of the chromatin model) lives in the
   // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
   for (int b = 1; b <= nbondtypes; b++) if (bondtab.style[b] == 3) fusable = false;
-  // angles (semiflexible chains) are a kernel of their own behind the force kernel: unfused steps
-  if (angles_active()) fusable = false;
+  // angles (semiflexible chains): a kernel of their own writes the angle forces right before the fused step
+  // kernel, which adds them to its sums (one GPU; decomposed runs refuse angles)
+  const bool ang = angles_active();
   bool ident = d.ident_order;
   bool pre_integrated = false;
   // halo/compute overlap issues the per-step halo on a second stream.  With RCCL that means two streams feeding ONE
@@ -813,15 +814,17 @@ void Engine::iterate(long nsteps) {
         d.halo_ahead = true;
         std::swap(d.pos, d.pos_tmp);
       } else {
+        if (ang) launch_angle(d, angtab, false, true);
         launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
-                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr);
+                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang);
         if (!finish_reneighbor()) {
           // a list of the build that preceded this launch overflowed: the kernel saw the flag and stored nothing.
           // Undo the launch on the host side, grow the table, rebuild, launch again.
           if (next) std::swap(d.pos, d.pos_tmp);
           regrow_lists();
+          if (ang) launch_angle(d, angtab, false, true);
           launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
-                      timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr);
+                      timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang);
         }
       }
       if (timed) d.ev_used++;

@@ -178,6 +178,9 @@ struct ForceArgs {
   // decomposed runs: border beads also write their new position into the halo send buffer (no pack launch per step)
   const int *sendslot;
   double4 *send_dn, *send_up;   // the staging buffer's two halves, or the neighbours' windows (kernels_dd.hip, fast halo)
+  // runs with an angle style: the angle forces of this step, written by k_angle<.., OVERWRITE> right before this launch
+  // into the (otherwise unused) force arrays; nullptr = no angles
+  const double *fang_x, *fang_y, *fang_z;
 };
 
 // reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp from the IEEE quotient 1/x; an IEEE divide is ~35 instructions)
@@ -548,6 +551,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
     for (int o = 1; o < LPB; o <<= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); }
     if (sub) return;
   }
+  if (A.fang_x) { f0 += A.fang_x[p]; f1 += A.fang_y[p]; f2 += A.fang_z[p]; }     // (wave-uniform) Angle::compute follows Bond::compute
   const int type = (int)ri.w;
   if (LANGEVIN) {
     double gamma1 = tt.g1[type], gamma2 = tt.g2[type];
@@ -669,6 +673,7 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.maxrow = d.maxneigh - 1;
   A.diag = 0;
   A.sendslot = nullptr; A.send_dn = A.send_up = nullptr;
+  A.fang_x = A.fang_y = A.fang_z = nullptr;
   {
     // posf = (float)xhold: a coordinate is off by <= M * 2^-24, a squared displacement d^2 <= skin^2/4 .. by
     // <= 2 * sqrt(3) * |d| * e + 3 e^2; |d| <= ~skin near the threshold.  Band = four times that bound.
@@ -711,8 +716,9 @@ void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool 
 // fused force + Langevin + final_integrate [+ next initial_integrate]; swaps the position buffers when `next`
 void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
-                 hipEvent_t ev_stop, int which, bool swap_buffers) {
+                 hipEvent_t ev_stop, int which, bool swap_buffers, bool angle_forces) {
   ForceArgs A = force_args(d, sl);
+  if (angle_forces) { A.fang_x = d.f[0]; A.fang_y = d.f[1]; A.fang_z = d.f[2]; }
   if (d.dd && next && d.sendslot && !d.sendslot_fallback) {
     A.sendslot = d.sendslot;
     if (d.fast_halo && d.direct_recv && which < 0) {
@@ -851,7 +857,7 @@ void launch_angle_list(DeviceState &d) {
 }
 
 #define ANGLE_SMALL 0.001
-template <bool EFLAG>
+template <bool EFLAG, bool OVERWRITE = false>
 __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, AngleTable at, const double4 *__restrict__ pos,
                                                  const int *__restrict__ tag, const int *__restrict__ map,
                                                  const int *__restrict__ num_angle, const int *__restrict__ rec,
@@ -915,7 +921,8 @@ __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, Angle
         acc[5] += third * (delx1 * f1z + delx2 * f3z); acc[6] += third * (dely1 * f1z + dely2 * f3z);
       }
     }
-    fx[p] += f0; fy[p] += f1v; fz[p] += f2;
+    if (OVERWRITE) { fx[p] = f0; fy[p] = f1v; fz[p] = f2; }      // the fused step kernel adds them to its own sums
+    else { fx[p] += f0; fy[p] += f1v; fz[p] += f2; }
   }
   if (EFLAG) {
     __shared__ double red[BLOCK / 64][8];
@@ -934,10 +941,13 @@ __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, Angle
     }
   }
 }
-void launch_angle(DeviceState &d, const AngleTable &at, bool eflag) {
+void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwrite) {
   if (d.apa <= 0) return;
   const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
-  if (eflag)
+  if (overwrite)
+    hipLaunchKernelGGL((k_angle<false, true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.tag, d.map, d.eff_n,
+                       d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
+  else if (eflag)
     hipLaunchKernelGGL((k_angle<true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.tag, d.map, d.eff_n,
                        d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
   else

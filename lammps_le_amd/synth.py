@@ -98,6 +98,19 @@ def scrambled_chains(nbeads, nchains=1, density=0.85, seed=1, jitter=0.03, temp=
     return _finish(x, n, nchains, barrier_every, L * a, rng, temp)
 
 
+def add_backbone_angles(s, nchains=1, atype=1, nangletypes=2, extra_angle=24):
+    """Semiflexible chains: one angle (i, i+1, i+2) of type `atype` per backbone triple (not across a chain end); the data
+    file then needs `atom_style angle | molecular`.  extra_angle: room for the angles `fix ex_load ... atype N` creates."""
+    n = len(s["x"])
+    per = n // nchains
+    i = np.arange(1, n - 1)
+    keep = (np.minimum((i - 1) // per, nchains - 1) == np.minimum((i + 1) // per, nchains - 1))
+    i = i[keep]
+    s["angles"] = np.stack([np.full_like(i, atype), i, i + 1, i + 2], axis=1).astype(np.int32)
+    s["nangletypes"], s["extra_angle"], s["atom_style"] = nangletypes, extra_angle, "molecular"
+    return s
+
+
 def write_data(path, s):
     """LAMMPS data file (atom_style bond) with %.17g coordinates; pandas C writer for speed."""
     import pandas as pd
@@ -105,6 +118,10 @@ def write_data(path, s):
     with open(path, "w") as fh:
         fh.write("synthetic bead-spring chains (lammps_le_amd.synth)\n\n")
         fh.write("%d atoms\n%d atom types\n%d bonds\n%d bond types\n" % (n, s["ntypes"], len(s["bonds"]), s["nbondtypes"]))
+        if s.get("nangletypes"):
+            fh.write("%d angles\n%d angle types\n" % (len(s.get("angles", [])), s["nangletypes"]))
+            if s.get("extra_angle"):
+                fh.write("%d extra angle per atom\n" % s["extra_angle"])
         if s.get("extra_bond"):
             fh.write("%d extra bond per atom\n" % s["extra_bond"])
         if s.get("extra_special"):
@@ -128,6 +145,11 @@ def write_data(path, s):
             b = s["bonds"]
             db = pd.DataFrame({"k": np.arange(1, len(b) + 1), "t": b[:, 0], "a": b[:, 1], "b": b[:, 2]})
             db.to_csv(fh, sep=" ", header=False, index=False)
+        if s.get("nangletypes") and len(s.get("angles", [])):
+            fh.write("\nAngles\n\n")
+            a = s["angles"]
+            da = pd.DataFrame({"k": np.arange(1, len(a) + 1), "t": a[:, 0], "a": a[:, 1], "b": a[:, 2], "c": a[:, 3]})
+            da.to_csv(fh, sep=" ", header=False, index=False)
 
 
 CHAIN_INPUT = """units lj
