@@ -59,7 +59,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
     dalloc(d.num_angle, nt); dalloc(d.angle_type, nt * d.apa); dalloc(d.angle_a1, nt * d.apa); dalloc(d.angle_a2, nt * d.apa);
     dalloc(d.angle_a3, nt * d.apa);
     d.ecap = d.apa + 8;
-    dalloc(d.eff_n, nt); dalloc(d.eff_rec, nt * (size_t)d.ecap * 4);
+    dalloc(d.eff_n, np); dalloc(d.eff_rec, np * (size_t)d.ecap * 4);       // by the bead's physical index, records column-major
   }
   if (maxtag >= (1 << BOND_TYPE_SHIFT)) throw LammpsError("MI355X engine: atom IDs must stay below 2^26");
   d.bond_pack_stride = ((1 + bpa) + 3) & ~3;

@@ -87,7 +87,7 @@ struct DeviceState {
   // the other two hold (copies go out of step when fix ex_unload's influence rule spares one atom).  eff_*[t]: the listed
   // angles bead t is part of, sorted, so that the force kernel is a per-bead gather with a fixed summation order.
   int ecap = 0;
-  int *eff_n = nullptr, *eff_rec = nullptr;      // [maxtag+2], [maxtag+2][ecap][4] = type a1 a2 a3
+  int *eff_n = nullptr, *eff_rec = nullptr;      // [npad], int4 [ecap][npad] = (type, i1, i2, i3) with PHYSICAL indices, column-major
   // bond tables as of the last reneighbor = the reference's neighbor->bondlist, which the LE fixes loop over
   // even when another LE fix changed the topology earlier in the same step (fix_ex_unload.cpp:223, fix_extrusion.cpp:368)
   int *num_bond0 = nullptr, *bond_type0 = nullptr, *bond_atom0 = nullptr;

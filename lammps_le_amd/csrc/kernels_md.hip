@@ -804,11 +804,12 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 // type), so that what a bead sums, and in which order, depends on nothing but the topology.  (An angle across a periodic
 // face is listed once here and moves all three atoms, which is what the reference's per-image listings add up to as long
 // as all three atoms hold their copies.)
-__global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, const int *__restrict__ crank,
+__global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, int npad, const int *__restrict__ crank,
+                                                      const int *__restrict__ map,
                                                       const int *__restrict__ num_angle, const int *__restrict__ angle_type,
                                                       const int *__restrict__ a1, const int *__restrict__ a2,
                                                       const int *__restrict__ a3, int *__restrict__ eff_n,
-                                                      int *__restrict__ eff_rec, int *__restrict__ flags) {
+                                                      int4 *__restrict__ eff_rec, int *__restrict__ flags) {
   const int i = blockIdx.x * BLOCK + threadIdx.x + 1;
   if (i > T) return;
   const int na = num_angle[i];
@@ -819,48 +820,57 @@ __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, 
     bool listed = true;
     for (int q = 0; q < 3; q++) listed = listed && li <= (crank ? crank[t[q]] : t[q]);
     if (!listed) continue;
+    // records hold PHYSICAL indices (this list lives until the next reneighbor, like the indices) and sit column-major by
+    // the bead's own index: the force kernel reads them coalesced and gathers positions without a tag -> index lookup
+    const int p[3] = {map[t[0]], map[t[1]], map[t[2]]};
+    if (p[0] < 0 || p[1] < 0 || p[2] < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
+    const int4 rec = make_int4(angle_type[c], p[0], p[1], p[2]);
     for (int q = 0; q < 3; q++) {
-      const int slot = atomicAdd(&eff_n[t[q]], 1);
+      const int slot = atomicAdd(&eff_n[p[q]], 1);
       if (slot >= ecap) { flags[FLAG_ERROR] = ERR_ANGLES; continue; }
-      int *r = eff_rec + ((size_t)t[q] * ecap + slot) * 4;
-      r[0] = angle_type[c]; r[1] = t[0]; r[2] = t[1]; r[3] = t[2];
+      eff_rec[(size_t)slot * npad + p[q]] = rec;
     }
   }
 }
-__global__ __launch_bounds__(BLOCK) void k_angle_sort(int T, int ecap, int *__restrict__ eff_n, int *__restrict__ eff_rec) {
-  const int i = blockIdx.x * BLOCK + threadIdx.x + 1;
-  if (i > T) return;
-  const int n = min(eff_n[i], ecap);
-  eff_n[i] = n;
-  int *r = eff_rec + (size_t)i * ecap * 4;
-  auto less = [](const int *x, const int *y) {
-    const int xl = min(x[1], x[3]), xh = max(x[1], x[3]), yl = min(y[1], y[3]), yh = max(y[1], y[3]);
-    if (x[2] != y[2]) return x[2] < y[2];
+__global__ __launch_bounds__(BLOCK) void k_angle_sort(int n, int ecap, int npad, int *__restrict__ eff_n, int4 *__restrict__ eff_rec) {
+  const int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const int cnt = min(eff_n[p], ecap);
+  eff_n[p] = cnt;
+  if (cnt < 2) return;
+  auto less = [](const int4 &x, const int4 &y) {       // (type, i1, i2, i3) = (x, y, z, w): centre, ends, type
+    const int xl = min(x.y, x.w), xh = max(x.y, x.w), yl = min(y.y, y.w), yh = max(y.y, y.w);
+    if (x.z != y.z) return x.z < y.z;
     if (xl != yl) return xl < yl;
     if (xh != yh) return xh < yh;
-    return x[0] < y[0];
+    return x.x < y.x;
   };
-  for (int a = 1; a < n; a++) {
-    int key[4] = {r[4 * a], r[4 * a + 1], r[4 * a + 2], r[4 * a + 3]};
+  for (int a = 1; a < cnt; a++) {
+    const int4 key = eff_rec[(size_t)a * npad + p];
     int b = a - 1;
-    while (b >= 0 && less(key, r + 4 * b)) { for (int q = 0; q < 4; q++) r[4 * (b + 1) + q] = r[4 * b + q]; b--; }
-    for (int q = 0; q < 4; q++) r[4 * (b + 1) + q] = key[q];
+    while (b >= 0) {
+      const int4 cur = eff_rec[(size_t)b * npad + p];
+      if (!less(key, cur)) break;
+      eff_rec[(size_t)(b + 1) * npad + p] = cur;
+      b--;
+    }
+    eff_rec[(size_t)(b + 1) * npad + p] = key;
   }
 }
 void launch_angle_list(DeviceState &d) {
   if (d.apa <= 0) return;
   const int T = d.maxtag, nb = std::max(1, (T + BLOCK - 1) / BLOCK);
-  HIP_CHECK(hipMemsetAsync(d.eff_n, 0, ((size_t)T + 2) * sizeof(int), d.stream));
-  hipLaunchKernelGGL(k_angle_list, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, d.ecap, d.ident_order ? (const int *)nullptr : d.crank,
-                     d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, d.eff_rec, d.flags);
-  hipLaunchKernelGGL(k_angle_sort, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.ecap, d.eff_n, d.eff_rec);
+  HIP_CHECK(hipMemsetAsync(d.eff_n, 0, (size_t)d.npad * sizeof(int), d.stream));
+  hipLaunchKernelGGL(k_angle_list, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, d.ecap, d.npad, d.ident_order ? (const int *)nullptr : d.crank,
+                     d.map, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
+  hipLaunchKernelGGL(k_angle_sort, dim3(std::max(1, (d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.npad, d.eff_n,
+                     (int4 *)d.eff_rec);
 }
 
 #define ANGLE_SMALL 0.001
 template <bool EFLAG, bool OVERWRITE = false>
 __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, AngleTable at, const double4 *__restrict__ pos,
-                                                 const int *__restrict__ tag, const int *__restrict__ map,
-                                                 const int *__restrict__ num_angle, const int *__restrict__ rec,
+                                                 int npad, const int *__restrict__ num_angle, const int4 *__restrict__ rec,
                                                  double *__restrict__ fx,
                                                  double *__restrict__ fy, double *__restrict__ fz,
                                                  double *__restrict__ partial_a, int *__restrict__ flags) {
@@ -869,17 +879,15 @@ __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, Angle
 #pragma unroll
   for (int k = 0; k < 8; k++) acc[k] = 0.0;
   if (p < n) {
-    const int t = tag[p];
-    const int na = num_angle[t];
+    const int na = num_angle[p];
+    const double4 rp = pos[p];
     double f0 = 0.0, f1v = 0.0, f2 = 0.0;
     for (int m = 0; m < na; m++) {
-      const int *r = rec + ((size_t)t * ecap + m) * 4;
-      const int type = r[0];
+      const int4 r = rec[(size_t)m * npad + p];
+      const int type = r.x;
       if (type <= 0 || at.style[type] == 0) continue;
-      const int t1 = r[1], t2 = r[2], t3 = r[3];
-      const int p1 = map[t1], p2 = map[t2], p3 = map[t3];
-      if (p1 < 0 || p2 < 0 || p3 < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
-      const double4 r1 = pos[p1], r2 = pos[p2], r3 = pos[p3];
+      const int p1 = r.y, p2 = r.z, p3 = r.w;
+      const double4 r1 = (p1 == p) ? rp : pos[p1], r2 = (p2 == p) ? rp : pos[p2], r3 = (p3 == p) ? rp : pos[p3];
       double delx1 = r1.x - r2.x, dely1 = r1.y - r2.y, delz1 = r1.z - r2.z;
       double delx2 = r3.x - r2.x, dely2 = r3.y - r2.y, delz2 = r3.z - r2.z;
       const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
@@ -910,8 +918,8 @@ __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, Angle
       const double a11 = a * cs / rsq1, a12 = -a / (ra * rb), a22 = a * cs / rsq2;
       const double f1x = a11 * delx1 + a12 * delx2, f1y = a11 * dely1 + a12 * dely2, f1z = a11 * delz1 + a12 * delz2;
       const double f3x = a22 * delx2 + a12 * delx1, f3y = a22 * dely2 + a12 * dely1, f3z = a22 * delz2 + a12 * delz1;
-      if (t == t1) { f0 += f1x; f1v += f1y; f2 += f1z; }
-      else if (t == t2) { f0 -= f1x + f3x; f1v -= f1y + f3y; f2 -= f1z + f3z; }
+      if (p == p1) { f0 += f1x; f1v += f1y; f2 += f1z; }
+      else if (p == p2) { f0 -= f1x + f3x; f1v -= f1y + f3y; f2 -= f1z + f3z; }
       else { f0 += f3x; f1v += f3y; f2 += f3z; }
       if (EFLAG) {
         const double third = 1.0 / 3.0;
@@ -945,14 +953,14 @@ void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwri
   if (d.apa <= 0) return;
   const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
   if (overwrite)
-    hipLaunchKernelGGL((k_angle<false, true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.tag, d.map, d.eff_n,
-                       d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
+    hipLaunchKernelGGL((k_angle<false, true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.npad, d.eff_n,
+                       (const int4 *)d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
   else if (eflag)
-    hipLaunchKernelGGL((k_angle<true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.tag, d.map, d.eff_n,
-                       d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
+    hipLaunchKernelGGL((k_angle<true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.npad, d.eff_n,
+                       (const int4 *)d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
   else
-    hipLaunchKernelGGL((k_angle<false>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.tag, d.map, d.eff_n,
-                       d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
+    hipLaunchKernelGGL((k_angle<false>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.box, at, d.pos, d.npad, d.eff_n,
+                       (const int4 *)d.eff_rec, d.f[0], d.f[1], d.f[2], d.partial_a, d.flags);
 }
 void reduce_angle_partials(DeviceState &d, double *out8) {
   const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
