@@ -189,6 +189,39 @@ std::shared_ptr<LocalHub> hub_for(const std::string &session) {
   if (!sp) { sp = std::make_shared<LocalHub>(); hubs[session] = sp; }
   return sp;
 }
+// A device message of the in-process transport is moved by a KERNEL on the receiver's stream (nothing for the runtime to
+// classify or stage).  Crash record, for whoever profiles this transport: three times - round 1 (gpurun_out/prof_ov2.log,
+// 2 rank threads) and twice in round 3 (8 rank threads x 1M beads) - a process died with SIGSEGV inside a host memcpy of
+// the HIP runtime, the fault address a device-visible address: first below hipMemcpyAsync <- local_exchange <- dd_halo,
+// and, once the copies were this kernel, below hipLaunchKernel <- msg_copy <- local_exchange <- dd_reneighbor, i.e. in the
+// runtime's own staging of a launch, with no buffer of the engine involved.  All three under `rocprofv3 --kernel-trace`
+// with several rank THREADS launching concurrently in one process; the same runs without the profiler, and every
+// multi-process run (one rank per process: the product's shape), have never failed.  Not an allocation of this engine:
+// the runtime's per-queue staging memory under the profiler's queue interception.  The gather buffer's regrow
+// (kernels_dd.hip ensure_gather) drains the device first all the same.
+__global__ __launch_bounds__(256) void k_msg_copy(void *__restrict__ dst, const void *__restrict__ src, size_t bytes) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t nvec = bytes / 16;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+    if (i < nvec) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+    const size_t tail = nvec * 16 + i;
+    if (i < bytes - nvec * 16) ((char *)dst)[tail] = ((const char *)src)[tail];
+  } else {                                           // unaligned (4-byte count messages): words, then bytes
+    const size_t nw = bytes / 4;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 3u) == 0) {
+      for (size_t k = i; k < nw; k += (size_t)gridDim.x * 256) ((unsigned *)dst)[k] = ((const unsigned *)src)[k];
+      const size_t tail = nw * 4 + i;
+      if (i < bytes - nw * 4) ((char *)dst)[tail] = ((const char *)src)[tail];
+    } else {
+      for (size_t k = i; k < bytes; k += (size_t)gridDim.x * 256) ((char *)dst)[k] = ((const char *)src)[k];
+    }
+  }
+}
+static void msg_copy(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  const size_t nvec = std::max<size_t>(bytes / 16, 1);
+  const unsigned grid = (unsigned)std::min<size_t>((nvec + 255) / 256, 65535u * 16u);
+  hipLaunchKernelGGL(k_msg_copy, dim3(std::max(grid, 1u)), dim3(256), 0, st, dst, src, bytes);
+}
 // one phase: post every send, serve every receive, then wait until the peers have taken the sends
 void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std::vector<Msg> &sends,
                     const std::vector<Msg> &recvs, double timeout_s) {
@@ -224,7 +257,7 @@ void local_exchange(LocalHub &h, int rank, hipStream_t st, bool host, const std:
       if (host) memcpy(m.dev, msg->ptr, m.bytes);
       else {
         HIP_CHECK(hipStreamWaitEvent(st, msg->ready, 0));
-        HIP_CHECK(hipMemcpyAsync(m.dev, msg->ptr, m.bytes, hipMemcpyDeviceToDevice, st));
+        msg_copy(m.dev, msg->ptr, m.bytes, st);
         msg->done = ring_event();
         HIP_CHECK(hipEventRecord(msg->done, st));
       }
@@ -413,7 +446,7 @@ void Comm::allgather(hipStream_t st, const void *send_dev, void *recv_dev, size_
   if (backend == LOCAL) {
     std::vector<Msg> ss, rr;
     for (int r = 0; r < world; r++) {
-      if (r == rank) { HIP_CHECK(hipMemcpyAsync((char *)recv_dev + (size_t)r * bytes, send_dev, bytes, hipMemcpyDeviceToDevice, st)); continue; }
+      if (r == rank) { msg_copy((char *)recv_dev + (size_t)r * bytes, send_dev, bytes, st); continue; }
       ss.push_back({const_cast<void *>(send_dev), bytes, r});
       rr.push_back({(char *)recv_dev + (size_t)r * bytes, bytes, r});
     }

@@ -290,9 +290,8 @@ static void ensure_gather(DeviceState &d, size_t doubles_per_rank, int world) {
   if (need > d.gather_cap) {
     // Regrow: no stream of this process may still touch the old buffer.  A peer rank that is a thread of this process copies
     // out of it on ITS stream (comm.cpp local_exchange); the sender's host has seen that copy enqueued (the acknowledgement)
-    // but not finished, so the whole device is drained before the buffer goes.  (The round-1 crash record
-    // gpurun_out/prof_ov2.log - hipMemcpyAsync <- local_exchange on a pointer HIP no longer knew as device memory - is what a
-    // free under such a copy looks like; this is the one buffer of a decomposed run that is re-allocated while a run is live.)
+    // but not finished, so the whole device is drained before the buffer goes: this is the one buffer of a decomposed run
+    // that is re-allocated while a run is live.  (The crash records of the in-process transport are not this: comm.cpp.)
     if (d.gather_send) { HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(d.gather_send); }
     HIP_CHECK(hipMalloc(&d.gather_send, need * sizeof(double)));
     d.gather_cap = need;
