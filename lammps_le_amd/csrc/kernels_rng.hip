@@ -306,7 +306,10 @@ static void rng_gen_batch(DeviceState &d, int pool, uint64_t base_raw, bool wait
     // been consumed, i.e. the main stream is past it: its `need` / `gen` words are free.  gen is written on the MAIN
     // stream, where the validation reads it (the batch itself runs on rng_stream for milliseconds).
     HIP_CHECK(hipMemsetAsync(need, 0, (size_t)d.rng_nseg * sizeof(int), d.stream));
-    const int m = d.n + d.nghost;
+    // (test hook LAMMPS_LE_TEST_RNG_NO_GHOST_MARK: owned beads only, so that every bead that migrates in misses its segment
+    //  and the validation + late generation path has to produce it)
+    const bool owned_only = getenv("LAMMPS_LE_TEST_RNG_NO_GHOST_MARK") != nullptr;      // (read per batch: tests share a process)
+    const int m = d.n + (owned_only ? 0 : d.nghost);
     hipLaunchKernelGGL(k_rng_mark, dim3(std::max(1, (m + 255) / 256)), dim3(256), 0, d.stream, m, d.tag,
                        d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, need);
     HIP_CHECK(hipMemcpyAsync(d.rng_gen[pool], need, (size_t)d.rng_nseg * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
