@@ -240,6 +240,7 @@ void launch_ke(DeviceState &d, const TypeTables &tt);
 // angle forces added to f (after launch_force); eflag: energy / virial thirds into partial_a (reduce_angle_partials)
 void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwrite = false);
 void launch_angle_list(DeviceState &d);       // at every reneighbor of a run with an angle style
+bool step_fuses_angles(const DeviceState &d, bool has_pair);
 void reduce_angle_partials(DeviceState &d, double *out8);
 // reductions: returns sums of `partial` columns on the host (synchronises the stream)
 void reduce_partials(DeviceState &d, double *out16);

@@ -750,6 +750,7 @@ void Engine::iterate(long nsteps) {
   // angles (semiflexible chains): a kernel of their own writes the angle forces right before the fused step
   // kernel, which adds them to its sums (one GPU; decomposed runs refuse angles)
   const bool ang = angles_active();
+  if (ang && !step_fuses_angles(d, pair_lj)) fusable = false;      // (no pair style: force kernel -> angle kernel -> integrate kernels)
   bool ident = d.ident_order;
   bool pre_integrated = false;
   // halo/compute overlap issues the per-step halo on a second stream.  With RCCL that means two streams feeding ONE

@@ -178,9 +178,6 @@ struct ForceArgs {
   // decomposed runs: border beads also write their new position into the halo send buffer (no pack launch per step)
   const int *sendslot;
   double4 *send_dn, *send_up;   // the staging buffer's two halves, or the neighbours' windows (kernels_dd.hip, fast halo)
-  // runs with an angle style: the angle forces of this step, written by k_angle<.., OVERWRITE> right before this launch
-  // into the (otherwise unused) force arrays; nullptr = no angles
-  const double *fang_x, *fang_y, *fang_z;
 };
 
 // reciprocal by v_rcp_f64 + two Newton steps (<= 1 ulp from the IEEE quotient 1/x; an IEEE divide is ~35 instructions)
@@ -505,7 +502,10 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
 // bonds one after the other: 10 us at 32k beads whatever the chip could stream).  Four lanes share a bead, each takes
 // every fourth list entry and every fourth bond slot, the partial forces meet in a two-step butterfly and lane 0
 // integrates: the chain shrinks to one or two stages.
-template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD>
+// ANG: runs with an angle style - the angle forces of this step were written into fx / fy / fz by k_angle<.., OVERWRITE>
+// right before this launch and are added to the bead's sums (a template parameter, not a run-time test: the step kernel's
+// schedule is sensitive - a pointer test here cost every run 2 us per launch)
+template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG = false>
 __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
                                                 const int *__restrict__ tag, const int *__restrict__ crank,
                                                 const uint32_t *__restrict__ draws, double *__restrict__ vx,
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
     for (int o = 1; o < LPB; o <<= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); }
     if (sub) return;
   }
-  if (A.fang_x) { f0 += A.fang_x[p]; f1 += A.fang_y[p]; f2 += A.fang_z[p]; }     // (wave-uniform) Angle::compute follows Bond::compute
+  if (ANG) { f0 += fx[p]; f1 += fy[p]; f2 += fz[p]; }     // Angle::compute follows Bond::compute
   const int type = (int)ri.w;
   if (LANGEVIN) {
     double gamma1 = tt.g1[type], gamma2 = tt.g2[type];
@@ -673,7 +673,6 @@ static ForceArgs force_args(DeviceState &d, const double sl[4]) {
   A.maxrow = d.maxneigh - 1;
   A.diag = 0;
   A.sendslot = nullptr; A.send_dn = A.send_up = nullptr;
-  A.fang_x = A.fang_y = A.fang_z = nullptr;
   {
     // posf = (float)xhold: a coordinate is off by <= M * 2^-24, a squared displacement d^2 <= skin^2/4 .. by
     // <= 2 * sqrt(3) * |d| * e + 3 e^2; |d| <= ~skin near the threshold.  Band = four times that bound.
@@ -718,7 +717,6 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
                  hipEvent_t ev_stop, int which, bool swap_buffers, bool angle_forces) {
   ForceArgs A = force_args(d, sl);
-  if (angle_forces) { A.fang_x = d.f[0]; A.fang_y = d.f[1]; A.fang_z = d.f[2]; }
   if (d.dd && next && d.sendslot && !d.sendslot_fallback) {
     A.sendslot = d.sendslot;
     if (d.fast_halo && d.direct_recv && which < 0) {
@@ -737,7 +735,8 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   // lanes per bead: 4 while the launch is latency-bound (few wavefronts per SIMD), 1 once it is throughput-bound
   static const int lpb_env = getenv("LAMMPS_LE_LPB") ? atoi(getenv("LAMMPS_LE_LPB")) : 0;
   static const int lpb_max_n = getenv("LAMMPS_LE_LPB_MAX_N") ? atoi(getenv("LAMMPS_LE_LPB_MAX_N")) : LPB4_MAX_BEADS;
-  const bool lpb4 = lpb_env ? lpb_env == 4 : d.n <= lpb_max_n;
+  const bool lpb4 = (lpb_env ? lpb_env == 4 : d.n <= lpb_max_n) && !angle_forces;     // (angle runs: one lane per bead, see step_fuses_angles)
+  if (angle_forces && !has_pair) throw LammpsError("internal: fused angle step without a pair style");
   static const int ahead_max_n = getenv("LAMMPS_LE_AHEAD_MAX_N") ? atoi(getenv("LAMMPS_LE_AHEAD_MAX_N")) : AHEAD_MAX_BEADS;
   const bool ahead = d.n <= ahead_max_n;
   // diagnostics only (LAMMPS_LE_STEP_LDS_PAD=bytes): unused dynamic LDS per workgroup, to lower the occupancy on purpose
@@ -757,11 +756,13 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   int grid = xcd_grid(A.nblocks);
   // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
   // the same clock rocprofv3 --kernel-trace reports
-#define STPL(L, N, I, P, W, D, H)                                                                            \
-  hipExtLaunchKernelGGL((k_step<L, N, I, P, W, D, H>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, ev_start, ev_stop, 0, A, bt, \
+#define STPL(L, N, I, P, W, D, H) STPA(L, N, I, P, W, D, H, false)
+#define STPA(L, N, I, P, W, D, H, G)                                                                         \
+  hipExtLaunchKernelGGL((k_step<L, N, I, P, W, D, H, G>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, ev_start, ev_stop, 0, A, bt, \
                         d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],    \
                         d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which)
-#define STP(L, N, I, P) do { if (lpb4) STPL(L, N, I, P, 4, false, true); else if (ahead) STPL(L, N, I, P, 1, false, true); else STPL(L, N, I, P, 1, false, false); } while (0)
+#define STP(L, N, I, P) do { if (angle_forces) { if (ahead) STPA(L, N, I, true, 1, false, true, true); else STPA(L, N, I, true, 1, false, false, true); } \
+    else if (lpb4) STPL(L, N, I, P, 4, false, true); else if (ahead) STPL(L, N, I, P, 1, false, true); else STPL(L, N, I, P, 1, false, false); } while (0)
   int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
   // LAMMPS_LE_DIAG_STEP=bits: the same kernel is launched once more BEFORE the real launch with parts switched off
   // (1 bonds, 2 pair loop, 4 draws, 8 pair gathers replaced by coalesced loads, 128 nothing); it writes only the second position buffer, which the real launch
@@ -787,6 +788,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   }
 #undef STP
 #undef STPL
+#undef STPA
   if (next && swap_buffers) std::swap(d.pos, d.pos_tmp);
 }
 
@@ -970,6 +972,9 @@ void reduce_angle_partials(DeviceState &d, double *out8) {
   for (int k = 0; k < 8; k++) out8[k] = 0.0;
   for (int b = 0; b < nb; b++) for (int k = 0; k < 8; k++) out8[k] += h[(size_t)b * 8 + k];
 }
+
+// can the fused step kernel take the angle forces of a run (launch_step's angle_forces)?  Needs the pair-style instantiations
+bool step_fuses_angles(const DeviceState &d, bool has_pair) { return has_pair && !d.dd; }
 
 // sum the per-block partials on the host in block order (deterministic)
 void reduce_partials(DeviceState &d, double *out16) {
