@@ -75,8 +75,8 @@ WORKLOADS = {
     "walk1m": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
     "walk100k": (100000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
     "walk8m": (8000000, 1, 200, 1000, 1000, 0.01, 0.5, "walk", 0.01),        # chain8m from the scrambled start (the one that survives long runs)
-    # semiflexible chain: walk1m + angle_style cosine on every backbone triple, ex_load ... atype 2.  Takes the
-    # unfused step (force kernel, angle kernel, Langevin / integrate kernels), so `roofline` is not reported for it
+    # semiflexible chain: walk1m + angle_style cosine on every backbone triple, ex_load ... atype 2 (the angle
+    # kernel writes its forces right before the fused step kernel, which adds them: `roofline` is that variant of k_step)
     "walk1m_angles": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
 }
 
@@ -246,7 +246,9 @@ def main():
         bad = max_over_ranks(lmp.stat("halo_window_mismatches"))
         os.environ["LAMMPS_LE_FAST_HALO_VERIFY"] = "0"
         if used > 0 and bad == 0:
-            halo_mode = "peer windows (verified against the transport over %d exchanges of the pre-roll)" % int(used)
+            halo_mode = "peer windows, %s (verified against the transport over %d exchanges of the pre-roll)" % (
+                "one launch per exchange" if lmp.stat("halo_fused") else "counter kernel + copy kernel (a neighbour shares this GPU)",
+                int(used))
         else:
             os.environ["LAMMPS_LE_FAST_HALO"] = "0"
             halo_mode = "rccl (peer windows %s)" % ("not available" if used <= 0 else "REJECTED: %d values differed" % int(bad))

@@ -179,6 +179,8 @@ struct DeviceState {
   double slab_lo = 0.0, slab_hi = 0.0, cutghost = 0.0, zlo_ext = 0.0;
   int *gcell_start = nullptr, *gcell_count = nullptr;   // ghost ranges per cell (relative to n)
   int *sendlist[2] = {nullptr, nullptr};                // owned indices sent down / up every step
+  int *sendlist_alt[2] = {nullptr, nullptr};            // ... and the buffers the next rebuild writes its reordered lists into
+  bool map_stale = true;                                // map[] was not left by a decomposed rebuild: fill it before the next one
   int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
   double4 *sendbuf = nullptr, *recvbuf = nullptr;       // halo staging
   int *gone = nullptr;                                  // [npad] 1 = this bead has just left for another slab
@@ -199,6 +201,7 @@ struct DeviceState {
   // store the new positions of their border beads straight into it, in this rank's sorted ghost order.
   double4 *halo_win = nullptr;
   unsigned *halo_flag = nullptr;                        // [2] arrival counters: [0] written by the rank below, [1] by the rank above
+  bool halo_fused = false;                              // counters + window copy in one launch (every neighbour is another GPU)
   size_t halo_cap = 0;
   double4 *peer_win[2] = {nullptr, nullptr};            // the windows of the rank below / above
   unsigned *peer_flag[2] = {nullptr, nullptr};          // ... and the counter of theirs that is mine to write
@@ -247,7 +250,9 @@ void reduce_partials(DeviceState &d, double *out16);
 
 // neighbor (kernels_neigh.hip)
 void launch_reneighbor(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
-void launch_sort_owned(DeviceState &d, int m_in = -1, int n_out = -1, const int *gone = nullptr);
+// (`binned`: cell, arrival order and counts of the m_in slots are in place - the decomposed rebuild's migration pass)
+void launch_sort_owned(DeviceState &d, int m_in = -1, int n_out = -1, const int *gone = nullptr, bool binned = false);
+void scan_cells(DeviceState &d, int *count, int *start, int nc, int total);   // start[0..nc] := exclusive scan of count[0..nc), count := 0
 void launch_lists(DeviceState &d, double cutneighsq, const double special_lj[4], bool has_pair);
 
 // Atom::sort emulation (kernels_sort.hip): crank[tag] := rank in the reference's sorted local order
@@ -262,6 +267,22 @@ void rng_langevin_consumed(DeviceState &d);
 // pools hold the draws of every owned bead?  Enqueues the check; rng_late_generate() (after the flags reached the host)
 // produces what was missing before the next step consumes it
 void rng_validate_owned(DeviceState &d);
+// the same check as kernel arguments, for a kernel that walks the owned beads anyway (late == nullptr: nothing to check)
+struct RngValidateArgs {
+  const int *crank;
+  long long seglen;
+  int nseg;
+  const int *gen0, *gen1;
+  int live0, live1;
+  int *late;
+};
+RngValidateArgs rng_validate_args(DeviceState &d);
+__device__ __forceinline__ void rng_validate_bead(const RngValidateArgs &V, int t, int *__restrict__ flags) {
+  const long long r = V.crank ? V.crank[t] : t - 1;
+  const int sg = (int)((3 * r) / V.seglen);
+  if (V.live0 && !V.gen0[sg]) { V.late[sg] = 1; flags[FLAG_RNG_MISS] = 1; }
+  if (V.live1 && !V.gen1[sg]) { V.late[V.nseg + sg] = 1; flags[FLAG_RNG_MISS] = 1; }
+}
 void rng_late_generate(DeviceState &d);
 int rng_segments_held(DeviceState &d);
 void launch_ranmars_gen(DeviceState &d, int slot, const int *count_ptr, uint32_t *out, int maxout);

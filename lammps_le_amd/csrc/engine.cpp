@@ -432,7 +432,8 @@ void Engine::reneighbor(bool defer_check) {
   // FLAG_MOVED / NEIGH_OVERFLOW / MAXNEIGH are zero here: they are reset by the publish kernel that reports them
   if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);
   else launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
-  if (d.dd) rng_validate_owned(d);               // beads that migrated in: are their Langevin draws in this rank's pools?
+  // (decomposed: the border pass of the rebuild has also checked that this rank's Langevin pools hold the draws of the beads
+  //  it owns now - FLAG_RNG_MISS, kernels_dd.hip k_dd_borders)
   if (defer_check && !d.dd) {
     publish_flags(d, 1u << FLAG_MOVED);          // NEIGH_OVERFLOW stays set on the device: the step kernel reads it
     reneigh_pending = true;

@@ -11,6 +11,9 @@
 //   * migration and ghost lists are rebuilt at reneighbor time on the device (flag + scan + scatter).
 #include <unistd.h>
 
+#include <cstring>
+
+#include "bin_inl.h"
 #include "comm.h"
 #include "device.h"
 
@@ -21,7 +24,6 @@ constexpr int MIG_W = 12;    // doubles per migrating bead: x y z type vx vy vz 
 constexpr int GATH_W = 14;   // doubles per bead in whole-system gathers: tag x y z type vx vy vz fx fy fz ix iy iz
 constexpr int GATH_LE_W = 8; // ... of the LE fixes' firing-step gather: tag x y z type xhold[3]
 
-void scan_exclusive(DeviceState &d, const int *in, int *out, int m, int total_flag);   // kernels_le.hip
 void dd_halo_wait(DeviceState &d);
 
 // signed z offset from the bottom of my slab, wrapped to [-Lz/2, Lz/2)
@@ -44,17 +46,27 @@ __device__ __forceinline__ int wave_append(bool pred, int *__restrict__ counter)
 
 // ---- migration: wrap owned beads (Domain::pbc, src/domain.cpp:528-645); a bead whose slab is no longer mine is
 // packed for the lower / upper neighbour (slots from wave-aggregated atomics: leavers are few) and marked `gone`.
-// Kept beads are not moved here: the cell sort that follows bins `gone` beads into a sentinel cell behind all real
-// cells, which compacts the arrays for free.  counters: flags[COUNT_B] = sent down, [NDRAW] = sent up.
-__global__ __launch_bounds__(BLOCK) void k_dd_leave(int n, int npad, int migcap, Box box, double slab_lo, double width,
+// Kept beads are not moved here: they are binned (cell, arrival order, counts) for the cell sort that follows, the
+// `gone` ones into a sentinel cell behind all real cells, which compacts the arrays for free.  The same pass takes the
+// tags of every slot this rank held - owned and ghost - out of map[]: what the rebuild then puts back (k_permute the owned
+// beads, k_dd_ghost_place the ghosts) is exactly the new set, without a fill of the whole tag range per rebuild.
+// counters: flags[COUNT_B] = sent down, [NDRAW] = sent up.
+struct BinArgs {
+  int ncx, ncy, ncz;
+  double cix, ciy, ciz, zlo_ext;
+  int *cell_of, *cell_count, *rank;
+  int sentinel;
+};
+__global__ __launch_bounds__(BLOCK) void k_dd_leave(int n, int nslots, int npad, int migcap, Box box, double slab_lo, double width,
                                                     int me, int P, double4 *__restrict__ pos,
                                                     const double *__restrict__ vx, const double *__restrict__ vy,
                                                     const double *__restrict__ vz, const int *__restrict__ tag,
                                                     int *__restrict__ img, double *__restrict__ mig_dn,
                                                     double *__restrict__ mig_up, int *__restrict__ gone,
-                                                    int *__restrict__ flags) {
+                                                    int *__restrict__ map, BinArgs B, int *__restrict__ flags) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   bool active = p < n;
+  if (p < nslots) map[tag[p]] = -1;
   double4 r = pos[active ? p : 0];
   int im[3] = {0, 0, 0};
   bool godn = false, goup = false;
@@ -82,6 +94,11 @@ __global__ __launch_bounds__(BLOCK) void k_dd_leave(int n, int npad, int migcap,
       goup = owner != me && zc >= 0.0;
     }
     gone[p] = (godn || goup) ? 1 : 0;
+    // (active lanes are a prefix of the wavefront, as count_into_cell asks)
+    int cell = bad ? 0 : cell_index(r, box, B.ncx, B.ncy, B.ncz, B.cix, B.ciy, B.ciz, B.zlo_ext, 0);
+    if (godn || goup) cell = B.sentinel;
+    B.cell_of[p] = cell;
+    B.rank[p] = count_into_cell(cell, B.cell_count);
   }
   int sd = wave_append(godn, &flags[FLAG_COUNT_B]);
   int su = wave_append(goup, &flags[FLAG_NDRAW]);
@@ -98,16 +115,20 @@ __global__ __launch_bounds__(BLOCK) void k_dd_arrive(int narr, int base, int npa
                                                      double4 *__restrict__ pos, double *__restrict__ vx,
                                                      double *__restrict__ vy, double *__restrict__ vz,
                                                      int *__restrict__ tag, int *__restrict__ img,
-                                                     int *__restrict__ gone) {
+                                                     int *__restrict__ gone, Box box, BinArgs B) {
   int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= narr) return;
   gone[base + i] = 0;
   const double *b = in + (size_t)i * MIG_W;
   int s = base + i;
-  pos[s] = make_double4(b[0], b[1], b[2], b[3]);
+  const double4 r = make_double4(b[0], b[1], b[2], b[3]);     // (wrapped by its sender)
+  pos[s] = r;
   vx[s] = b[4]; vy[s] = b[5]; vz[s] = b[6];
   tag[s] = (int)b[7];
   img[s] = (int)b[8]; img[npad + s] = (int)b[9]; img[2 * npad + s] = (int)b[10];
+  const int cell = cell_index(r, box, B.ncx, B.ncy, B.ncz, B.cix, B.ciy, B.ciz, B.zlo_ext, 0);
+  B.cell_of[s] = cell;
+  B.rank[s] = count_into_cell(cell, B.cell_count);
 }
 
 // ---- borders (after the cell sort): the send lists hold (a) every owned bead within the PAIR shell (rc + skin) of
@@ -123,9 +144,11 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
                                                       const int *__restrict__ num_bond,
                                                       const int *__restrict__ bond_atom, int *__restrict__ list_dn,
                                                       int *__restrict__ list_up, int *__restrict__ flags,
-                                                      unsigned char *__restrict__ phase, int *__restrict__ sendslot) {
+                                                      unsigned char *__restrict__ phase, int *__restrict__ sendslot,
+                                                      RngValidateArgs V) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   bool active = p < n;
+  if (active && V.late) rng_validate_bead(V, tag[p], flags);      // do this rank's pools hold the draws of what it owns now?
   double zc = active ? zrel_slab(pos[p].z, slab_lo, box) : 0.0;
   bool dn = active && zc < cutpair, up = active && zc >= width - cutpair;
   bool far_dn = active && !dn && zc < cutghost, far_up = active && !up && zc >= width - cutghost;
@@ -155,11 +178,16 @@ __global__ __launch_bounds__(BLOCK) void k_dd_pack(int m0, int m1, const int *__
   int i = blockIdx.x * BLOCK + threadIdx.x;
   if (i < m0 + m1) out[i] = pos[i < m0 ? list0[i] : list1[i - m0]];
 }
-__global__ __launch_bounds__(BLOCK) void k_dd_pack_tags(int m0, int m1, const int *__restrict__ list0,
-                                                        const int *__restrict__ list1, const int *__restrict__ tag,
-                                                        int *__restrict__ out) {
+// the first exchange after a rebuild: positions and tags of both send lists
+__global__ __launch_bounds__(BLOCK) void k_dd_pack_xt(int m0, int m1, const int *__restrict__ list0,
+                                                      const int *__restrict__ list1, const double4 *__restrict__ pos,
+                                                      const int *__restrict__ tag, double4 *__restrict__ out,
+                                                      int *__restrict__ out_tag) {
   int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i < m0 + m1) out[i] = tag[i < m0 ? list0[i] : list1[i - m0]];
+  if (i >= m0 + m1) return;
+  const int p = i < m0 ? list0[i] : list1[i - m0];
+  out[i] = pos[p];
+  out_tag[i] = tag[p];
 }
 __global__ __launch_bounds__(BLOCK) void k_dd_unpack(int m, int base, const int *__restrict__ gdest,
                                                      const double4 *__restrict__ in, double4 *__restrict__ pos) {
@@ -202,11 +230,16 @@ __global__ __launch_bounds__(BLOCK) void k_dd_ghost_sort(int ncells, const int *
     perm[j + 1] = pi;
   }
 }
-__global__ __launch_bounds__(BLOCK) void k_dd_ghost_place(int m, int base, const int *__restrict__ perm,
+// The ghosts that came from below fill the low z layers of the local grid and those from above the high ones, so
+// the cell-sorted ghost array is [from below | from above].  Each sender is told where its k-th border bead ended up
+// inside its block (`rel`); it then reorders its send list accordingly, and from then on a halo message is received
+// STRAIGHT into the ghost slots: no unpack kernel per step.  arrival layout of the first exchange: [above | below].
+__global__ __launch_bounds__(BLOCK) void k_dd_ghost_place(int m, int base, int nabove, int nbelow, const int *__restrict__ perm,
                                                           const double4 *__restrict__ in, const int *__restrict__ tag_in,
                                                           double4 *__restrict__ pos, int *__restrict__ tag,
                                                           int *__restrict__ gdest, int *__restrict__ map,
-                                                          float4 *__restrict__ posf) {
+                                                          float4 *__restrict__ posf, int *__restrict__ rel,
+                                                          int *__restrict__ flags) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= m) return;
   int i = perm[s];
@@ -217,20 +250,12 @@ __global__ __launch_bounds__(BLOCK) void k_dd_ghost_place(int m, int base, const
   tag[base + s] = t;
   gdest[i] = s;
   map[t] = base + s;
-}
-// The ghosts that came from below fill the low z layers of the local grid and those from above the high ones, so
-// the cell-sorted ghost array is [from below | from above].  Each sender is told where its k-th border bead ended up
-// inside its block (`rel`); it then reorders its send list accordingly, and from then on a halo message is received
-// STRAIGHT into the ghost slots: no unpack kernel per step.  arrival layout of the first exchange: [above | below].
-__global__ __launch_bounds__(BLOCK) void k_dd_ghost_rel(int m, int nabove, int nbelow, const int *__restrict__ gdest,
-                                                        int *__restrict__ rel, int *__restrict__ flags) {
-  int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= m) return;
-  int s = gdest[i];
-  bool above = i < nabove;                     // arrival block
-  int r = above ? s - nbelow : s;               // slot inside its sorted block
-  if (r < 0 || r >= (above ? nabove : nbelow)) { flags[FLAG_ERROR] = ERR_GHOST_ORDER; r = 0; }
-  rel[i] = r;
+  if (rel) {
+    const bool above = i < nabove;               // arrival block
+    int q = above ? s - nbelow : s;              // slot inside its sorted block
+    if (q < 0 || q >= (above ? nabove : nbelow)) { flags[FLAG_ERROR] = ERR_GHOST_ORDER; q = 0; }
+    rel[i] = q;
+  }
 }
 __global__ __launch_bounds__(BLOCK) void k_dd_reorder_sends(int m0, int m1, const int *__restrict__ rel,
                                                             const int *__restrict__ list0, const int *__restrict__ list1,
@@ -303,9 +328,10 @@ static void ensure_gather(DeviceState &d, size_t doubles_per_rank, int world) {
 // Fast halo: the per-step forward communication (CommBrick::forward_comm, src/comm_brick.cpp:452-512) without a transport
 // call.  A grouped RCCL exchange costs ~25 us per step against a ~12 us step kernel at 125k beads per GPU; here the step
 // kernel of a rank stores the new positions of its border beads straight into the neighbours' windows (peer memory over
-// xGMI, mapped once per allocation through hipIpcOpenMemHandle), and what is left per step is one single-wavefront kernel
+// xGMI, mapped once per allocation through hipIpcOpenMemHandle), and what is left per step is a single-wavefront kernel
 // that publishes "my stores are complete" to both neighbours and waits for theirs, plus the copy of the window into the
-// ghost slots.  Protocol, per rank and exchange number s (parity s & 1; all ranks count the same exchanges):
+// ghost slots - one launch for both when every neighbour is another GPU (k_halo_exchange_win).
+// Protocol, per rank and exchange number s (parity s & 1; all ranks count the same exchanges):
 //   step kernel:  stores into the neighbours' window[s & 1]                     (it follows this rank's unpack of s - 1)
 //   k_halo_sync:  release-store s into my counter at each neighbour, then spin until both of my counters reach s
 //   unpack:       window[s & 1] -> ghost slots
@@ -344,6 +370,46 @@ __global__ __launch_bounds__(BLOCK) void k_halo_unpack_win(int n0, int n1, const
   if (corrupt && i == 0) r.x += 0.25;      // test hook (LAMMPS_LE_TEST_HALO_CORRUPT): the verify mode must notice and repair
   ghost[i] = r;
 }
+// The same in ONE launch (ranks on different GPUs): block 0 publishes, every block waits for the two counters itself (polls of
+// two uncached words) and then copies its part of the window.  Not used when a neighbour shares this GPU (one-GPU rehearsals):
+// there a grid of waiting workgroups holds up the very kernels it waits for (measured, 4 ranks on one GPU: 55 us per
+// exchange against 13 + 8 us for the two launches above).
+__global__ __launch_bounds__(BLOCK) void k_halo_exchange_win(unsigned *__restrict__ to_dn, unsigned *__restrict__ to_up,
+                                                             const unsigned *__restrict__ mine, unsigned seq,
+                                                             long long timeout_ticks, int *__restrict__ flags, int n0, int n1,
+                                                             const double4 *__restrict__ from_below,
+                                                             const double4 *__restrict__ from_above,
+                                                             double4 *__restrict__ ghost, int corrupt) {
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) {
+      __threadfence_system();
+      __hip_atomic_store(to_dn, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(to_up, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    int ok = 1;
+    const long long t0 = wall_clock64();
+    for (int side = 0; side < 2 && ok; side++)
+      while ((int)(__hip_atomic_load(mine + side, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > timeout_ticks) { flags[FLAG_ERROR] = ERR_HALO_TIMEOUT; ok = 0; break; }
+      }
+    s_ok = ok;
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n0 + n1) return;
+  const unsigned long long *src = (const unsigned long long *)(i < n0 ? from_below + i : from_above + (i - n0));
+  unsigned long long w[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) w[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  double4 r;
+  r.x = __longlong_as_double((long long)w[0]); r.y = __longlong_as_double((long long)w[1]);
+  r.z = __longlong_as_double((long long)w[2]); r.w = __longlong_as_double((long long)w[3]);
+  if (corrupt && i == 0) r.x += 0.25;      // test hook (LAMMPS_LE_TEST_HALO_CORRUPT): the verify mode must notice and repair
+  ghost[i] = r;
+}
 
 // LAMMPS_LE_FAST_HALO_VERIFY=1: the same halo once more through the transport; differences are counted and the transport's
 // copy wins (a first multi-GPU run checks the windows against RCCL for as long as it likes before it relies on them)
@@ -362,6 +428,7 @@ struct PeerInfo {
   unsigned long long raw;        // the window's address in its owner's address space (ranks that are threads of one process)
   int exported;
   int pad;
+  char busid[32];                // PCI bus id of the rank's GPU: a neighbour on MY GPU means a one-GPU rehearsal
   hipIpcMemHandle_t handle;
 };
 static size_t halo_flag_offset(size_t cap) { return 4 * cap * sizeof(double4); }
@@ -422,6 +489,11 @@ void dd_fast_halo_setup(DeviceState &d, Comm &comm) {
     HIP_CHECK(hipMemset(d.halo_win, 0, bytes));
     HIP_CHECK(hipStreamSynchronize(nullptr));
     d.halo_flag = (unsigned *)((char *)d.halo_win + halo_flag_offset(d.halo_cap));
+    {
+      int dev = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      if (hipDeviceGetPCIBusId(mine.busid, (int)sizeof mine.busid, dev) != hipSuccess) { (void)hipGetLastError(); mine.busid[0] = 0; }
+    }
     mine.pid = (long long)getpid();
     mine.raw = (unsigned long long)(uintptr_t)d.halo_win;
     mine.exported = hipIpcGetMemHandle(&mine.handle, d.halo_win) == hipSuccess ? 1 : 0;
@@ -449,6 +521,16 @@ void dd_fast_halo_setup(DeviceState &d, Comm &comm) {
   }
   bad = comm.allreduce_host_max(bad);           // all ranks or none
   if (bad) { dd_fast_halo_free(d); return; }
+  // one launch per exchange when no neighbour shares this GPU (LAMMPS_LE_HALO_FUSED=0 / 1 overrides: tests run the fused
+  // kernel between processes on one GPU)
+  long shared = 0;
+  for (int k = 0; k < 2; k++) {
+    const PeerInfo &pi = all[(size_t)nbr[k]];
+    if (!mine.busid[0] || !pi.busid[0] || strncmp(mine.busid, pi.busid, sizeof mine.busid) == 0) shared = 1;
+  }
+  shared = comm.allreduce_host_max(shared);
+  const char *fz = getenv("LAMMPS_LE_HALO_FUSED");
+  d.halo_fused = fz ? atoi(fz) != 0 : !shared;
   d.halo_timeout_s = comm.timeout_s;
   d.halo_mapped = true;
   dd_fast_halo_switch(d);
@@ -465,7 +547,8 @@ void dd_alloc(DeviceState &d, int world) {
   };
   al(d.gcell_start, ((size_t)d.ncells + 2) * sizeof(int));
   al(d.gcell_count, ((size_t)d.ncells + 2) * sizeof(int));
-  for (int k = 0; k < 2; k++) { al(d.sendlist[k], np * sizeof(int)); al(d.migbuf[k], np * MIG_W * sizeof(double) / 4 + 1024); }
+  for (int k = 0; k < 2; k++) { al(d.sendlist[k], np * sizeof(int)); al(d.sendlist_alt[k], np * sizeof(int)); al(d.migbuf[k], np * MIG_W * sizeof(double) / 4 + 1024); }
+  d.map_stale = true;
   al(d.migin, np * MIG_W * sizeof(double) / 2 + 1024);
   al(d.sendbuf, np * sizeof(double4));
   al(d.recvbuf, np * sizeof(double4));
@@ -501,10 +584,20 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
                   {{d.flags + FLAG_RECV_UP, sizeof(int), up_rank}, {d.flags + FLAG_RECV_DN, sizeof(int), dn_rank}});
     sync_flags(d, counters);     // published, then zeroed for the next phase
   };
-  // ---- 1. migration ----
+  // ---- 1. migration (+ binning of what stays, + the old slots' tags out of map[]) ----
   HIP_CHECK(hipMemsetAsync(d.flags + FLAG_COUNT_A, 0, 4 * sizeof(int), st));   // COUNT_A, COUNT_B, NDRAW, NLIST
-  hipLaunchKernelGGL(k_dd_leave, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, migcap, d.box, d.slab_lo, width, me, P, d.pos,
-                     d.v[0], d.v[1], d.v[2], d.tag, d.img, d.migbuf[0], d.migbuf[1], d.gone, d.flags);
+  if (d.map_stale) {      // first rebuild on freshly uploaded arrays: map[] may hold anything
+    hipLaunchKernelGGL(k_fill_int, dim3((d.maxtag + 2 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.maxtag + 2, d.map, -1);
+    d.map_stale = false;
+  }
+  if (d.cell_count_dirty) { HIP_CHECK(hipMemsetAsync(d.cell_count, 0, ((size_t)d.ncells + 2) * sizeof(int), st)); d.cell_count_dirty = false; }
+  const BinArgs BA{d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of, d.cell_count,
+                   d.tag_tmp, d.ncells};
+  {
+    const int nslots = n + d.nghost, gl = std::max(1, (nslots + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_dd_leave, dim3(gl), dim3(BLOCK), 0, st, n, nslots, d.npad, migcap, d.box, d.slab_lo, width, me, P, d.pos,
+                       d.v[0], d.v[1], d.v[2], d.tag, d.img, d.migbuf[0], d.migbuf[1], d.gone, d.map, BA, d.flags);
+  }
   swap_counts(FLAG_COUNT_B, FLAG_NDRAW);      // what I send down arrives as the lower rank's "from above"
   int ndn = d.flags_h[FLAG_COUNT_B], nup = d.flags_h[FLAG_NDRAW];
   int recvc[2] = {d.flags_h[FLAG_RECV_DN], d.flags_h[FLAG_RECV_UP]};   // [0] from below (their up), [1] from above
@@ -520,16 +613,15 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   if (n + narr > d.npad - 64) throw LammpsError("slab overflow: more beads than the allocation of this rank");
   if (narr)
     hipLaunchKernelGGL(k_dd_arrive, dim3((narr + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, narr, n, d.npad, d.migin,
-                       d.pos, d.v[0], d.v[1], d.v[2], d.tag, d.img, d.gone);
-  // ---- 2. map reset, cell sort of kept + arrived beads (sets map for them; the gone ones drop off the end) ----
-  hipLaunchKernelGGL(k_fill_int, dim3((d.maxtag + 2 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.maxtag + 2, d.map, -1);
-  launch_sort_owned(d, n + narr, n + narr - ndn - nup, d.gone);
+                       d.pos, d.v[0], d.v[1], d.v[2], d.tag, d.img, d.gone, d.box, BA);
+  // ---- 2. cell sort of kept + arrived beads (sets map for them; the gone ones drop off the end) ----
+  launch_sort_owned(d, n + narr, n + narr - ndn - nup, d.gone, true);
   d.n = n = n + narr - ndn - nup;
   nb = std::max(1, (n + BLOCK - 1) / BLOCK);
   // ---- 3. borders ----
   hipLaunchKernelGGL(k_dd_borders, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width,
                      std::min(sqrt(cutneighsq), d.cutghost), d.cutghost, d.bpa, d.tag, d.map, d.num_bond, d.bond_atom,
-                     d.sendlist[0], d.sendlist[1], d.flags, d.phase, d.sendslot);
+                     d.sendlist[0], d.sendlist[1], d.flags, d.phase, d.sendslot, rng_validate_args(d));
   swap_counts(FLAG_COUNT_A, FLAG_COUNT_B);
   d.nsend[0] = d.flags_h[FLAG_COUNT_A];
   d.nsend[1] = d.flags_h[FLAG_COUNT_B];
@@ -541,13 +633,9 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   // first exchange: positions and tags (arrival order: from above first, then from below — same as every step)
   int *tagsend = d.le_i[6], *tagrecv = d.gtag_in;
   int nsall = d.nsend[0] + d.nsend[1];
-  if (nsall) {
-    int g = (nsall + BLOCK - 1) / BLOCK;
-    hipLaunchKernelGGL(k_dd_pack, dim3(g), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1], d.sendlist[0], d.sendlist[1], d.pos,
-                       d.sendbuf);
-    hipLaunchKernelGGL(k_dd_pack_tags, dim3(g), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1], d.sendlist[0], d.sendlist[1],
-                       d.tag, tagsend);
-  }
+  if (nsall)
+    hipLaunchKernelGGL(k_dd_pack_xt, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1], d.sendlist[0],
+                       d.sendlist[1], d.pos, d.tag, d.sendbuf, tagsend);
   comm.exchange(st, {{d.sendbuf, (size_t)d.nsend[0] * sizeof(double4), dn_rank},
                      {d.sendbuf + d.nsend[0], (size_t)d.nsend[1] * sizeof(double4), up_rank},
                      {tagsend, (size_t)d.nsend[0] * sizeof(int), dn_rank},
@@ -556,27 +644,25 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
                  {d.recvbuf + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(double4), dn_rank},
                  {tagrecv, (size_t)d.nrecv[1] * sizeof(int), up_rank},
                  {tagrecv + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(int), dn_rank}});
-  // ---- 4. ghosts into cell order behind the owned beads ----
+  // ---- 4. ghosts into cell order behind the owned beads (the scan leaves the counts at zero for the next rebuild) ----
   int m = d.nghost, gb = std::max(1, (m + BLOCK - 1) / BLOCK);
-  HIP_CHECK(hipMemsetAsync(d.gcell_count, 0, ((size_t)d.ncells + 1) * sizeof(int), st));
   int *gcell_of = d.le_i[7], *grank = d.le_i[8], *gperm = d.le_i[9];
+  static const bool no_direct = getenv("LAMMPS_LE_NO_DIRECT_RECV") != nullptr;
+  int *rel_out = d.le_i[10], *rel_in = d.le_i[11];
   if (m)
     hipLaunchKernelGGL(k_dd_ghost_bin, dim3(gb), dim3(BLOCK), 0, st, m, d.recvbuf, d.box, d.ncell[0], d.ncell[1],
                        d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, gcell_of, d.gcell_count, grank);
-  scan_exclusive(d, d.gcell_count, d.gcell_start, d.ncells + 1, FLAG_AUX);
+  scan_cells(d, d.gcell_count, d.gcell_start, d.ncells, m);
   if (m) {
     hipLaunchKernelGGL(k_dd_ghost_slot, dim3(gb), dim3(BLOCK), 0, st, m, gcell_of, d.gcell_start, grank, gperm);
     hipLaunchKernelGGL(k_dd_ghost_sort, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells, d.gcell_start,
                        gperm, tagrecv);
-    hipLaunchKernelGGL(k_dd_ghost_place, dim3(gb), dim3(BLOCK), 0, st, m, n, gperm, d.recvbuf, tagrecv, d.pos, d.tag,
-                       d.gdest, d.map, d.posf);
+    hipLaunchKernelGGL(k_dd_ghost_place, dim3(gb), dim3(BLOCK), 0, st, m, n, d.nrecv[1], d.nrecv[0], gperm, d.recvbuf, tagrecv,
+                       d.pos, d.tag, d.gdest, d.map, d.posf, no_direct ? (int *)nullptr : rel_out, d.flags);
   }
   // ---- 4b. tell the senders the sorted order of what they sent; they reorder their lists (direct receive from now on)
   d.direct_recv = false;
-  static const bool no_direct = getenv("LAMMPS_LE_NO_DIRECT_RECV") != nullptr;
   if (!no_direct) {
-    int *rel_out = d.le_i[10], *rel_in = d.le_i[11];
-    if (m) hipLaunchKernelGGL(k_dd_ghost_rel, dim3(gb), dim3(BLOCK), 0, st, m, d.nrecv[1], d.nrecv[0], d.gdest, rel_out, d.flags);
     // my "from above" block came from up_rank's lower list, my "from below" block from dn_rank's upper list
     comm.exchange(st, {{rel_out, (size_t)d.nrecv[1] * sizeof(int), up_rank},
                        {rel_out + d.nrecv[1], (size_t)d.nrecv[0] * sizeof(int), dn_rank}},
@@ -584,16 +670,13 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
                    {rel_in + d.nsend[0], (size_t)d.nsend[1] * sizeof(int), up_rank}});
     // (slabs are at least two ghost shells thick, so the two blocks cannot interleave and no bead is in both send
     // lists; FLAG_GHOST_MIXED / FLAG_SEND_BOTH would be an internal error and are reported with the build's flags)
-    {
-      int *new0 = d.le_i[12], *new1 = d.le_i[13];
-      if (nsall) {
-        hipLaunchKernelGGL(k_dd_reorder_sends, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
-                           rel_in, d.sendlist[0], d.sendlist[1], new0, new1, d.sendslot);
-        HIP_CHECK(hipMemcpyAsync(d.sendlist[0], new0, (size_t)d.nsend[0] * sizeof(int), hipMemcpyDeviceToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(d.sendlist[1], new1, (size_t)d.nsend[1] * sizeof(int), hipMemcpyDeviceToDevice, st));
-      }
-      d.direct_recv = true;
+    if (nsall) {
+      hipLaunchKernelGGL(k_dd_reorder_sends, dim3((nsall + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nsend[0], d.nsend[1],
+                         rel_in, d.sendlist[0], d.sendlist[1], d.sendlist_alt[0], d.sendlist_alt[1], d.sendslot);
+      std::swap(d.sendlist[0], d.sendlist_alt[0]);
+      std::swap(d.sendlist[1], d.sendlist_alt[1]);
     }
+    d.direct_recv = true;
   }
   // ---- 5. lists ----
   launch_lists(d, cutneighsq, sl, has_pair);
@@ -615,11 +698,18 @@ void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, dou
     }
     const long long ticks = (long long)(d.halo_timeout_s * 1e3 * (double)clock_khz);
     static const int corrupt = getenv("LAMMPS_LE_TEST_HALO_CORRUPT") ? 1 : 0;
-    hipLaunchKernelGGL(k_halo_sync, dim3(1), dim3(64), 0, st, d.peer_flag[0], d.peer_flag[1], d.halo_flag, seq, ticks, d.flags);
-    if (d.nghost)
-      hipLaunchKernelGGL(k_halo_unpack_win, dim3((d.nghost + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nrecv[0], d.nrecv[1],
+    if (d.halo_fused)
+      hipLaunchKernelGGL(k_halo_exchange_win, dim3(std::max(1, (d.nghost + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.peer_flag[0],
+                         d.peer_flag[1], d.halo_flag, seq, ticks, d.flags, d.nrecv[0], d.nrecv[1],
                          d.halo_win + (size_t)(parity * 2 + 0) * d.halo_cap, d.halo_win + (size_t)(parity * 2 + 1) * d.halo_cap,
                          dst + d.n, corrupt);
+    else {
+      hipLaunchKernelGGL(k_halo_sync, dim3(1), dim3(64), 0, st, d.peer_flag[0], d.peer_flag[1], d.halo_flag, seq, ticks, d.flags);
+      if (d.nghost)
+        hipLaunchKernelGGL(k_halo_unpack_win, dim3((d.nghost + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nrecv[0], d.nrecv[1],
+                           d.halo_win + (size_t)(parity * 2 + 0) * d.halo_cap, d.halo_win + (size_t)(parity * 2 + 1) * d.halo_cap,
+                           dst + d.n, corrupt);
+    }
     d.halo_seq = seq;
     d.packed_peer = 0;
     if (d.halo_verify && nsall + d.nghost > 0) {

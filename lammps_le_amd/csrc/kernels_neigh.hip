@@ -551,7 +551,12 @@ __global__ __launch_bounds__(BLOCK, BUILD_WAVES_PER_SIMD) void k_build_neigh_dia
 
 // phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
 // Decomposed runs pass m_in = slots to bin (kept + gone + arrived) and `gone`; n_out beads remain afterwards.
-void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
+void scan_cells(DeviceState &d, int *count, int *start, int nc, int total) {
+  const int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, d.stream, nc, count, start, d.scan_tmp);
+  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, d.stream, nc, start, d.scan_tmp, total);
+}
+void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone, bool binned) {
   if (m_in < 0) m_in = n_out = d.n;
   int nb = std::max(1, (m_in + BLOCK - 1) / BLOCK);
   const int nc = d.ncells + (gone ? 1 : 0);     // + sentinel cell
@@ -560,15 +565,13 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone) {
   // only Domain::pbc is left, and k_permute applies it while it moves the beads
   const bool prebinned = d.bins_ready && !gone && !d.dd && m_in == d.n;
   d.bins_ready = false;
-  if (!prebinned) {
+  if (!prebinned && !binned) {
     if (d.cell_count_dirty) HIP_CHECK(hipMemsetAsync(d.cell_count, 0, (size_t)(nc + 1) * sizeof(int), st));   // bins nobody consumed
     hipLaunchKernelGGL(k_wrap_bin, dim3(nb), dim3(BLOCK), 0, st, m_in, d.pos, d.img, d.npad, d.box, d.ncell[0],
                        d.ncell[1], d.ncell[2], d.cellinv[0], d.cellinv[1], d.cellinv[2], d.zlo_ext, d.cell_of,
                        d.cell_count, d.tag_tmp, d.flags, gone, d.ncells, d.row_tile);
   }
-  int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_count, d.cell_start, d.scan_tmp);
-  hipLaunchKernelGGL(k_scan_add, dim3(sb), dim3(SCAN_BLOCK), 0, st, nc, d.cell_start, d.scan_tmp, m_in);
+  scan_cells(d, d.cell_count, d.cell_start, nc, m_in);
   d.cell_count_dirty = false;      // k_scan_local left the counts at zero
   hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, m_in, d.cell_of, d.cell_start, d.tag_tmp, d.perm);
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,

@@ -168,11 +168,7 @@ __global__ __launch_bounds__(256) void k_rng_validate(int n, const int *__restri
                                                       int *__restrict__ late, int *__restrict__ flags) {
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
-  const int t = tag[p];
-  const long long r = crank ? crank[t] : t - 1;
-  const int sg = (int)((3 * r) / seglen);
-  if (live0 && !gen0[sg]) { late[sg] = 1; flags[FLAG_RNG_MISS] = 1; }
-  if (live1 && !gen1[sg]) { late[nseg + sg] = 1; flags[FLAG_RNG_MISS] = 1; }
+  rng_validate_bead(RngValidateArgs{crank, seglen, nseg, gen0, gen1, live0, live1, late}, tag[p], flags);
 }
 
 static void rng_free_batch(DeviceState &d) {
@@ -339,6 +335,12 @@ void rng_validate_owned(DeviceState &d) {
   hipLaunchKernelGGL(k_rng_validate, dim3(std::max(1, (d.n + 255) / 256)), dim3(256), 0, d.stream, d.n, d.tag,
                      d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, d.rng_nseg, d.rng_gen[0], d.rng_gen[1],
                      d.rng_batch_raw[0] ? 1 : 0, d.rng_batch_raw[1] ? 1 : 0, d.rng_late, d.flags);
+}
+RngValidateArgs rng_validate_args(DeviceState &d) {
+  if (!d.rng_skip || d.rng_mode != 1 || !d.rng_gen[0] || (!d.rng_batch_raw[0] && !d.rng_batch_raw[1]))
+    return RngValidateArgs{nullptr, 1, 0, nullptr, nullptr, 0, 0, nullptr};
+  return RngValidateArgs{d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, d.rng_nseg, d.rng_gen[0], d.rng_gen[1],
+                         d.rng_batch_raw[0] ? 1 : 0, d.rng_batch_raw[1] ? 1 : 0, d.rng_late};
 }
 void rng_late_generate(DeviceState &d) {
   // (rare: a bead reached this slab from beyond the ghost shell within the life of a batch, or the canonical ranks changed)

@@ -83,13 +83,15 @@ def bond_set(nb, bt, ba):
 
 
 @pytest.mark.parametrize("world,n,overlap,windows", [(2, 6000, 0, 1), (3, 20000, 0, 1), (2, 6000, 1, 1), (3, 20000, 0, 0),
-                                                     (5, 60000, 0, 1)])
+                                                     (5, 60000, 0, 1), (2, 6000, 0, 2), (3, 20000, 0, 2)])
 def test_md_across_slabs(tmp_path, world, n, overlap, windows, monkeypatch):
     """NVE + Langevin for 60 steps incl. reneighbors with migration across slab faces (one process per rank).  `windows`:
     the per-step halo goes through the peer windows (the step kernel stores into the neighbour's IPC-mapped buffer) or
-    through the transport."""
+    through the transport; 2 = windows with the one-launch exchange kernel a multi-GPU run takes (here the ranks share a
+    GPU, where the engine would choose the two-launch form by itself)."""
     monkeypatch.setenv("LAMMPS_LE_OVERLAP", str(overlap))
-    monkeypatch.setenv("LAMMPS_LE_FAST_HALO", str(windows))
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO", str(min(windows, 1)))
+    monkeypatch.setenv("LAMMPS_LE_HALO_FUSED", "1" if windows == 2 else "0")
     monkeypatch.setenv("LAMMPS_LE_FAST_HALO_VERIFY", "1" if world in (3, 5) else "0")
     s = lattice_chain(n, nchains=2, seed=21)
     script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
