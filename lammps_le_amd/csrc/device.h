@@ -180,6 +180,7 @@ struct DeviceState {
   int *gcell_start = nullptr, *gcell_count = nullptr;   // ghost ranges per cell (relative to n)
   int *sendlist[2] = {nullptr, nullptr};                // owned indices sent down / up every step
   int *sendlist_alt[2] = {nullptr, nullptr};            // ... and the buffers the next rebuild writes its reordered lists into
+  bool bpart_fresh = false;                             // the permute pass of this rebuild has written the bond-partner table
   bool map_stale = true;                                // map[] was not left by a decomposed rebuild: fill it before the next one
   int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
   double4 *sendbuf = nullptr, *recvbuf = nullptr;       // halo staging
@@ -236,7 +237,9 @@ void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4
 void launch_flevel_copy(DeviceState &d, double *flevel, bool to_level, bool add);
 void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start = nullptr,
-                 hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true, bool angle_forces = false);
+                 hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true, bool angle_forces = false,
+                 bool eflag = false);
+bool step_fuses_energy(const DeviceState &d, bool has_pair);   // a thermo step can be one launch of the step kernel's energy variant
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt);
 void launch_ke(DeviceState &d, const TypeTables &tt);

@@ -833,6 +833,21 @@ void Engine::iterate(long nsteps) {
       if (lg) rng_langevin_consumed(d);
       pre_integrated = next;
       stamp(T_PAIR);          // the fused kernel: pair + bond + post_force + final_integrate (+ next initial_integrate)
+    } else if (fusable && eflag && !dump_now && !ang && step_fuses_energy(d, pair_lj)) {
+      // a thermo step without dumps: the step kernel's energy variant - forces, energies, virial, post_force and
+      // final_integrate in one pass; the next step starts with its own initial_integrate (thermo reads the velocities
+      // of the END of this step)
+      if (!finish_reneighbor()) regrow_lists();
+      if (lg) langevin_draws(this, lg);
+      launch_step(d, bondtab, special_lj, tt, lg != nullptr, false, ident, pair_lj, dt, triggersq, false, nullptr, nullptr, -1,
+                  true, false, true);
+      if (lg) rng_langevin_consumed(d);
+      pre_integrated = false;
+      stamp(T_PAIR);
+      last_thermo = eval_thermo();
+      thermo_log.push_back(last_thermo);
+      print_thermo(last_thermo);
+      stamp(T_OUTPUT);
     } else {
       if (!finish_reneighbor()) regrow_lists();
       if (d.dd) dd_halo_wait(d);

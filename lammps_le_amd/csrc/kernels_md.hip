@@ -505,22 +505,21 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
 // ANG: runs with an angle style - the angle forces of this step were written into fx / fy / fz by k_angle<.., OVERWRITE>
 // right before this launch and are added to the bead's sums (a template parameter, not a run-time test: the step kernel's
 // schedule is sensitive - a pointer test here cost every run 2 us per launch)
-template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG = false>
-__global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
-                                                const int *__restrict__ tag, const int *__restrict__ crank,
-                                                const uint32_t *__restrict__ draws, double *__restrict__ vx,
-                                                double *__restrict__ vy, double *__restrict__ vz,
-                                                double *__restrict__ fx, double *__restrict__ fy,
-                                                double *__restrict__ fz, double4 *__restrict__ pos_next,
-                                                const double4 *__restrict__ xhold, double dtv, double triggersq,
-                                                int check, int *__restrict__ flags,
-                                                const unsigned char *__restrict__ phase, int which) {
-  __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
-  __shared__ double s_bt[(MAXTYPES + 1) * BT_W];
-  fill_bond_table(bt, s_bt);
-  if (HAS_PAIR && !(A.uniform && !A.has_sb))     // one coefficient set and no fractional special weights: scalars, no table
-    for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
-  __syncthreads();
+// EF: a thermo step - the same pass also sums the energies and the virial of the pair and bond terms into `partial`
+// (rows of 16 per block, as k_force<EFLAG> writes them), so that a step with thermo output is not a pass of k_force
+// plus a Langevin / integrate kernel.  Only for NEXT = false, one lane per bead (the velocities thermo reads are those
+// after final_integrate); the block totals travel in through `pos_next`, which a NEXT = false launch does not use.
+template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG, bool EF>
+__device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &bt, const Box &box, const TypeTables &tt,
+                                          const double *s_tab, const double *s_bt,
+                                          const int *__restrict__ tag, const int *__restrict__ crank,
+                                          const uint32_t *__restrict__ draws, double *__restrict__ vx,
+                                          double *__restrict__ vy, double *__restrict__ vz,
+                                          double *__restrict__ fx, double *__restrict__ fy,
+                                          double *__restrict__ fz, double4 *__restrict__ pos_next,
+                                          const double4 *__restrict__ xhold, double dtv, double triggersq,
+                                          int check, int *__restrict__ flags,
+                                          const unsigned char *__restrict__ phase, int which, double (&e)[14]) {
   int lb = logical_block(A.nblocks);
   const int sub = (LPB == 1) ? 0 : (int)(threadIdx.x % LPB);
   int p = lb * (BLOCK / LPB) + threadIdx.x / LPB;
@@ -544,8 +543,7 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
     d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
   }
   double f0 = 0.0, f1 = 0.0, f2 = 0.0;
-  double e[14];
-  bead_force<false, HAS_PAIR, LPB, DIAG, AHEAD>(A, bt, box, s_tab, s_bt, p, sub, L, ri, f0, f1, f2, e, flags);
+  bead_force<EF, HAS_PAIR, LPB, DIAG, AHEAD>(A, bt, box, s_tab, s_bt, p, sub, L, ri, f0, f1, f2, e, flags);
   if (LPB > 1) {
 #pragma unroll
     for (int o = 1; o < LPB; o <<= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); }
@@ -614,6 +612,35 @@ __global__ __launch_bounds__(BLOCK, (AHEAD ? 1 : STEP_WAVES_PER_SIMD)) void k_st
   }
   if (DIAG && (A.diag & 64)) { if (a == 1.2345e300) vx[p] = a; return; }   // diagnostic launch: v is left alone (the value is still computed)
   vx[p] = a; vy[p] = b; vz[p] = c;
+}
+template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG = false, bool EF = false>
+__global__ __launch_bounds__(BLOCK, ((AHEAD || EF) ? 1 : STEP_WAVES_PER_SIMD)) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
+                                                const int *__restrict__ tag, const int *__restrict__ crank,
+                                                const uint32_t *__restrict__ draws, double *__restrict__ vx,
+                                                double *__restrict__ vy, double *__restrict__ vz,
+                                                double *__restrict__ fx, double *__restrict__ fy,
+                                                double *__restrict__ fz, double4 *__restrict__ pos_next,
+                                                const double4 *__restrict__ xhold, double dtv, double triggersq,
+                                                int check, int *__restrict__ flags,
+                                                const unsigned char *__restrict__ phase, int which) {
+  static_assert(!EF || (!NEXT && LPB == 1), "energy variant: NEXT = false, one lane per bead");
+  __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
+  __shared__ double s_bt[(MAXTYPES + 1) * BT_W];
+  fill_bond_table(bt, s_bt);
+  if (HAS_PAIR && !(A.uniform && !A.has_sb))     // one coefficient set and no fractional special weights: scalars, no table
+    for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
+  __syncthreads();
+  double e[14];
+  if (EF) {
+#pragma unroll
+    for (int k = 0; k < 14; k++) e[k] = 0.0;
+  }
+  step_body<LANGEVIN, NEXT, IDENT, HAS_PAIR, LPB, DIAG, AHEAD, ANG, EF>(A, bt, box, tt, s_tab, s_bt, tag, crank, draws, vx, vy, vz, fx, fy, fz,
+                                                                        pos_next, xhold, dtv, triggersq, check, flags, phase, which, e);
+  if (EF) {
+    const int lb = logical_block(A.nblocks);
+    if (lb < A.nblocks) block_reduce_store<14>(e, reinterpret_cast<double *>(pos_next), lb, 0);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -712,10 +739,25 @@ void launch_force(DeviceState &d, const BondTable &bt, const double sl[4], bool 
   else { if (has_pair) FRC(false, true); else FRC(false, false); }
 #undef FRC
 }
+// which shape of the step kernel a system of this size takes (environment overrides for experiments)
+static bool step_lpb4(const DeviceState &d) {
+  static const int lpb_env = getenv("LAMMPS_LE_LPB") ? atoi(getenv("LAMMPS_LE_LPB")) : 0;
+  static const int lpb_max_n = getenv("LAMMPS_LE_LPB_MAX_N") ? atoi(getenv("LAMMPS_LE_LPB_MAX_N")) : LPB4_MAX_BEADS;
+  return lpb_env ? lpb_env == 4 : d.n <= lpb_max_n;
+}
+static bool step_ahead(const DeviceState &d) {
+  static const int ahead_max_n = getenv("LAMMPS_LE_AHEAD_MAX_N") ? atoi(getenv("LAMMPS_LE_AHEAD_MAX_N")) : AHEAD_MAX_BEADS;
+  return d.n <= ahead_max_n;
+}
+// a thermo step as ONE pass (k_step<.., EF>): one GPU, a pair style, the throughput shape of the kernel (one lane per bead)
+bool step_fuses_energy(const DeviceState &d, bool has_pair) {
+  static const bool off = getenv("LAMMPS_LE_NO_FUSED_THERMO") != nullptr;
+  return has_pair && !d.dd && !step_lpb4(d) && !step_ahead(d) && !off;
+}
 // fused force + Langevin + final_integrate [+ next initial_integrate]; swaps the position buffers when `next`
 void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
-                 hipEvent_t ev_stop, int which, bool swap_buffers, bool angle_forces) {
+                 hipEvent_t ev_stop, int which, bool swap_buffers, bool angle_forces, bool eflag) {
   ForceArgs A = force_args(d, sl);
   if (d.dd && next && d.sendslot && !d.sendslot_fallback) {
     A.sendslot = d.sendslot;
@@ -733,12 +775,11 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
     }
   }
   // lanes per bead: 4 while the launch is latency-bound (few wavefronts per SIMD), 1 once it is throughput-bound
-  static const int lpb_env = getenv("LAMMPS_LE_LPB") ? atoi(getenv("LAMMPS_LE_LPB")) : 0;
-  static const int lpb_max_n = getenv("LAMMPS_LE_LPB_MAX_N") ? atoi(getenv("LAMMPS_LE_LPB_MAX_N")) : LPB4_MAX_BEADS;
-  const bool lpb4 = (lpb_env ? lpb_env == 4 : d.n <= lpb_max_n) && !angle_forces;     // (angle runs: one lane per bead, see step_fuses_angles)
+  const bool lpb4 = step_lpb4(d) && !angle_forces;     // (angle runs: one lane per bead, see step_fuses_angles)
   if (angle_forces && !has_pair) throw LammpsError("internal: fused angle step without a pair style");
-  static const int ahead_max_n = getenv("LAMMPS_LE_AHEAD_MAX_N") ? atoi(getenv("LAMMPS_LE_AHEAD_MAX_N")) : AHEAD_MAX_BEADS;
-  const bool ahead = d.n <= ahead_max_n;
+  const bool ahead = step_ahead(d);
+  if (eflag && (next || angle_forces || which >= 0 || !step_fuses_energy(d, has_pair)))
+    throw LammpsError("internal: energy variant of the fused step asked for a launch it does not cover");
   // diagnostics only (LAMMPS_LE_STEP_LDS_PAD=bytes): unused dynamic LDS per workgroup, to lower the occupancy on purpose
   static const unsigned lds_pad = getenv("LAMMPS_LE_STEP_LDS_PAD") ? (unsigned)atoi(getenv("LAMMPS_LE_STEP_LDS_PAD")) : 0u;
   if (lpb4) { A.nblocks = (d.n + BLOCK / 4 - 1) / (BLOCK / 4); A.maxrow = (d.maxneigh - 4) / 4; }
@@ -764,6 +805,16 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 #define STP(L, N, I, P) do { if (angle_forces) { if (ahead) STPA(L, N, I, true, 1, false, true, true); else STPA(L, N, I, true, 1, false, false, true); } \
     else if (lpb4) STPL(L, N, I, P, 4, false, true); else if (ahead) STPL(L, N, I, P, 1, false, true); else STPL(L, N, I, P, 1, false, false); } while (0)
   int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
+  if (eflag) {      // thermo step: energies and virial in the same pass (block totals through the unused pos_next argument)
+#define STPE(L, I)                                                                                              \
+  hipExtLaunchKernelGGL((k_step<L, false, I, true, 1, false, false, false, true>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, ev_start, \
+                        ev_stop, 0, A, bt, d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],  \
+                        reinterpret_cast<double4 *>(d.partial), d.xhold, dtv, triggersq, 0, d.flags, d.phase, which)
+    if (langevin) { if (ident) STPE(true, true); else STPE(true, false); }
+    else { if (ident) STPE(false, true); else STPE(false, false); }
+#undef STPE
+    return;
+  }
   // LAMMPS_LE_DIAG_STEP=bits: the same kernel is launched once more BEFORE the real launch with parts switched off
   // (1 bonds, 2 pair loop, 4 draws, 8 pair gathers replaced by coalesced loads, 128 nothing); it writes only the second position buffer, which the real launch
   // overwrites, so the run is physically unchanged and a kernel trace shows what each part costs

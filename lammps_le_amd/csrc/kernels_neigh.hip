@@ -106,8 +106,11 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(int n, const int *__restrict_
   perm[cell_start[cell_of[p]] + rank[p]] = p;
 }
 // one thread per cell: order the cell's entries by tag so the final order is deterministic
+// (`map` != nullptr: the new index of every bead is known here already - map[tag] is written now, so that the permute pass
+//  that follows can translate bond partners while it moves the beads)
 __global__ __launch_bounds__(BLOCK) void k_sort_cells(int ncells, const int *__restrict__ cell_start,
-                                                      int *__restrict__ perm, const int *__restrict__ tag) {
+                                                      int *__restrict__ perm, const int *__restrict__ tag,
+                                                      int *__restrict__ map) {
   int c = blockIdx.x * BLOCK + threadIdx.x;
   if (c >= ncells) return;
   int b = cell_start[c], e = cell_start[c + 1];
@@ -116,30 +119,8 @@ __global__ __launch_bounds__(BLOCK) void k_sort_cells(int ncells, const int *__r
     while (j >= b && tag[perm[j]] > ti) { perm[j + 1] = perm[j]; j--; }
     perm[j + 1] = pi;
   }
-}
-__global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *__restrict__ perm,
-                                                   const double4 *__restrict__ pos, double4 *__restrict__ pos_new,
-                                                   double4 *__restrict__ xhold, const double *__restrict__ vx,
-                                                   const double *__restrict__ vy, const double *__restrict__ vz,
-                                                   double *__restrict__ vxn, double *__restrict__ vyn,
-                                                   double *__restrict__ vzn, const int *__restrict__ tag,
-                                                   int *__restrict__ tagn, const int *__restrict__ img,
-                                                   int *__restrict__ imgn, int *__restrict__ map,
-                                                   float4 *__restrict__ posf, int wrap, Box box) {
-  int s = blockIdx.x * BLOCK + threadIdx.x;
-  if (s >= n) return;
-  int p = perm[s];
-  double4 r = pos[p];
-  int dix = 0, diy = 0, diz = 0;
-  if (wrap) wrap_into_box(r, box, dix, diy, diz);   // the step kernel binned these positions: Domain::pbc is applied here
-  pos_new[s] = r;
-  xhold[s] = r;
-  vxn[s] = vx[p]; vyn[s] = vy[p]; vzn[s] = vz[p];
-  int t = tag[p];
-  tagn[s] = t;
-  imgn[s] = img[p] + dix; imgn[npad + s] = img[npad + p] + diy; imgn[2 * npad + s] = img[2 * npad + p] + diz;
-  map[t] = s;
-  posf[s] = make_float4((float)r.x, (float)r.y, (float)r.z, 0.f);
+  if (map)
+    for (int i = b; i < e; i++) map[tag[perm[i]]] = i;
 }
 // bond-partner table of bead s: physical index + type of every stored bond (the step kernel's `bpart` rows)
 struct BondTabArgs {
@@ -189,6 +170,36 @@ __device__ __forceinline__ void bond_table_row(int s, int n, int npad, int t, co
   }
   if (freeze) B.bshift[s] = code;
   if (B.phase && ghost) B.phase[s] = 1;     // reads a ghost position: phase 1 of a decomposed step
+}
+// the beads move into cell order.  `B.bpart` != nullptr (one GPU, bonds whose image needs no freezing): map[] is complete
+// (k_sort_cells), and the bond-partner table of the new order is written in the same pass - the scattered reads of the
+// packed bond records and of map[] ride under the streaming of the permutation instead of taking a launch of their own
+// (k_bond_table: 27 us per rebuild at 1M beads from the scrambled start).
+__global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *__restrict__ perm,
+                                                   const double4 *__restrict__ pos, double4 *__restrict__ pos_new,
+                                                   double4 *__restrict__ xhold, const double *__restrict__ vx,
+                                                   const double *__restrict__ vy, const double *__restrict__ vz,
+                                                   double *__restrict__ vxn, double *__restrict__ vyn,
+                                                   double *__restrict__ vzn, const int *__restrict__ tag,
+                                                   int *__restrict__ tagn, const int *__restrict__ img,
+                                                   int *__restrict__ imgn, int *__restrict__ map,
+                                                   float4 *__restrict__ posf, int wrap, Box box, BondTabArgs B,
+                                                   int *__restrict__ flags) {
+  int s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= n) return;
+  int p = perm[s];
+  int t = tag[p];
+  if (B.bpart) bond_table_row(s, n, npad, t, map, B, flags);
+  double4 r = pos[p];
+  int dix = 0, diy = 0, diz = 0;
+  if (wrap) wrap_into_box(r, box, dix, diy, diz);   // the step kernel binned these positions: Domain::pbc is applied here
+  pos_new[s] = r;
+  xhold[s] = r;
+  vxn[s] = vx[p]; vyn[s] = vy[p]; vzn[s] = vz[p];
+  tagn[s] = t;
+  imgn[s] = img[p] + dix; imgn[npad + s] = img[npad + p] + diy; imgn[2 * npad + s] = img[2 * npad + p] + diz;
+  if (!B.bpart) map[t] = s;
+  posf[s] = make_float4((float)r.x, (float)r.y, (float)r.z, 0.f);
 }
 // packed bond records by tag (see DeviceState::bond_pack); run when the bond tables changed
 __global__ __launch_bounds__(BLOCK) void k_bond_pack(int maxtag, int bpa, int stride, const int *__restrict__ num_bond,
@@ -551,6 +562,12 @@ __global__ __launch_bounds__(BLOCK, BUILD_WAVES_PER_SIMD) void k_build_neigh_dia
 
 // phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
 // Decomposed runs pass m_in = slots to bin (kept + gone + arrived) and `gone`; n_out beads remain afterwards.
+static void ensure_bond_pack(DeviceState &d) {
+  if (!d.bond_pack_dirty) return;
+  hipLaunchKernelGGL(k_bond_pack, dim3((d.maxtag + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.maxtag, d.bpa, d.bond_pack_stride,
+                     d.num_bond, d.bond_type, d.bond_atom, d.bond_pack);
+  d.bond_pack_dirty = false;
+}
 void scan_cells(DeviceState &d, int *count, int *start, int nc, int total) {
   const int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
   hipLaunchKernelGGL(k_scan_local, dim3(sb), dim3(SCAN_BLOCK), 0, d.stream, nc, count, start, d.scan_tmp);
@@ -574,13 +591,20 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone, boo
   scan_cells(d, d.cell_count, d.cell_start, nc, m_in);
   d.cell_count_dirty = false;      // k_scan_local left the counts at zero
   hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BLOCK), 0, st, m_in, d.cell_of, d.cell_start, d.tag_tmp, d.perm);
+  // one GPU, bonds that need no frozen image: the permute pass also writes the bond-partner table (see k_permute)
+  static const bool no_fuse = getenv("LAMMPS_LE_NO_PERMUTE_BONDS") != nullptr;
+  const bool with_bonds = !d.dd && !gone && d.bond_minimg && d.bpa > 0 && d.bpart && !no_fuse;
+  if (with_bonds) ensure_bond_pack(d);
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
-                     d.cell_start, d.perm, d.tag);
+                     d.cell_start, d.perm, d.tag, with_bonds ? d.map : (int *)nullptr);
   const int n = n_out;
   nb = std::max(1, (n + BLOCK - 1) / BLOCK);
+  BondTabArgs BT{d.bpa, d.maxtag, d.num_bond, d.bond_type, d.bond_atom, d.bond_pack, d.bond_pack_stride, with_bonds ? d.bpart : (int *)nullptr,
+                 nullptr, nullptr, nullptr, 0.0, 0.0, 0.0};
   hipLaunchKernelGGL(k_permute, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.perm, d.pos, d.pos_tmp, d.xhold, d.v[0],
                      d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map, d.posf,
-                     prebinned ? 1 : 0, d.box);
+                     prebinned ? 1 : 0, d.box, BT, d.flags);
+  d.bpart_fresh = with_bonds;
   std::swap(d.pos, d.pos_tmp);
   for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
   std::swap(d.tag, d.tag_tmp);
@@ -592,16 +616,13 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
   int n = d.n, nb = (n + BLOCK - 1) / BLOCK;
   if (nb == 0) nb = 1;
   hipStream_t st = d.stream;
-  if (d.bond_pack_dirty) {
-    hipLaunchKernelGGL(k_bond_pack, dim3((d.maxtag + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.maxtag, d.bpa, d.bond_pack_stride,
-                       d.num_bond, d.bond_type, d.bond_atom, d.bond_pack);
-    d.bond_pack_dirty = false;
-  }
+  ensure_bond_pack(d);
   BondTabArgs BT{d.bpa, d.maxtag, d.num_bond, d.bond_type, d.bond_atom, d.bond_pack, d.bond_pack_stride, d.bpart, d.dd ? d.phase : nullptr,
                  d.pos, d.bond_minimg ? nullptr : d.bshift, d.box.half[0], d.box.half[1], d.box.half[2]};
   // (a launch of its own: folded into the prologue of the list build it made that kernel 48 us slower to save 16, and
   // even the unused extra kernel argument cost the build 32 us)
-  hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.tag, d.map, BT, d.flags);
+  if (!d.bpart_fresh) hipLaunchKernelGGL(k_bond_table, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.tag, d.map, BT, d.flags);
+  d.bpart_fresh = false;      // (a second call for the same order - the list table grew - re-derives the same table)
   if (has_pair) {
     const int sf1 = d.sflag[1], sf2 = d.sflag[2], sf3 = d.sflag[3];
     const int ddcode = d.dd ? 1 : (d.row_tile ? 0 : 2);     // see build_body   // Engine::special_flag (lj AND coul weights)

@@ -121,10 +121,12 @@ def test_velocity_create_between_runs(tmp_path, n):
     {"LAMMPS_LE_LPB": "1", "LAMMPS_LE_AHEAD_MAX_N": "0"},           # throughput variant (what >64k-bead systems run)
     {"LAMMPS_LE_LPB": "1", "LAMMPS_LE_AHEAD_MAX_N": "1000000000"},  # loads issued ahead
     {"LAMMPS_LE_LPB": "4"},                                          # four lanes per bead
-], ids=["plain", "ahead", "lpb4"])
+    {"LAMMPS_LE_LPB": "1", "LAMMPS_LE_AHEAD_MAX_N": "0", "LAMMPS_LE_NO_FUSED_THERMO": "1"},   # thermo steps through k_force + k_langevin
+], ids=["plain", "ahead", "lpb4", "plain-unfused-thermo"])
 def test_step_kernel_variants(tmp_path, env):
     """Every variant of the fused step kernel (chosen by system size in production) on the same system: hybrid bonds,
-    fractional special weights, two atom types, Langevin; against the oracle."""
+    fractional special weights, two atom types, Langevin; against the oracle.  "plain" takes its thermo steps (every 25th)
+    through the energy variant of the step kernel, as systems above 64k beads do."""
     import pickle
     import subprocess
     import sys
