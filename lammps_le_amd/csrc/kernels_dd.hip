@@ -340,19 +340,35 @@ static void ensure_gather(DeviceState &d, size_t doubles_per_rank, int world) {
 // The rebuild keeps its variable-size exchanges on the transport, which also fence the windows across a rebuild.
 // The spin is bounded (halo_timeout_s, the transports' own limit): every wave reaches its exit, a dead neighbour ends
 // in ERR_HALO_TIMEOUT -> LammpsError -> Comm::abort on this rank.
-__global__ __launch_bounds__(64) void k_halo_sync(unsigned *__restrict__ to_dn, unsigned *__restrict__ to_up,
-                                                  const unsigned *__restrict__ mine, unsigned seq, long long timeout_ticks,
-                                                  int *__restrict__ flags) {
-  if (threadIdx.x != 0) return;
-  __threadfence_system();
-  __hip_atomic_store(to_dn, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(to_up, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// the wait of one lane for both arrival counters.  `vstate` (verify mode only: [0] mismatch count, [1] "windows broken"): a
+// counter that does not arrive in time is then not an error - the transport's copy of this halo follows and wins - but one
+// more mismatch, and later exchanges do not wait again (a first multi-GPU run whose windows do not work loses a few seconds
+// of its pre-roll and carries on over the transport, instead of ending in ERR_HALO_TIMEOUT).
+__device__ __forceinline__ bool halo_wait_counters(const unsigned *__restrict__ mine, unsigned seq, long long timeout_ticks,
+                                                   int *__restrict__ flags, unsigned *__restrict__ vstate, bool count_it) {
+  if (vstate && __hip_atomic_load(vstate + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
   const long long t0 = wall_clock64();
   for (int side = 0; side < 2; side++)
     while ((int)(__hip_atomic_load(mine + side, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
       __builtin_amdgcn_s_sleep(4);
-      if (wall_clock64() - t0 > timeout_ticks) { flags[FLAG_ERROR] = ERR_HALO_TIMEOUT; return; }
+      if (wall_clock64() - t0 > timeout_ticks) {
+        if (vstate) {
+          __hip_atomic_store(vstate + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (count_it) atomicAdd(vstate, 1u);
+        } else flags[FLAG_ERROR] = ERR_HALO_TIMEOUT;
+        return false;
+      }
     }
+  return true;
+}
+__global__ __launch_bounds__(64) void k_halo_sync(unsigned *__restrict__ to_dn, unsigned *__restrict__ to_up,
+                                                  const unsigned *__restrict__ mine, unsigned seq, long long timeout_ticks,
+                                                  int *__restrict__ flags, unsigned *__restrict__ vstate) {
+  if (threadIdx.x != 0) return;
+  __threadfence_system();
+  __hip_atomic_store(to_dn, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(to_up, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  (void)halo_wait_counters(mine, seq, timeout_ticks, flags, vstate, true);
 }
 // window -> ghost slots [from below | from above]; the window is read with system-scope loads (never from a stale line)
 __global__ __launch_bounds__(BLOCK) void k_halo_unpack_win(int n0, int n1, const double4 *__restrict__ from_below,
@@ -376,7 +392,8 @@ __global__ __launch_bounds__(BLOCK) void k_halo_unpack_win(int n0, int n1, const
 // exchange against 13 + 8 us for the two launches above).
 __global__ __launch_bounds__(BLOCK) void k_halo_exchange_win(unsigned *__restrict__ to_dn, unsigned *__restrict__ to_up,
                                                              const unsigned *__restrict__ mine, unsigned seq,
-                                                             long long timeout_ticks, int *__restrict__ flags, int n0, int n1,
+                                                             long long timeout_ticks, int *__restrict__ flags,
+                                                             unsigned *__restrict__ vstate, int n0, int n1,
                                                              const double4 *__restrict__ from_below,
                                                              const double4 *__restrict__ from_above,
                                                              double4 *__restrict__ ghost, int corrupt) {
@@ -387,14 +404,7 @@ __global__ __launch_bounds__(BLOCK) void k_halo_exchange_win(unsigned *__restric
       __hip_atomic_store(to_dn, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(to_up, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    int ok = 1;
-    const long long t0 = wall_clock64();
-    for (int side = 0; side < 2 && ok; side++)
-      while ((int)(__hip_atomic_load(mine + side, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > timeout_ticks) { flags[FLAG_ERROR] = ERR_HALO_TIMEOUT; ok = 0; break; }
-      }
-    s_ok = ok;
+    s_ok = halo_wait_counters(mine, seq, timeout_ticks, flags, vstate, blockIdx.x == 0) ? 1 : 0;
   }
   __syncthreads();
   if (!s_ok) return;
@@ -696,15 +706,20 @@ void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, dou
       HIP_CHECK(hipGetDevice(&dev));
       if (hipDeviceGetAttribute(&clock_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || clock_khz <= 0) clock_khz = 100000;
     }
-    const long long ticks = (long long)(d.halo_timeout_s * 1e3 * (double)clock_khz);
+    // (verify mode: a window that does not deliver is rejected after 5 s, not waited for as long as the transports wait)
+    const long long ticks = (long long)((d.halo_verify ? std::min(d.halo_timeout_s, 5.0) : d.halo_timeout_s) * 1e3 * (double)clock_khz);
+    unsigned *vstate = d.halo_verify ? d.halo_flag + HALO_MISMATCH_SLOT : (unsigned *)nullptr;
+    // test hook (LAMMPS_LE_TEST_HALO_MUTE): my "stores complete" never reaches the neighbours - windows that do not deliver
+    const bool mute = getenv("LAMMPS_LE_TEST_HALO_MUTE") != nullptr;
+    unsigned *to_dn = mute ? d.halo_flag + HALO_MISMATCH_SLOT + 4 : d.peer_flag[0], *to_up = mute ? d.halo_flag + HALO_MISMATCH_SLOT + 5 : d.peer_flag[1];
     static const int corrupt = getenv("LAMMPS_LE_TEST_HALO_CORRUPT") ? 1 : 0;
     if (d.halo_fused)
-      hipLaunchKernelGGL(k_halo_exchange_win, dim3(std::max(1, (d.nghost + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, d.peer_flag[0],
-                         d.peer_flag[1], d.halo_flag, seq, ticks, d.flags, d.nrecv[0], d.nrecv[1],
+      hipLaunchKernelGGL(k_halo_exchange_win, dim3(std::max(1, (d.nghost + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, to_dn,
+                         to_up, d.halo_flag, seq, ticks, d.flags, vstate, d.nrecv[0], d.nrecv[1],
                          d.halo_win + (size_t)(parity * 2 + 0) * d.halo_cap, d.halo_win + (size_t)(parity * 2 + 1) * d.halo_cap,
                          dst + d.n, corrupt);
     else {
-      hipLaunchKernelGGL(k_halo_sync, dim3(1), dim3(64), 0, st, d.peer_flag[0], d.peer_flag[1], d.halo_flag, seq, ticks, d.flags);
+      hipLaunchKernelGGL(k_halo_sync, dim3(1), dim3(64), 0, st, to_dn, to_up, d.halo_flag, seq, ticks, d.flags, vstate);
       if (d.nghost)
         hipLaunchKernelGGL(k_halo_unpack_win, dim3((d.nghost + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.nrecv[0], d.nrecv[1],
                            d.halo_win + (size_t)(parity * 2 + 0) * d.halo_cap, d.halo_win + (size_t)(parity * 2 + 1) * d.halo_cap,
