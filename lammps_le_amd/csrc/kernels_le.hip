@@ -198,7 +198,11 @@ __device__ void dev_rebuild_special_one(const Topo &tp, int m, int *__restrict__
   cn3 = dev_dedup(cn2, cn3, copy);
   if (cn3 > ms) { flags[FLAG_ERROR] = ERR_SPECIAL_SCRATCH; return; }
   // the 1-2 block is unchanged: only the 1-3 / 1-4 blocks are rewritten, so concurrent rebuilds of
-  // neighbours (which read only 1-2 blocks) see consistent data
+  // neighbours (which read only 1-2 blocks) see consistent data.  Its COUNT is stored as the reference stores it
+  // (nspecial[m][0] = cn1, fix_extrusion.cpp:1104): a count that the unconditional decrements of a bond removal have
+  // pushed below zero (a bead whose 1-2 block had already lost that partner) comes back as 0 - for a concurrent reader
+  // -1 and 0 are the same empty block.  Found by the wide fuzz sweep (seeds 184, 215: profiles/r03/fuzz_wide.log).
+  if (n1 != cn1) tp.nspecial[3 * (size_t)m] = cn1;
   tp.nspecial[3 * (size_t)m + 1] = cn2;
   tp.nspecial[3 * (size_t)m + 2] = cn3;
   for (int i = cn1; i < cn3; i++) slist[i] = copy[i];

@@ -10,7 +10,25 @@ from test_gpu_le import LE, barrier_types, melted
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(16))
+# found by the wide sweep of round 3 (seeds 16..215): a bead whose 1-2 block had already lost the partner of the bond an
+# extrusion step removes - the reference's unconditional decrement takes the count to -1 and rebuild_special_one stores it
+# back as 0 (fix_extrusion.cpp:1104); the device kernel used to leave the -1
+REGRESSION_SEEDS = [184, 215]
+
+
+def _seeds(env, default_stop):
+    """The suite's fixed seeds, or LE_FUZZ_SEEDS / LE_FUZZ_SEEDS_DD = "start:stop" for a one-off wider sweep
+    (scripts/r03_fuzz_wide.sh; the log of the last one is profiles/r03/fuzz_wide.log)."""
+    import os
+    v = os.environ.get(env)
+    if not v:
+        return list(range(default_stop)) + (REGRESSION_SEEDS if env == "LE_FUZZ_SEEDS" else [])
+    a, b = v.split(":")
+    return range(int(a), int(b))
+
+
+
+@pytest.mark.parametrize("seed", _seeds("LE_FUZZ_SEEDS", 16))
 def test_random_le_scenarios(tmp_path, seed):
     rng = np.random.RandomState(1000 + seed)
     n = int(rng.choice([1200, 2000, 3500]))
@@ -52,7 +70,7 @@ def test_random_le_scenarios(tmp_path, seed):
     assert np.abs(p.gather("x") - o.x()).max() < 1e-6
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds("LE_FUZZ_SEEDS_DD", 12))
 def test_random_le_scenarios_decomposed(tmp_path, seed):
     """The same randomised LE scenarios (incl. the ones where several fixes fire in one step) on two z-slabs: the
     replicated extruder table must give the 1-rank topology bit for bit."""
