@@ -11,7 +11,7 @@
 
 namespace lmp_le {
 
-void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair);
+void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair, bool build_lists = true);
 void dd_halo(DeviceState &d, Comm &comm);
 void dd_halo(DeviceState &d, Comm &comm, hipStream_t st, const double4 *src, double4 *dst);
 void dd_halo_wait(DeviceState &d);
@@ -423,15 +423,20 @@ static void check_device_error(Engine *e, DeviceState &d) {
 // defer_check: the flags of the build are published but not waited for - the caller enqueues the step kernel first
 // (it leaves the state untouched if a list overflowed) and then calls finish_reneighbor(); the host round trip of
 // the check (~25 us) is hidden behind that kernel instead of idling the GPU once per rebuild.
-void Engine::reneighbor(bool defer_check) {
+void Engine::reneighbor(bool defer_check, bool sort_now) {
   DeviceState &d = *dev;
   // (read at every rebuild, not cached: the test that sets it shares its process with tests that must not see it)
   const char *ovf = getenv("LAMMPS_LE_TEST_OVERFLOW_AT");
   const long test_overflow_at = ovf ? atol(ovf) : -1;
   if (test_overflow_at >= 0 && neigh_builds == test_overflow_at) dev_alloc_neigh(d, 4);   // test hook: force an overflow
   // FLAG_MOVED / NEIGH_OVERFLOW / MAXNEIGH are zero here: they are reset by the publish kernel that reports them
-  if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj);
-  else launch_reneighbor(d, cutneighmax * cutneighmax, special_lj, pair_lj);
+  // pbc + ownership + cell order, then - on a sort step - the reference's Atom::sort (src/verlet.cpp:270-286: after pbc,
+  // BEFORE neighbor->build: the pair list of this very build is stored in the new local order, which decides whose special
+  // list a pair's status comes from when the lists are asymmetric), then the lists
+  if (d.dd) dd_reneighbor(d, *comm, cutneighmax * cutneighmax, special_lj, pair_lj, false);
+  else launch_sort_owned(d);
+  if (sort_now) emulate_atom_sort();
+  launch_lists(d, cutneighmax * cutneighmax, special_lj, pair_lj);
   // (decomposed: the border pass of the rebuild has also checked that this rank's Langevin pools hold the draws of the beads
   //  it owns now - FLAG_RNG_MISS, kernels_dd.hip k_dd_borders)
   if (defer_check && !d.dd) {
@@ -717,10 +722,9 @@ void Engine::print_thermo(const ThermoRow &r) {
 void Engine::setup() {
   const bool trace = getenv("LAMMPS_LE_TRACE_RUN") != nullptr;
   double s0 = wall();
-  reneighbor();                       // pbc + (spatial sort) + lists; ncalls reset below
+  reneighbor(false, sortfreq > 0);    // pbc + (spatial sort) + Atom::sort + lists; ncalls reset below
   double s1 = wall();
   neigh_builds = 0;
-  if (sortfreq > 0) emulate_atom_sort();
   compute_forces(true);
   FixLangevin *lg = the_langevin(this);
   for (auto &f : fixes) f->setup();
@@ -783,8 +787,7 @@ void Engine::iterate(long nsteps) {
     if (decide()) {
       const bool sort_due = sortfreq > 0 && ntimestep >= nextsort;
       stamp();
-      reneighbor(fusable && !eflag && !dump_now && !sort_due);
-      if (sort_due) emulate_atom_sort();
+      reneighbor(fusable && !eflag && !dump_now && !sort_due, sort_due);
       stamp(T_NEIGH);
     } else {
       stamp();
@@ -898,9 +901,8 @@ void Engine::respa_setup() {                                   // Respa::setup (
     HIP_CHECK(hipMemsetAsync(respa_flevel[l], 0, need * sizeof(double), d.stream));
   }
   respa_flevel_n = need;
-  reneighbor();
+  reneighbor(false, sortfreq > 0);
   neigh_builds = 0;
-  if (sortfreq > 0) emulate_atom_sort();
   for (int l = 0; l <= top; l++) {
     respa_level_forces(l);
     launch_flevel_copy(d, respa_flevel[l], true, false);
@@ -945,8 +947,7 @@ void Engine::respa_recurse(int l, bool last) {
     if (l == top && decide()) {
       const bool sort_due = sortfreq > 0 && ntimestep >= nextsort;
       stamp();
-      reneighbor();
-      if (sort_due) emulate_atom_sort();
+      reneighbor(false, sort_due);
       stamp(T_NEIGH);
     }
     if (l) respa_recurse(l - 1, last_here);

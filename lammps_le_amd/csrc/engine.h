@@ -344,7 +344,7 @@ class Engine {
   void device_init();                 // throws LammpsError if no HIP device
   void upload();                      // host -> device (after read_data / scatter)
   void download();                    // device -> host (x, v, f, type, image, topology)
-  void reneighbor(bool defer_check = false);   // pbc + spatial sort + cell lists + neighbor list + bond table
+  void reneighbor(bool defer_check = false, bool sort_now = false);   // pbc + spatial sort + cell lists + neighbor list + bond table
   bool reneigh_pending = false;       // the build's overflow / error flags are published but not yet looked at
   bool finish_reneighbor();           // waits for them; false = a list overflowed (nothing may depend on the lists yet)
   void regrow_lists();                // grow the table and rebuild until every list fits

@@ -576,7 +576,7 @@ void dd_alloc(DeviceState &d, int world) {
 }
 
 // Rebuild ownership and ghosts on this rank, then sort and build lists.  Collective over all ranks.
-void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair) {
+void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double sl[4], bool has_pair, bool build_lists) {
   hipStream_t st = d.stream;
   dd_halo_wait(d);
   d.halo_ahead = false;
@@ -688,8 +688,8 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
     }
     d.direct_recv = true;
   }
-  // ---- 5. lists ----
-  launch_lists(d, cutneighsq, sl, has_pair);
+  // ---- 5. lists (the engine builds them itself when an Atom::sort emulation has to come in between) ----
+  if (build_lists) launch_lists(d, cutneighsq, sl, has_pair);
 }
 
 // per-step forward communication of ghost positions (CommBrick::forward_comm, src/comm_brick.cpp:452-512): owned

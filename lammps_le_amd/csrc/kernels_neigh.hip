@@ -243,6 +243,53 @@ static_assert(SPMAX == 4, "neigh_range compares against spi[0..3]");
 // band (a fraction ~1e-4 of the candidates) the FP64 test is repeated on the double positions, so the accepted set is
 // exactly the FP64 one.  (A variant that used FP32 only to reject, confirming every survivor in FP64, was slower:
 // some lane of a wavefront survives in almost every iteration, so both paths executed.)
+// Which end of a pair STORES it in the reference's half neighbor list - the end whose special list gives the pair its
+// special status (npair_half_bin_newtoff.cpp:90-108, npair_half_bin_newton.cpp:84-149; only asked when the special lists
+// are not symmetric, k_build_neigh ASYM):
+//   newton_pair off: an owned-owned pair under the lower LOCAL index (`crank`: Atom::sort / data-file order; nullptr: ID - 1);
+//     a pair that interacts through a periodic image is an owned-ghost pair on BOTH sides, each end stores its own copy.
+//   newton_pair on: the end whose neighbor bin (cutneighmax / 2 bins fitted to the box, nbin_standard.cpp; a ghost's
+//     coordinates lie outside the box, nbin.cpp:120-152) comes first in (z, y, x) order; inside one bin the lower local index,
+//     and for an owned-ghost pair the owned end iff the ghost is not below / behind / left of it (:85-91).
+struct PairOrder {
+  const int *crank;
+  int newton;
+  double lo[3], hi[3], prd[3], half[3], bininv[3];
+  int nbin[3];
+};
+__device__ __forceinline__ int ref_bin(const PairOrder &O, double x, int d) {      // NBin::coord2bin, one dimension
+  if (x >= O.hi[d]) return (int)((x - O.hi[d]) * O.bininv[d]) + O.nbin[d];
+  if (x >= O.lo[d]) return min((int)((x - O.lo[d]) * O.bininv[d]), O.nbin[d] - 1);
+  return (int)((x - O.lo[d]) * O.bininv[d]) - 1;
+}
+// true: the force on bead s from its neighbor q takes the pair's special status from q's list, not from its own
+__device__ __forceinline__ bool pair_stored_by_other(const PairOrder &O, int ts, int tq, const double4 &ri, const double4 &rj) {
+  const double pi[3] = {ri.x, ri.y, ri.z};
+  double pj[3] = {rj.x, rj.y, rj.z};
+  bool image = false;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const double del = pi[d] - pj[d];
+    if (del > O.half[d]) { pj[d] += O.prd[d]; image = true; }
+    else if (del < -O.half[d]) { pj[d] -= O.prd[d]; image = true; }
+  }
+  const int li = O.crank ? O.crank[ts] : ts - 1, lj = O.crank ? O.crank[tq] : tq - 1;
+  if (!O.newton) return image ? false : lj < li;
+#pragma unroll
+  for (int d = 2; d >= 0; d--) {
+    const int bi = ref_bin(O, pi[d], d), bj = ref_bin(O, pj[d], d);
+    if (bi != bj) return bj < bi;
+  }
+  if (!image) return lj < li;
+  // same bin, q is a ghost of s's rank: s stores the pair unless the ghost lies "below" it
+  if (pj[2] < pi[2]) return true;
+  if (pj[2] == pi[2]) {
+    if (pj[1] < pi[1]) return true;
+    if (pj[1] == pi[1] && pj[0] < pi[0]) return true;
+  }
+  return false;
+}
+
 template <bool NOSPECIAL, bool MINIMG, bool ASYM, bool STAGED, bool FRAC>
 __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &ri, const float4 *__restrict__ posf,
                                             float cutf, const double4 *__restrict__ pos,
@@ -253,7 +300,7 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
                                             int sf1, int sf2, int sf3, int npad, int maxneigh,
                                             int *__restrict__ neigh, const int *__restrict__ all_nspecial,
                                             const int *__restrict__ all_special, int ms_, int &cnt, float bandf,
-                                            const float4 *stg, int stg_base) {
+                                            const float4 *stg, int stg_base, const PairOrder &order) {
 #pragma clang fp contract(fast)
   const float rix = (float)ri.x, riy = (float)ri.y, riz = (float)ri.z;
   const float px = (float)box.prd[0], py = (float)box.prd[1], pz = (float)box.prd[2];
@@ -291,11 +338,10 @@ __device__ __forceinline__ void neigh_range(int s, int b, int e, const double4 &
     int entry = q;
     bool own_list = true;
     if (!NOSPECIAL && ASYM) {
-      // half-list semantics of the reference: the pair is stored under the lower local index (= lower ID at the
-      // canonical order), so ITS special list decides (npair_half_bin_newtoff.cpp:90-108)
+      // half-list semantics of the reference: the special list of the end that STORES the pair decides (pair_stored_by_other)
       if (keep) {
         int ts = tag[s], tq = tag[q];
-        if (tq < ts) {
+        if (pair_stored_by_other(order, ts, tq, ri, pos[q])) {
           own_list = false;
           const int *ql = all_special + (size_t)tq * ms_;
           int q1 = all_nspecial[3 * (size_t)tq], q2 = all_nspecial[3 * (size_t)tq + 1], q3 = all_nspecial[3 * (size_t)tq + 2];
@@ -351,7 +397,7 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
                                                        int sf3, const int *__restrict__ bondtab, int bpa,
                                                        const unsigned long long *__restrict__ bshift,
                                                        int *__restrict__ neigh, int *__restrict__ numneigh,
-                                                       int *__restrict__ flags, int diag) {
+                                                       int *__restrict__ flags, int diag, const PairOrder &order) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   bool active = s < n;
   double4 ri = pos[active ? s : 0];
@@ -435,9 +481,9 @@ __device__ __forceinline__ void build_body(int n, int npad, int maxneigh, const 
 #define RANGE_T(B, E, STG, SB)                                                                                    \
   do {                                                                                                            \
     if (all_in) neigh_range<NOSPECIAL, false, ASYM, STG, FRAC>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, \
-                                              sf1, sf2, sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
+                                              sf1, sf2, sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB, order);  \
     else neigh_range<NOSPECIAL, true, ASYM, STG, FRAC>(s, B, E, ri, posf, cutf, pos, tag, box, cutneighsq, n1, n2, kmax, nrel, spi, spc, slist, sf1, sf2, \
-                                      sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB);  \
+                                      sf3, npad, maxneigh_w, neigh, nspecial, special, ms, cnt, bandf, stg, SB, order);  \
   } while (0)
 #define RANGE(B, E) RANGE_T(B, E, false, 0)
   // Pass A: the main index range of all nine (dz,dy) rows, 18 independent loads issued together (the rolled loop
@@ -539,7 +585,25 @@ __global__ __launch_bounds__(BLOCK, BUILD_WAVES_PER_SIMD) void k_build_neigh(int
                                                        const unsigned long long *__restrict__ bshift,
                                                        int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags, int diag) {
-  build_body<NOSPECIAL, ASYM, FRAC>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, bshift, neigh, numneigh, flags, diag);
+  build_body<NOSPECIAL, ASYM, FRAC>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, bshift, neigh, numneigh, flags, diag, PairOrder{});
+}
+// asymmetric special lists: the same body with the order of the reference's half list as an argument (a kernel of its own:
+// the argument list of k_build_neigh is part of what its schedule was tuned with)
+template <bool FRAC>
+__global__ __launch_bounds__(BLOCK, BUILD_WAVES_PER_SIMD) void k_build_neigh_asym(int n, int npad, int maxneigh, const double4 *__restrict__ pos,
+                                                       const float4 *__restrict__ posf, float cutf, float bandf,
+                                                       const int *__restrict__ tag, const int *__restrict__ map,
+                                                       const int *__restrict__ cell_start,
+                                                       const int *__restrict__ gcell_start, int dd, double zlo_ext,
+                                                       int ncx, int ncy, int ncz, double cix, double ciy, double ciz,
+                                                       Box box, double cutneighsq, double margin,
+                                                       const int *__restrict__ nspecial,
+                                                       const int *__restrict__ special, int ms, int sf1, int sf2,
+                                                       int sf3, const int *__restrict__ bondtab, int bpa,
+                                                       const unsigned long long *__restrict__ bshift,
+                                                       int *__restrict__ neigh, int *__restrict__ numneigh,
+                                                       int *__restrict__ flags, PairOrder order) {
+  build_body<false, true, FRAC>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, bshift, neigh, numneigh, flags, 0, order);
 }
 // same body under a second name: LAMMPS_LE_DIAG_BUILD re-runs the build into scratch outputs with parts switched
 // off, so that a profile of a physically unchanged run shows what each part costs
@@ -557,7 +621,7 @@ __global__ __launch_bounds__(BLOCK, BUILD_WAVES_PER_SIMD) void k_build_neigh_dia
                                                        const unsigned long long *__restrict__ bshift,
                                                        int *__restrict__ neigh, int *__restrict__ numneigh,
                                                        int *__restrict__ flags, int diag) {
-  build_body<NOSPECIAL, ASYM, FRAC>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, bshift, neigh, numneigh, flags, diag);
+  build_body<NOSPECIAL, ASYM, FRAC>(n, npad, maxneigh, pos, posf, cutf, bandf, tag, map, cell_start, gcell_start, dd, zlo_ext, ncx, ncy, ncz, cix, ciy, ciz, box, cutneighsq, margin, nspecial, special, ms, sf1, sf2, sf3, bondtab, bpa, bshift, neigh, numneigh, flags, diag, PairOrder{});
 }
 
 // phase 1: wrap owned beads, sort them into cell order (ties by ID), permute the physical arrays.
@@ -649,7 +713,22 @@ void launch_lists(DeviceState &d, double cutneighsq, const double sl[4], bool ha
                      d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, nsp, spl, msp, sf1,  \
                      sf2, sf3, d.bpart, d.bpa, d.bond_minimg ? nullptr : d.bshift, d.neigh, d.numneigh, d.flags, 0)
     if (sf1 == 1 && sf2 == 1 && sf3 == 1) BUILD(true, false, false);
-    else if (d.flags_h[FLAG_SPECIAL_ASYM]) { if (frac) BUILD(false, true, true); else BUILD(false, true, false); }   // sticky flag, read back at the last sync
+    else if (d.flags_h[FLAG_SPECIAL_ASYM]) {      // sticky flag, read back at the last sync
+      PairOrder O{};
+      O.crank = d.ident_order ? (const int *)nullptr : d.crank;
+      O.newton = d.newton_pair;
+      for (int k = 0; k < 3; k++) {
+        O.lo[k] = d.box.lo[k]; O.hi[k] = d.box.hi[k]; O.prd[k] = d.box.prd[k]; O.half[k] = d.box.half[k];
+        O.bininv[k] = d.ref_bininv[k]; O.nbin[k] = d.ref_nbin[k];
+      }
+#define BUILD_ASYM(FR)                                                                                             \
+  hipLaunchKernelGGL((k_build_neigh_asym<FR>), dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.maxneigh, d.pos, d.posf, cutf, bandf, d.tag, d.map, \
+                     d.cell_start, d.gcell_start, ddcode, d.zlo_ext, d.ncell[0], d.ncell[1], d.ncell[2], d.cellinv[0],  \
+                     d.cellinv[1], d.cellinv[2], d.box, cutneighsq, margin, nsp, spl, msp, sf1,  \
+                     sf2, sf3, d.bpart, d.bpa, d.bond_minimg ? nullptr : d.bshift, d.neigh, d.numneigh, d.flags, O)
+      if (frac) BUILD_ASYM(true); else BUILD_ASYM(false);
+#undef BUILD_ASYM
+    }
     else if (frac) BUILD(false, false, true);
     else BUILD(false, false, false);
 #undef BUILD

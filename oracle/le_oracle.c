@@ -72,7 +72,7 @@ struct leo {
   int newton_pair;        /* `newton on|off [bond]`: who stores an owned-owned pair (half/bin/newton vs newtoff); bonds are always newton off */
   long nbuilds, ndanger;
   int brute;              /* image-enumerating path for small boxes */
-  long npairs, maxpairs;
+  long npairs, maxpairs, noneside;
   int *firstneigh;        /* CSR [n+1] (cell path) */
   int *pj;                /* partner local index | special bits << 30 */
   int *pi_;               /* brute path: explicit i */
@@ -557,13 +557,20 @@ static inline int find_special(const leo_t *s, int i, int tagj) {
     }
   return 0;
 }
-static void push_pair(leo_t *s, int i, int j, int which, const signed char *sh) {
+/* list entry: index | ONESIDE << 29 | which << 30.  ONESIDE: an owned-ghost entry of a newton_pair-off list - a pair that
+   interacts through a periodic image is stored by BOTH owned ends (each with the ghost image of the other, its own special
+   status, force and half the energy / virial to the owned end only: pair_lj_cut.cpp:118-122, pair.cpp ev_tally) */
+#define PJ_INDEX(e) ((e) & 0x1FFFFFFF)
+#define PJ_ONESIDE(e) (((e) >> 29) & 1)
+#define PJ_WHICH(e) (((e) >> 30) & 3)
+static void push_pair(leo_t *s, int i, int j, int which, const signed char *sh, int oneside) {
   if (s->npairs == s->maxpairs) {
     s->maxpairs = s->maxpairs ? 2 * s->maxpairs : 1024;
     s->pj = realloc(s->pj, s->maxpairs * sizeof(int));
     if (s->brute) { s->pi_ = realloc(s->pi_, s->maxpairs * sizeof(int)); s->pshift = realloc(s->pshift, 3 * s->maxpairs); }
   }
-  s->pj[s->npairs] = j | (which << 30);
+  s->pj[s->npairs] = j | (oneside << 29) | (which << 30);
+  if (oneside) s->noneside++;
   if (s->brute) { s->pi_[s->npairs] = i; memcpy(s->pshift + 3 * s->npairs, sh, 3); }
   s->npairs++;
 }
@@ -749,6 +756,30 @@ static void ref_bin(const leo_t *s, const double *x, int *b) {
     b[d] = i;
   }
 }
+/* NBin::coord2bin for any coordinate (src/nbin.cpp:120-152): a ghost image lies outside the box, in the bins beyond it */
+static void ref_bin_any(const leo_t *s, const double *x, int *b) {
+  double binsizeinv = 1.0 / (0.5 * s->cutneighmax);
+  for (int d = 0; d < 3; d++) {
+    int nb = (int)(s->prd[d] * binsizeinv); if (nb == 0) nb = 1;
+    double bininv = 1.0 / (s->prd[d] / nb), hi = s->lo[d] + s->prd[d];
+    if (x[d] >= hi) b[d] = (int)((x[d] - hi) * bininv) + nb;
+    else if (x[d] >= s->lo[d]) { int i = (int)((x[d] - s->lo[d]) * bininv); b[d] = i > nb - 1 ? nb - 1 : i; }
+    else b[d] = (int)((x[d] - s->lo[d]) * bininv) - 1;
+  }
+}
+/* newton_pair on, owned i and the GHOST image of j at x_j + sh * prd: i stores the pair iff the ghost's bin is one of the
+   upper-half stencil bins of i's (npair_half_bin_newton.cpp:120-149), or - same bin - the ghost is not below / behind /
+   left of i (:85-91); otherwise the owner of j stores it with the ghost image of i */
+static int stores_image_pair(const leo_t *s, int i, int j, const signed char *sh) {
+  double g[3]; int bi[3], bj[3];
+  for (int d = 0; d < 3; d++) g[d] = s->xhold[3 * j + d] + sh[d] * s->prd[d];
+  ref_bin_any(s, s->xhold + 3 * i, bi); ref_bin_any(s, g, bj);
+  for (int d = 2; d >= 0; d--) if (bi[d] != bj[d]) return bi[d] < bj[d];
+  const double *xi = s->xhold + 3 * i;
+  if (g[2] < xi[2]) return 0;
+  if (g[2] == xi[2]) { if (g[1] < xi[1]) return 0; if (g[1] == xi[1] && g[0] < xi[0]) return 0; }
+  return 1;
+}
 static int stores_pair(const leo_t *s, int i, int j) {          /* 1: i is the storing end of (i, j) */
   if (!s->newton_pair) return i < j;
   int bi[3], bj[3];
@@ -761,7 +792,7 @@ static void neigh_build(leo_t *s) {
   int n = s->n;
   s->ago = 0; s->nbuilds++;
   memcpy(s->xhold, s->x, 3 * n * sizeof(double));
-  s->npairs = 0;
+  s->npairs = 0; s->noneside = 0;
   double cutneighsq = s->cutneighmax * s->cutneighmax;
   int nc[3]; s->brute = 0;
   if (!s->pair_on || s->cutneighmax <= 0.0) { build_bondlist(s); build_anglelist(s); return; }
@@ -772,8 +803,15 @@ static void neigh_build(leo_t *s) {
   if (s->brute) {
     /* small periodic boxes (unit-test systems): enumerate the 27 images explicitly, like ghost atoms */
     for (int i = 0; i < n; i++)
-      for (int j = i + 1; j < n; j++)
+      for (int j = 0; j < n; j++)
         for (int sx = -1; sx <= 1; sx++) for (int sy = -1; sy <= 1; sy++) for (int sz = -1; sz <= 1; sz++) {
+          if (j == i) continue;
+          signed char sh[3] = { (signed char)sx, (signed char)sy, (signed char)sz };
+          const int image = sx || sy || sz;
+          int oneside = 0;
+          if (!image) { if (!stores_pair(s, i, j)) continue; }
+          else if (!s->newton_pair) oneside = 1;
+          else if (!stores_image_pair(s, i, j, sh)) continue;
           double dx = s->x[3 * i] - (s->x[3 * j] + sx * s->prd[0]);
           double dy = s->x[3 * i + 1] - (s->x[3 * j + 1] + sy * s->prd[1]);
           double dz = s->x[3 * i + 2] - (s->x[3 * j + 2] + sz * s->prd[2]);
@@ -783,8 +821,7 @@ static void neigh_build(leo_t *s) {
           /* src/domain.h:156-161 minimum_image_check */
           if (which != 0 && (fabs(dx) > 0.5 * s->prd[0] || fabs(dy) > 0.5 * s->prd[1] || fabs(dz) > 0.5 * s->prd[2])) which = 0;
           if (which < 0) continue;
-          signed char sh[3] = { (signed char)sx, (signed char)sy, (signed char)sz };
-          push_pair(s, i, j, which, sh);
+          push_pair(s, i, j, which, sh, oneside);
         }
     build_bondlist(s); build_anglelist(s);
     return;
@@ -818,14 +855,20 @@ static void neigh_build(leo_t *s) {
       int c = (az * nc[1] + ay) * nc[0] + ax;
       for (int p = head[c]; p < head[c + 1]; p++) {
         int j = order[p];
-        if (j == i || !stores_pair(s, i, j)) continue;
+        if (j == i) continue;
         double d[3] = { xi - s->x[3 * j], yi - s->x[3 * j + 1], zi - s->x[3 * j + 2] };
         signed char sh[3]; minimg(s, d, sh);
+        /* who stores the pair: an owned-owned pair one end (stores_pair); a pair through a periodic image is an owned-ghost
+           pair - both ends with newton_pair off, the end whose stencil reaches the ghost with newton_pair on */
+        int oneside = 0;
+        if (!(sh[0] || sh[1] || sh[2])) { if (!stores_pair(s, i, j)) continue; }
+        else if (!s->newton_pair) oneside = 1;
+        else if (!stores_image_pair(s, i, j, sh)) continue;
         double rsq = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
         if (rsq > cutneighsq) continue;
         int which = find_special(s, i, s->tag[j]);
         if (which < 0) continue;
-        push_pair(s, i, j, which, sh);
+        push_pair(s, i, j, which, sh, oneside);
       }
     }
   }
@@ -861,7 +904,8 @@ static void pair_compute(leo_t *s, int eflag) {
   const double *x = s->x; double *f = s->f;
   if (s->brute) {
     for (long p = 0; p < s->npairs; p++) {
-      int i = s->pi_[p], j = s->pj[p]; double factor = s->special_lj[(j >> 30) & 3]; j &= 0x3FFFFFFF;
+      int i = s->pi_[p], j = s->pj[p]; double factor = s->special_lj[PJ_WHICH(j)]; const int one = PJ_ONESIDE(j); j = PJ_INDEX(j);
+      const double w = one ? 0.5 : 1.0;
       const signed char *sh = s->pshift + 3 * p;
       double dx = x[3 * i] - (x[3 * j] + sh[0] * s->prd[0]);
       double dy = x[3 * i + 1] - (x[3 * j + 1] + sh[1] * s->prd[1]);
@@ -873,12 +917,12 @@ static void pair_compute(leo_t *s, int eflag) {
         double forcelj = r6inv * (s->lj1[ij] * r6inv - s->lj2[ij]);
         double fpair = factor * forcelj * r2inv;
         f[3 * i] += dx * fpair; f[3 * i + 1] += dy * fpair; f[3 * i + 2] += dz * fpair;
-        f[3 * j] -= dx * fpair; f[3 * j + 1] -= dy * fpair; f[3 * j + 2] -= dz * fpair;
+        if (!one) { f[3 * j] -= dx * fpair; f[3 * j + 1] -= dy * fpair; f[3 * j + 2] -= dz * fpair; }
         if (eflag) {
           double e = r6inv * (s->lj3[ij] * r6inv - s->lj4[ij]) - s->offset[ij];
-          s->evdwl += factor * e;
-          s->vpair[0] += dx * dx * fpair; s->vpair[1] += dy * dy * fpair; s->vpair[2] += dz * dz * fpair;
-          s->vpair[3] += dx * dy * fpair; s->vpair[4] += dx * dz * fpair; s->vpair[5] += dy * dz * fpair;
+          s->evdwl += w * factor * e;
+          s->vpair[0] += w * dx * dx * fpair; s->vpair[1] += w * dy * dy * fpair; s->vpair[2] += w * dz * dz * fpair;
+          s->vpair[3] += w * dx * dy * fpair; s->vpair[4] += w * dx * dz * fpair; s->vpair[5] += w * dy * dz * fpair;
         }
       }
     }
@@ -890,7 +934,8 @@ static void pair_compute(leo_t *s, int eflag) {
     int ti = s->type[i];
     double fx = 0, fy = 0, fz = 0;
     for (int p = s->firstneigh[i]; p < s->firstneigh[i + 1]; p++) {
-      int j = s->pj[p]; double factor = s->special_lj[(j >> 30) & 3]; j &= 0x3FFFFFFF;
+      int j = s->pj[p]; double factor = s->special_lj[PJ_WHICH(j)]; const int one = PJ_ONESIDE(j); j = PJ_INDEX(j);
+      const double w = one ? 0.5 : 1.0;
       double dx = xi - x[3 * j], dy = yi - x[3 * j + 1], dz = zi - x[3 * j + 2];
       if (dx > hx) dx -= s->prd[0]; else if (dx < -hx) dx += s->prd[0];
       if (dy > hy) dy -= s->prd[1]; else if (dy < -hy) dy += s->prd[1];
@@ -902,12 +947,12 @@ static void pair_compute(leo_t *s, int eflag) {
         double forcelj = r6inv * (s->lj1[ij] * r6inv - s->lj2[ij]);
         double fpair = factor * forcelj * r2inv;
         fx += dx * fpair; fy += dy * fpair; fz += dz * fpair;
-        f[3 * j] -= dx * fpair; f[3 * j + 1] -= dy * fpair; f[3 * j + 2] -= dz * fpair;
+        if (!one) { f[3 * j] -= dx * fpair; f[3 * j + 1] -= dy * fpair; f[3 * j + 2] -= dz * fpair; }
         if (eflag) {
           double e = r6inv * (s->lj3[ij] * r6inv - s->lj4[ij]) - s->offset[ij];
-          s->evdwl += factor * e;
-          s->vpair[0] += dx * dx * fpair; s->vpair[1] += dy * dy * fpair; s->vpair[2] += dz * dz * fpair;
-          s->vpair[3] += dx * dy * fpair; s->vpair[4] += dx * dz * fpair; s->vpair[5] += dy * dz * fpair;
+          s->evdwl += w * factor * e;
+          s->vpair[0] += w * dx * dx * fpair; s->vpair[1] += w * dy * dy * fpair; s->vpair[2] += w * dz * dz * fpair;
+          s->vpair[3] += w * dx * dy * fpair; s->vpair[4] += w * dx * dz * fpair; s->vpair[5] += w * dy * dz * fpair;
         }
       }
     }
@@ -1291,10 +1336,10 @@ static int in_pair_list(const leo_t *s, int i, int j) {
   if (!s->pair_on) return 0;
   if (s->brute) {
     for (long p = 0; p < s->npairs; p++)
-      if (s->pi_[p] == i && (s->pj[p] & 0x3FFFFFFF) == j && !s->pshift[3 * p] && !s->pshift[3 * p + 1] && !s->pshift[3 * p + 2]) return 1;
+      if (s->pi_[p] == i && PJ_INDEX(s->pj[p]) == j && !s->pshift[3 * p] && !s->pshift[3 * p + 1] && !s->pshift[3 * p + 2]) return 1;
     return 0;
   }
-  for (int p = s->firstneigh[i]; p < s->firstneigh[i + 1]; p++) if ((s->pj[p] & 0x3FFFFFFF) == j) return 1;
+  for (int p = s->firstneigh[i]; p < s->firstneigh[i + 1]; p++) if (PJ_INDEX(s->pj[p]) == j && !PJ_ONESIDE(s->pj[p])) return 1;
   return 0;
 }
 static int fire_ex_load(leo_t *s, leo_fix *fx) {
@@ -1398,7 +1443,7 @@ static int fire_bond_create(leo_t *s, leo_fix *fx) {
     for (int i = 0; i < n; i++) {
       int itype = s->type[i];
       for (int p = s->firstneigh[i]; p < s->firstneigh[i + 1]; p++) {
-        int j = s->pj[p] & 0x3FFFFFFF;
+        int j = PJ_INDEX(s->pj[p]);
         int jtype = s->type[j], possible = 0;
         if (itype == fx->iatomtype && jtype == fx->jatomtype) {
           if ((fx->imaxbond == 0 || s->bondcount[i] < fx->imaxbond) && (fx->jmaxbond == 0 || s->bondcount[j] < fx->jmaxbond)) possible = 1;
@@ -1765,7 +1810,7 @@ void leo_fix_vector(leo_t *s, int k, double *o) {
   o[1] = (s->fix[k].kind == FIX_EXTRUSION) ? 0.0 : (double)s->fix[k].totalcount;  /* fix_extrusion.cpp:1496-1501 */
 }
 long leo_neigh_builds(leo_t *s) { return s->nbuilds; }
-long leo_neigh_pairs(leo_t *s) { return s->npairs; }
+long leo_neigh_pairs(leo_t *s) { return s->npairs - s->noneside / 2; }   /* (an owned-ghost pair is listed by both of its owned ends) */
 long leo_fene_warnings(leo_t *s) { return s->fene_warn; }
 void leo_timers(leo_t *s, double *o) {
   o[0] = s->t_pair; o[1] = s->t_bond; o[2] = s->t_neigh; o[3] = s->t_modify;

@@ -1,0 +1,109 @@
+"""Second randomised parity sweep: the LE fixes under everything else that changes what they see - local order (`atom_modify
+sort N`, `newton on off`), r-RESPA, angles (`ex_load ... atype`, angle breaking in ex_unload), second instances of the
+loader / unloader, type conversion at the bond limit, and runs cut into several `run` commands.  Product (HIP) against the
+oracle: bond tables, special lists, fix counters, angle tables, reneighbor count bit for bit, positions to 1e-6.
+The suite runs a fixed set of seeds; LE_FUZZ2_SEEDS="start:stop" runs a one-off wider sweep (scripts/r03_fuzz_wide.sh)."""
+import os
+
+import numpy as np
+import pytest
+
+from systems import CHAIN_SCRIPT, run_oracle, run_product
+from test_gpu_le import barrier_types, compare, melted
+
+pytestmark = pytest.mark.gpu
+
+RESPA = ["run_style respa 2 4", "run_style respa 3 2 2 bond 1 pair 3", "run_style respa 2 3 bond 2 pair 2"]
+
+
+def _seeds():
+    v = os.environ.get("LE_FUZZ2_SEEDS")
+    if not v:
+        return list(range(24))
+    a, b = v.split(":")
+    return range(int(a), int(b))
+
+
+def scenario(seed):
+    rng = np.random.RandomState(7000 + seed)
+    n = int(rng.choice([1500, 2400, 3600]))
+    nchains = int(rng.choice([1, 3]))
+    frac = float(rng.choice([0.0, 0.15, 0.4]))
+    types = barrier_types(n, 90 + seed, frac=frac) if frac > 0 else np.ones(n, dtype=np.int32)
+    s = melted(n, nchains=nchains, seed=1 + seed % 2, steps=600, types=types)
+    s["ntypes"], s["mass"] = 4, [1.0] * 4
+    flavour = str(rng.choice(["plain", "sort", "newton", "sort+newton", "respa", "angles", "angles", "convert"]))
+    base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 6.0 8.0 1.0 1.0")
+    if "sort" in flavour:
+        base = base.replace("atom_modify sort 0 0", "atom_modify sort %d 0" % int(rng.randint(3, 16)))
+    if "newton" in flavour:
+        base = base.replace("newton off", "newton on off")
+    angle_lines, atype = "", ""
+    if flavour == "angles":
+        per = n // nchains
+        ang = [(1, i, i + 1, i + 2) for i in range(1, n - 1) if (i - 1) // per == (i + 1) // per]
+        s["nangletypes"], s["angles"], s["extra_angle"] = 2, np.array(ang, dtype=np.int32), 24
+        s["atom_style"] = "molecular"
+        base = base.replace("atom_style bond", "atom_style molecular")
+        if rng.rand() < 0.5:
+            angle_lines = "angle_style harmonic\nangle_coeff 1 %.2f %.1f\nangle_coeff 2 %.2f %.1f\n" % (
+                rng.uniform(0.5, 4.0), rng.uniform(120.0, 180.0), rng.uniform(0.5, 2.0), rng.uniform(90.0, 150.0))
+        else:
+            angle_lines = "angle_style cosine\nangle_coeff 1 %.2f\nangle_coeff 2 %.2f\n" % (rng.uniform(0.5, 3.0), rng.uniform(0.2, 1.5))
+        atype = str(rng.choice(["", " atype 1", " atype 2"]))
+    n1, nl, nu = int(rng.randint(3, 10)), int(rng.randint(3, 10)), int(rng.randint(3, 10))
+    tp = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
+    lp, up = float(rng.choice([0.2, 0.6, 1.0])), float(rng.choice([0.1, 0.5, 1.0]))
+    lprob = "" if lp >= 1.0 else "prob %g %d" % (lp, 100 + seed)
+    uprob = "" if up >= 1.0 else "prob %g %d" % (up, 200 + seed)
+    rmax = float(rng.choice([0.5, 1.3, 2.0]))
+    lr = "4" if rng.rand() < 0.7 else ""
+    iparam = "iparam 1 1 jparam 1 1"
+    if flavour == "convert":          # beads at their bond limit change type (and stop being loadable / become barriers)
+        nt = int(rng.choice([1, 2, 3, 4]))     # (itype == jtype: the reference insists on equal limits and new types for both ends)
+        iparam = "iparam 1 %d jparam 1 %d" % (nt, nt)
+    fixes = ["fix 1 all nve", "fix 2 all langevin 1.0 1.0 1.0 %d" % int(rng.randint(1, 900000)),
+             "fix loop all extrusion %d 1 2 3 %g 2 %s" % (n1, tp, lr),
+             "fix loading all ex_load %d 1 1 1.12 2 %s %s%s" % (nl, lprob, iparam, atype),
+             "fix unloading all ex_unload %d 2 %g %s" % (nu, rmax, uprob)]
+    ids = ["loop", "loading", "unloading"]
+    if rng.rand() < 0.3:
+        fixes.append("fix loading2 all ex_load %d 1 1 1.1 2 prob 0.4 %d iparam 1 1 jparam 1 1%s" % (int(rng.randint(4, 12)), 300 + seed, atype))
+        ids.append("loading2")
+    if rng.rand() < 0.3:
+        fixes.append("fix unloading2 all ex_unload %d 2 0.9 prob 0.3 %d" % (int(rng.randint(5, 14)), 400 + seed))
+        ids.append("unloading2")
+    tail = "thermo 10\n"
+    if flavour == "respa":
+        tail += str(rng.choice(RESPA)) + "\n"
+    total = int(rng.randint(40, 110))
+    cuts = sorted(set(int(c) for c in rng.randint(1, total, size=int(rng.randint(0, 3)))))
+    runs, last = [], 0
+    for c in cuts + [total]:
+        runs.append(c - last)
+        last = c
+    script = base + angle_lines + "\n".join(fixes) + "\n" + tail + "".join("run %d\n" % r for r in runs if r > 0)
+    return s, script, ids, flavour
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_le_scenarios_mixed(tmp_path, seed):
+    s, script, ids, flavour = scenario(seed)
+    try:
+        o = run_oracle(script, s)
+    except RuntimeError:           # the oracle stops on this parameter set (Bad FENE bond, a full special list ..): so must the product
+        from lammps_le_amd import LammpsError
+        with pytest.raises(LammpsError):
+            run_product(script, s, tmp_path)
+        return
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ids)
+    assert p.stat("neigh_builds") == o.neigh_builds(), flavour
+    if flavour == "angles":
+        na, at, a1, a2, a3 = o.angle_table()
+        assert (p.gather("num_angle") == na).all()
+        for name, ref in (("angle_type", at), ("angle_atom1", a1), ("angle_atom2", a2), ("angle_atom3", a3)):
+            got = p.gather(name)
+            for i in np.nonzero(na)[0]:
+                assert list(got[i, :na[i]]) == list(ref[i, :na[i]]), (name, i + 1)
+        assert p.extract_setting("nangles") == o.nangles()
