@@ -854,11 +854,15 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 // The angle list (NTopoAngleAll::build with newton_bond off, src/ntopo_angle_all.cpp:55-76): the copy atom i stores is
 // listed iff i has the lowest local index of the three atoms, and a listed angle moves all three.  One thread per atom
 // appends its listed copies to the three atoms' records; a second kernel sorts each atom's records (central atom, ends,
-// type), so that what a bead sums, and in which order, depends on nothing but the topology.  (An angle across a periodic
-// face is listed once here and moves all three atoms, which is what the reference's per-image listings add up to as long
-// as all three atoms hold their copies.)
+// type), so that what a bead sums, and in which order, depends on nothing but the topology.  An angle across a periodic
+// face: seen from the listing atom i the atoms on the other side are ghost images (Domain::closest_image, index >= nlocal),
+// which never block a listing and which the listing does not move (newton_bond off: forces go to owned atoms only,
+// angle_harmonic.cpp:121-137) - so the copy on i is listed iff i has the lowest local index among the atoms on ITS side, and
+// its record goes to those atoms only; the atoms on the other side are moved by the listings of their own copies.  With all
+// copies in place that adds up to one evaluation per atom, with copies out of step it is what the reference computes
+// (found by the mixed sweep, tests/test_gpu_fuzz2.py seeds 17, 74, 125).
 __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, int npad, const int *__restrict__ crank,
-                                                      const int *__restrict__ map,
+                                                      const int *__restrict__ map, const double4 *__restrict__ pos, Box box,
                                                       const int *__restrict__ num_angle, const int *__restrict__ angle_type,
                                                       const int *__restrict__ a1, const int *__restrict__ a2,
                                                       const int *__restrict__ a3, int *__restrict__ eff_n,
@@ -870,15 +874,22 @@ __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, 
   for (int m = 0; m < na; m++) {
     const size_t c = (size_t)i * apa + m;
     const int t[3] = {a1[c], a2[c], a3[c]};
-    bool listed = true;
-    for (int q = 0; q < 3; q++) listed = listed && li <= (crank ? crank[t[q]] : t[q]);
-    if (!listed) continue;
     // records hold PHYSICAL indices (this list lives until the next reneighbor, like the indices) and sit column-major by
     // the bead's own index: the force kernel reads them coalesced and gathers positions without a tag -> index lookup
     const int p[3] = {map[t[0]], map[t[1]], map[t[2]]};
-    if (p[0] < 0 || p[1] < 0 || p[2] < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
+    const int pi = map[i];
+    if (p[0] < 0 || p[1] < 0 || p[2] < 0 || pi < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
+    const double4 ri = pos[pi];
+    bool listed = true, ghost[3];
+    for (int q = 0; q < 3; q++) {
+      const double4 rq = pos[p[q]];
+      ghost[q] = fabs(ri.x - rq.x) > box.half[0] || fabs(ri.y - rq.y) > box.half[1] || fabs(ri.z - rq.z) > box.half[2];
+      listed = listed && (ghost[q] || li <= (crank ? crank[t[q]] : t[q]));
+    }
+    if (!listed) continue;
     const int4 rec = make_int4(angle_type[c], p[0], p[1], p[2]);
     for (int q = 0; q < 3; q++) {
+      if (ghost[q]) continue;
       const int slot = atomicAdd(&eff_n[p[q]], 1);
       if (slot >= ecap) { flags[FLAG_ERROR] = ERR_ANGLES; continue; }
       eff_rec[(size_t)slot * npad + p[q]] = rec;
@@ -915,7 +926,7 @@ void launch_angle_list(DeviceState &d) {
   const int T = d.maxtag, nb = std::max(1, (T + BLOCK - 1) / BLOCK);
   HIP_CHECK(hipMemsetAsync(d.eff_n, 0, (size_t)d.npad * sizeof(int), d.stream));
   hipLaunchKernelGGL(k_angle_list, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, d.ecap, d.npad, d.ident_order ? (const int *)nullptr : d.crank,
-                     d.map, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
+                     d.map, d.pos, d.box, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
   hipLaunchKernelGGL(k_angle_sort, dim3(std::max(1, (d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.npad, d.eff_n,
                      (int4 *)d.eff_rec);
 }
