@@ -271,6 +271,11 @@ class OracleScript:
                         k += 2
                         continue
                     k += 3
+                # fix_ex_load.cpp:130-133 / fix_bond_create.cpp:153-156: one atom type at both ends must come with one set of limits
+                inew = kw["inew"] if kw["inew"] is not None else int(p[1])
+                jnew = kw["jnew"] if kw["jnew"] is not None else int(p[2])
+                if int(p[1]) == int(p[2]) and (kw["imax"] != kw["jmax"] or inew != jnew):
+                    raise RuntimeError("Inconsistent iparam/jparam values in fix %s command" % style)
                 (o.fix_ex_load if style == "ex_load" else o.fix_bond_create)(int(p[0]), int(p[1]), int(p[2]), float(p[3]), int(p[4]), fid=fid, **kw)
                 if atype:
                     o.ex_load_atype(fid, atype)
