@@ -27,6 +27,8 @@ def _seeds():
 def scenario(seed):
     rng = np.random.RandomState(7000 + seed)
     n = int(rng.choice([1500, 2400, 3600]))
+    if os.environ.get("LE_FUZZ2_N"):       # one-off sweeps at sizes that take the throughput shapes of the kernels (> 64k beads:
+        n = int(os.environ["LE_FUZZ2_N"])  # one lane per bead, energy variant on thermo steps, bond table by the permute pass)
     nchains = int(rng.choice([1, 3]))
     frac = float(rng.choice([0.0, 0.15, 0.4]))
     types = barrier_types(n, 90 + seed, frac=frac) if frac > 0 else np.ones(n, dtype=np.int32)
