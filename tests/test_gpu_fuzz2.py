@@ -53,6 +53,17 @@ def scenario(seed):
         else:
             angle_lines = "angle_style cosine\nangle_coeff 1 %.2f\nangle_coeff 2 %.2f\n" % (rng.uniform(0.5, 3.0), rng.uniform(0.2, 1.5))
         atype = str(rng.choice(["", " atype 1", " atype 2"]))
+    # (drawn behind everything above, so that the seeds of the first 600-seed sweep keep their scenarios when the three
+    #  below stay at their defaults)
+    rng2 = np.random.RandomState(17000 + seed)
+    if rng2.rand() < 0.5:         # the reneighbor cadence the LE fixes' forced rebuilds cut into
+        base = base.replace("neigh_modify every 1 delay 1 check yes", "neigh_modify every %d delay %d check %s" % (
+            int(rng2.choice([1, 1, 2])), int(rng2.choice([0, 2, 5, 10])), str(rng2.choice(["yes", "yes", "no"]))))
+    if rng2.rand() < 0.3:         # extruder bonds as harmonic springs (bond hybrid): their partner image is frozen at the rebuild
+        base = base.replace("bond_style fene", "bond_style hybrid fene harmonic").replace("bond_coeff 1 30.0 1.5 1.0 1.0", "bond_coeff 1 fene 30.0 1.5 1.0 1.0") \
+            .replace("bond_coeff 2 6.0 8.0 1.0 1.0", "bond_coeff 2 harmonic %g %g" % (rng2.uniform(2.0, 8.0), rng2.uniform(1.0, 2.0)))
+    if rng2.rand() < 0.3:         # special weights other than the FENE set (fractional: list entries carry the level)
+        base = base.replace("special_bonds fene", "special_bonds lj %s" % str(rng2.choice(["0 1 1", "1 1 1", "0 0.5 1", "0.5 0.5 0.5", "0 0 1"])))
     n1, nl, nu = int(rng.randint(3, 10)), int(rng.randint(3, 10)), int(rng.randint(3, 10))
     tp = float(rng.choice([0.0, 0.3, 0.7, 1.0]))
     lp, up = float(rng.choice([0.2, 0.6, 1.0])), float(rng.choice([0.1, 0.5, 1.0]))
