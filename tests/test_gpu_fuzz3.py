@@ -163,3 +163,41 @@ def test_random_md_settings(tmp_path, seed):
         assert abs(p.get_thermo(key) - to[k]) <= 1e-8 * max(1.0, abs(to[k])), key
     assert p.stat("neigh_builds") == o.neigh_builds()
     assert p.stat("neigh_pairs") == 2 * o.neigh_pairs()
+
+
+@pytest.mark.parametrize("seed", _seeds("LE_FUZZ3_RESTART_SEEDS", 8))
+def test_random_restart_continuity(tmp_path, seed):
+    """A mixed LE scenario (test_gpu_fuzz2.py; not the angle and r-RESPA ones, which write_restart refuses / which is not a
+    fix) cut at a random step by write_restart + read_restart into a NEW instance: bit-identical to the uninterrupted run of the
+    same two `run` commands - positions, velocities, images, types, bonds, special lists, fix counters - whatever the local
+    order (`atom_modify sort N`: the sorted order and the next sort step are part of the state), and equal to the oracle."""
+    from lammps_le_amd import lammps
+    from test_gpu_fuzz2 import scenario
+    s, script, ids, flavour = scenario(seed)
+    if flavour in ("angles", "respa"):
+        pytest.skip("no restart for this flavour")
+    lines = [ln for ln in script.split("\n") if not ln.startswith("run ")]
+    total = sum(int(ln.split()[1]) for ln in script.split("\n") if ln.startswith("run "))
+    rng = np.random.RandomState(23000 + seed)
+    a_steps = int(rng.randint(1, total))
+    head = "\n".join(lines) + "\n"
+    later = "\n".join(ln for ln in lines if ln.startswith(("fix ", "thermo "))) + "\n"
+    full = head + "run %d\nrun %d\n" % (a_steps, total - a_steps)
+    try:
+        o = run_oracle(full, s)
+    except RuntimeError:
+        pytest.skip("the oracle stops on this parameter set")
+    a = run_product(full, s, tmp_path)
+    rfile = str(tmp_path / "state.restart")
+    b1 = run_product(head + "run %d\nwrite_restart %s\n" % (a_steps, rfile), s, tmp_path)
+    b1.close()
+    b = lammps(cmdargs=["-screen", "none"])
+    b.command("read_restart " + rfile)
+    for ln in (later + "run %d\n" % (total - a_steps)).split("\n"):
+        b.command(ln)
+    for name in ("x", "v", "image", "type", "num_bond", "bond_type", "bond_atom", "nspecial", "special"):
+        assert np.array_equal(a.gather(name), b.gather(name)), (name, flavour)
+    for fid in ids:
+        assert a.extract_fix(fid, 0, 1, 0) == b.extract_fix(fid, 0, 1, 0) and a.extract_fix(fid, 0, 1, 1) == b.extract_fix(fid, 0, 1, 1), fid
+    assert b.bond_set() == o.bond_set() and np.abs(b.gather("x") - o.x()).max() < 1e-6
+    b.close()
