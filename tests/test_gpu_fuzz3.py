@@ -29,6 +29,9 @@ def dd_scenario(seed):
     rng = np.random.RandomState(9000 + seed)
     world = int(rng.choice([2, 2, 3]))
     n = int(rng.choice([9000, 11000])) if world == 2 else 27000     # slabs must be two 5.0 ghost shells thick
+    if os.environ.get("LE_FUZZ3_WORLD"):                            # one-off sweeps on more slabs
+        world = int(os.environ["LE_FUZZ3_WORLD"])
+        n = {2: 9000, 3: 27000, 4: 58000, 5: 110000, 6: 190000}[world]
     nchains = int(rng.choice([1, 3]))
     frac = float(rng.choice([0.0, 0.15, 0.4]))
     types = barrier_types(n, 190 + seed, frac=frac) if frac > 0 else np.ones(n, dtype=np.int32)

@@ -134,7 +134,13 @@ def test_stock_bond_create_sticky_beads(tmp_path, prob):
     assert (o.types() == 3).sum() >= 2 * o.fix_vector("creating")[1] - 2 * o.fix_vector("breaking")[1]
 
 
-@pytest.mark.parametrize("seed", range(6))
+def _stock_seeds():
+    import os
+    v = os.environ.get("LE_STOCK_SEEDS")          # "start:stop": one-off wider sweep
+    return range(*[int(a) for a in v.split(":")]) if v else range(6)
+
+
+@pytest.mark.parametrize("seed", _stock_seeds())
 def test_stock_bond_create_randomised(tmp_path, seed):
     """bond/create between two DIFFERENT types with unequal bond limits and new types, random cadence and probability;
     natural reneighbor schedule (the fix scans the pair list of the last build)."""
