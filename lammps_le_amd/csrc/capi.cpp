@@ -279,6 +279,7 @@ double lammps_le_stat(void *handle, const char *name) {
   if (k == "comm_bytes_allgather") return e->comm ? e->comm->bytes_allgather : 0.0;
   if (k == "comm_bytes_allreduce") return e->comm ? e->comm->bytes_allreduce : 0.0;
   if (k == "halo_window_mismatches") return e->dev ? (double)dd_halo_mismatches(*e->dev) : 0.0;   // LAMMPS_LE_FAST_HALO_VERIFY
+  if (k == "special_asym") return e->dev ? (double)e->dev->flags_h[FLAG_SPECIAL_ASYM] : 0.0;   // some 1-2 list lost an entry its partner still has (sticky)
   if (k == "halo_fused") return e->dev && e->dev->fast_halo && e->dev->halo_fused ? 1.0 : 0.0;   // counters + window copy in one launch
   if (k == "halo_window_exchanges") return e->dev ? (double)e->dev->halo_seq : 0.0;   // per-step halos that went through the peer windows
   if (k == "pair_kernel_ms") return e->kstat_ms;

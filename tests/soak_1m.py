@@ -29,6 +29,6 @@ for k in range(blocks):
         lmp.command("run 20000")
     except Exception as e:
         print("aborted in block %d: %s" % (k + 1, e)); break
-    print("step %d T %.4f epair %.4f emol %.4f press %.4f bonds %d fene_warn %d builds %d  (%.1f s)" % (
+    print("step %d T %.4f epair %.4f emol %.4f press %.4f bonds %d fene_warn %d builds %d asym_special_lists %d  (%.1f s)" % (
         (k + 1) * 20000, lmp.get_thermo("temp"), lmp.get_thermo("epair"), lmp.get_thermo("emol"), lmp.get_thermo("press"),
-        lmp.get_thermo("bonds"), lmp.stat("fene_warnings"), lmp.stat("neigh_builds"), time.time() - t0), flush=True)
+        lmp.get_thermo("bonds"), lmp.stat("fene_warnings"), lmp.stat("neigh_builds"), lmp.stat("special_asym"), time.time() - t0), flush=True)
