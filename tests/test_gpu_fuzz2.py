@@ -95,7 +95,23 @@ def scenario(seed):
     for c in cuts + [total]:
         runs.append(c - last)
         last = c
-    script = base + angle_lines + "\n".join(fixes) + "\n" + tail + "".join("run %d\n" % r for r in runs if r > 0)
+    # commands between two `run`s (every `run` re-runs setup: new lists, forces, fix setup)
+    runs = [r for r in runs if r > 0]
+    body = ""
+    for k, r in enumerate(runs):
+        body += "run %d\n" % r
+        if k + 1 < len(runs) and rng2.rand() < 0.5:
+            what = str(rng2.choice(["reset", "velocity", "timestep", "neigh"]))
+            if what == "reset":          # shifts the phase of every firing period (and of the next Atom::sort)
+                body += "reset_timestep %d\n" % int(rng2.choice([0, 7, 100, 1000]))
+            elif what == "velocity":
+                body += "velocity all create %g %d %s\n" % (rng2.uniform(0.5, 1.5), int(rng2.randint(1, 900000)),
+                                                             str(rng2.choice(["dist gaussian", "loop local", ""])))
+            elif what == "timestep":
+                body += "timestep %g\n" % float(rng2.choice([0.003, 0.004, 0.006]))
+            else:
+                body += "neigh_modify every 1 delay %d check yes\n" % int(rng2.choice([0, 1, 3]))
+    script = base + angle_lines + "\n".join(fixes) + "\n" + tail + body
     return s, script, ids, flavour
 
 
