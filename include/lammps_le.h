@@ -62,7 +62,12 @@ int  lammps_has_style(void *handle, const char *category, const char *name);
 
 /* engine-specific introspection (no reference counterpart; used by bench.py / tests):
  * name = "loop_time", "neigh_builds", "pair_kernel_ms" (mean HIP-event duration of the force kernel
- * over the last run), "pair_kernel_launches", "neigh_pairs" (stored full-list entries), "maxneigh" */
+ * over the last run), "pair_kernel_launches", "neigh_pairs" (stored full-list entries), "maxneigh", "nlocal", "nghost",
+ * "fene_warnings", "time_pair" / "_bond" / "_neigh" / "_comm" / "_output" / "_modify" / "_other" (the reference's loop
+ * sections, seconds), "special_asym" (1 once some bead's 1-2 list lost an entry its partner still has: the list build
+ * then asks which end stores each pair); with ranks: "comm_nranks", "comm_bytes_allgather", "comm_bytes_allreduce",
+ * "halo_window_exchanges", "halo_window_mismatches", "halo_fused", "rng_segments", "rng_segments_held",
+ * "rng_late_generations".  An unknown name returns 0. */
 double lammps_le_stat(void *handle, const char *name);
 
 /* ranks: one process per GPU.  Replaces the MPI_Comm argument of the reference's `lammps_open` entry point
