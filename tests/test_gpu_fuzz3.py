@@ -204,3 +204,29 @@ def test_random_restart_continuity(tmp_path, seed):
         assert a.extract_fix(fid, 0, 1, 0) == b.extract_fix(fid, 0, 1, 0) and a.extract_fix(fid, 0, 1, 1) == b.extract_fix(fid, 0, 1, 1), fid
     assert b.bond_set() == o.bond_set() and np.abs(b.gather("x") - o.x()).max() < 1e-6
     b.close()
+
+
+@pytest.mark.parametrize("seed", _seeds("LE_FUZZ3_PROC_SEEDS", 4))
+def test_random_le_scenarios_mixed_decomposed_processes(tmp_path, seed, monkeypatch):
+    """The decomposed mixed scenarios once more with the ranks as PROCESSES (file-mailbox transport) and the per-step halo
+    through the peer windows in the one-launch form a multi-GPU run takes (forced here: the ranks share the GPU), every window
+    halo also checked against the transport.  Oracle-stopped parameter sets are skipped (a stopped rank ends its peers by
+    time-out: covered once, in test_gpu_dd.py)."""
+    from test_gpu_dd import bond_set, run_ranks
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO", "1")
+    monkeypatch.setenv("LAMMPS_LE_HALO_FUSED", str(seed % 2))
+    monkeypatch.setenv("LAMMPS_LE_FAST_HALO_VERIFY", "1")
+    s, script, world, flavour = dd_scenario(seed)
+    try:
+        o = run_oracle(script, s)
+    except RuntimeError:
+        pytest.skip("the oracle stops on this parameter set")
+    r = run_ranks(world, s, script, tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set(), flavour
+    nso, spo = o.special_table()
+    assert (r["nspecial"] == nso).all(), flavour
+    for fid in ("loop", "loading", "unloading"):
+        assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1], (fid, flavour)
+    assert np.abs(r["x"] - o.x()).max() < 1e-6, flavour
+    assert r["builds"][0] == o.neigh_builds()
+    assert int(r["window_exchanges"][0]) > 0 and int(r["window_mismatches"][0]) == 0
