@@ -64,7 +64,9 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   if (maxtag >= (1 << BOND_TYPE_SHIFT)) throw LammpsError("MI355X engine: atom IDs must stay below 2^26");
   d.bond_pack_stride = ((1 + bpa) + 3) & ~3;
   dalloc(d.bond_pack, nt * (size_t)d.bond_pack_stride);
+  for (int k = 0; k < 2; k++) dalloc(d.bond_pack_p[k], np * (size_t)d.bond_pack_stride);
   d.bond_pack_dirty = true;
+  d.bond_pack_p_valid = false;
   // cells of edge >= cutneigh
   d.ncells = 1;
   for (int k = 0; k < 3; k++) {
@@ -122,7 +124,7 @@ void dev_free(DeviceState &d) {
   for (int k = 0; k < 3; k++) { dfree(d.v[k]); dfree(d.v_tmp[k]); dfree(d.f[k]); }
   dfree(d.tag); dfree(d.tag_tmp); dfree(d.img); dfree(d.img_tmp);
   dfree(d.map); dfree(d.type_t); dfree(d.crank);
-  dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special); dfree(d.num_bond0); dfree(d.bond_type0); dfree(d.bond_atom0); dfree(d.bond_pack);
+  dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special); dfree(d.num_bond0); dfree(d.bond_type0); dfree(d.bond_atom0); dfree(d.bond_pack); dfree(d.bond_pack_p[0]); dfree(d.bond_pack_p[1]);
   dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
   dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial); dfree(d.partial_a);
   dfree(d.num_angle); dfree(d.angle_type); dfree(d.angle_a1); dfree(d.angle_a2); dfree(d.angle_a3); dfree(d.eff_n); dfree(d.eff_rec);

@@ -98,6 +98,10 @@ struct DeviceState {
   int *bond_pack = nullptr;
   int bond_pack_stride = 0;
   bool bond_pack_dirty = true;
+  // the same records by PHYSICAL index (one GPU, permute pass writes the bond-partner table): moved with the beads by
+  // k_permute, so that the table pass reads them next to the bead's other data instead of gathering them by tag
+  int *bond_pack_p[2] = {nullptr, nullptr};
+  bool bond_pack_p_valid = false;
   // ---- cells / neighbor list ----
   int ncell[3] = {0, 0, 0}, ncells = 0;
   int row_tile = 0;          // (y, z) rows of cells numbered in tiles of this edge (bin_inl.h row_id); 0 = z-major (decomposed runs)

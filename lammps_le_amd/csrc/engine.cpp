@@ -160,6 +160,7 @@ void Engine::upload() {
   }
   DeviceState &d = *dev;
   d.bins_ready = false;      // the device arrays are about to be replaced (tag order): bins of the old arrays are void
+  d.bond_pack_p_valid = false;
   bool realloc = (d.ntotal != natoms || d.bpa != bpa || d.maxspecial != maxspecial || d.ntypes != ntypes || !d.pos || d.apa != apa);
   double cellcut = cutneighmax > 0.0 ? cutneighmax : std::max({box.prd[0], box.prd[1], box.prd[2]}) / 3.0;
   if (world > 1) {

@@ -134,9 +134,8 @@ struct BondTabArgs {
   unsigned long long *bshift;
   double hx, hy, hz;       // half box
 };
-__device__ __forceinline__ void bond_table_row(int s, int n, int npad, int t, const int *__restrict__ map,
+__device__ __forceinline__ void bond_table_row(int s, int n, int npad, const int *__restrict__ rec, const int *__restrict__ map,
                                                const BondTabArgs &B, int *__restrict__ flags) {
-  const int *rec = B.pack + (size_t)t * B.stride;
   int nb = rec[0];
   bool ghost = false;
   const bool freeze = B.bshift != nullptr;
@@ -184,12 +183,20 @@ __global__ __launch_bounds__(BLOCK) void k_permute(int n, int npad, const int *_
                                                    int *__restrict__ tagn, const int *__restrict__ img,
                                                    int *__restrict__ imgn, int *__restrict__ map,
                                                    float4 *__restrict__ posf, int wrap, Box box, BondTabArgs B,
+                                                   const int4 *__restrict__ pack_old, int4 *__restrict__ pack_new,
                                                    int *__restrict__ flags) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= n) return;
   int p = perm[s];
   int t = tag[p];
-  if (B.bpart) bond_table_row(s, n, npad, t, map, B, flags);
+  if (B.bpart) {
+    if (pack_old) {     // (records of one int4: up to three bonds per bead) the record travels with the bead
+      const int4 r4 = pack_old[p];
+      pack_new[s] = r4;
+      const int rec[4] = {r4.x, r4.y, r4.z, r4.w};
+      bond_table_row(s, n, npad, rec, map, B, flags);
+    } else bond_table_row(s, n, npad, B.pack + (size_t)t * B.stride, map, B, flags);
+  }
   double4 r = pos[p];
   int dix = 0, diy = 0, diz = 0;
   if (wrap) wrap_into_box(r, box, dix, diy, diz);   // the step kernel binned these positions: Domain::pbc is applied here
@@ -218,7 +225,15 @@ __global__ __launch_bounds__(BLOCK) void k_bond_table(int n, int npad, const int
                                                       int *__restrict__ flags) {
   int s = blockIdx.x * BLOCK + threadIdx.x;
   if (s >= n) return;
-  bond_table_row(s, n, npad, tag[s], map, B, flags);
+  bond_table_row(s, n, npad, B.pack + (size_t)tag[s] * B.stride, map, B, flags);
+}
+// the packed records by physical index (after the bond tables or the physical order changed outside k_permute)
+__global__ __launch_bounds__(BLOCK) void k_bond_pack_phys(int n, int stride, const int *__restrict__ tag, const int *__restrict__ pack,
+                                                          int *__restrict__ pack_p) {
+  int i = blockIdx.x * BLOCK + threadIdx.x;      // one lane per word
+  if (i >= n * stride) return;
+  const int s = i / stride, k = i - s * stride;
+  pack_p[i] = pack[(size_t)tag[s] * stride + k];
 }
 
 // full neighbor list of atom s.  The 27-cell sweep is done as 9 (dy,dz) row segments: the three x-cells of a
@@ -631,6 +646,7 @@ static void ensure_bond_pack(DeviceState &d) {
   hipLaunchKernelGGL(k_bond_pack, dim3((d.maxtag + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.maxtag, d.bpa, d.bond_pack_stride,
                      d.num_bond, d.bond_type, d.bond_atom, d.bond_pack);
   d.bond_pack_dirty = false;
+  d.bond_pack_p_valid = false;
 }
 void scan_cells(DeviceState &d, int *count, int *start, int nc, int total) {
   const int sb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -659,6 +675,14 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone, boo
   static const bool no_fuse = getenv("LAMMPS_LE_NO_PERMUTE_BONDS") != nullptr;
   const bool with_bonds = !d.dd && !gone && d.bond_minimg && d.bpa > 0 && d.bpart && !no_fuse;
   if (with_bonds) ensure_bond_pack(d);
+  static const bool no_phys = getenv("LAMMPS_LE_NO_PHYS_BOND_PACK") != nullptr;
+  const bool phys = with_bonds && d.bond_pack_stride == 4 && !no_phys;
+  if (phys && !d.bond_pack_p_valid) {
+    const int words = m_in * d.bond_pack_stride;
+    hipLaunchKernelGGL(k_bond_pack_phys, dim3((words + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, m_in, d.bond_pack_stride, d.tag, d.bond_pack,
+                       d.bond_pack_p[0]);
+  }
+  d.bond_pack_p_valid = phys;
   hipLaunchKernelGGL(k_sort_cells, dim3((d.ncells + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d.ncells,
                      d.cell_start, d.perm, d.tag, with_bonds ? d.map : (int *)nullptr);
   const int n = n_out;
@@ -667,7 +691,8 @@ void launch_sort_owned(DeviceState &d, int m_in, int n_out, const int *gone, boo
                  nullptr, nullptr, nullptr, 0.0, 0.0, 0.0};
   hipLaunchKernelGGL(k_permute, dim3(nb), dim3(BLOCK), 0, st, n, d.npad, d.perm, d.pos, d.pos_tmp, d.xhold, d.v[0],
                      d.v[1], d.v[2], d.v_tmp[0], d.v_tmp[1], d.v_tmp[2], d.tag, d.tag_tmp, d.img, d.img_tmp, d.map, d.posf,
-                     prebinned ? 1 : 0, d.box, BT, d.flags);
+                     prebinned ? 1 : 0, d.box, BT, phys ? (const int4 *)d.bond_pack_p[0] : (const int4 *)nullptr, (int4 *)d.bond_pack_p[1], d.flags);
+  if (phys) std::swap(d.bond_pack_p[0], d.bond_pack_p[1]);
   d.bpart_fresh = with_bonds;
   std::swap(d.pos, d.pos_tmp);
   for (int k = 0; k < 3; k++) std::swap(d.v[k], d.v_tmp[k]);
