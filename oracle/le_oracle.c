@@ -560,16 +560,16 @@ static inline int find_special(const leo_t *s, int i, int tagj) {
 /* list entry: index | ONESIDE << 29 | which << 30.  ONESIDE: an owned-ghost entry of a newton_pair-off list - a pair that
    interacts through a periodic image is stored by BOTH owned ends (each with the ghost image of the other, its own special
    status, force and half the energy / virial to the owned end only: pair_lj_cut.cpp:118-122, pair.cpp ev_tally) */
-#define PJ_INDEX(e) ((e) & 0x1FFFFFFF)
-#define PJ_ONESIDE(e) (((e) >> 29) & 1)
-#define PJ_WHICH(e) (((e) >> 30) & 3)
+#define PJ_INDEX(e) ((int)((unsigned)(e) & 0x1FFFFFFFu))
+#define PJ_ONESIDE(e) ((int)(((unsigned)(e) >> 29) & 1u))
+#define PJ_WHICH(e) ((int)(((unsigned)(e) >> 30) & 3u))
 static void push_pair(leo_t *s, int i, int j, int which, const signed char *sh, int oneside) {
   if (s->npairs == s->maxpairs) {
     s->maxpairs = s->maxpairs ? 2 * s->maxpairs : 1024;
     s->pj = realloc(s->pj, s->maxpairs * sizeof(int));
     if (s->brute) { s->pi_ = realloc(s->pi_, s->maxpairs * sizeof(int)); s->pshift = realloc(s->pshift, 3 * s->maxpairs); }
   }
-  s->pj[s->npairs] = j | (oneside << 29) | (which << 30);
+  s->pj[s->npairs] = (int)((unsigned)j | ((unsigned)oneside << 29) | ((unsigned)which << 30));
   if (oneside) s->noneside++;
   if (s->brute) { s->pi_[s->npairs] = i; memcpy(s->pshift + 3 * s->npairs, sh, 3); }
   s->npairs++;
