@@ -185,6 +185,7 @@ struct DeviceState {
   int *sendlist[2] = {nullptr, nullptr};                // owned indices sent down / up every step
   int *sendlist_alt[2] = {nullptr, nullptr};            // ... and the buffers the next rebuild writes its reordered lists into
   bool bpart_fresh = false;                             // the permute pass of this rebuild has written the bond-partner table
+  bool ghost_whole_shell = false;                       // every bead within the ghost cutoff of a face is sent (runs with an angle style)
   bool map_stale = true;                                // map[] was not left by a decomposed rebuild: fill it before the next one
   int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
   double4 *sendbuf = nullptr, *recvbuf = nullptr;       // halo staging

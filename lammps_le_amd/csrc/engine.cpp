@@ -166,6 +166,7 @@ void Engine::upload() {
   if (world > 1) {
     // z-slab decomposition: rank r owns z in [lo + r*w, lo + (r+1)*w); ghost shell = max(neighbor cutoff, comm cutoff)
     d.dd = 1;
+    d.ghost_whole_shell = angles_active();
     double w = box.prd[2] / world;
     d.slab_lo = box.lo[2] + rank * w;
     d.slab_hi = d.slab_lo + w;
@@ -337,6 +338,17 @@ void Engine::download() {
     std::copy(ba.begin() + bpa, ba.begin() + bpa + (size_t)natoms * bpa, bond_atom.begin());
     std::copy(ns.begin() + 3, ns.begin() + 3 + (size_t)natoms * 3, nspecial.begin());
     std::copy(sp.begin() + maxspecial, sp.begin() + maxspecial + (size_t)natoms * maxspecial, special.begin());
+    if (apa > 0) {       // the angle tables are replicated by tag, like the bond tables
+      std::vector<int> an(nt), ag(nt * apa);
+      HIP_CHECK(hipMemcpy(an.data(), d.num_angle, nt * sizeof(int), hipMemcpyDeviceToHost));
+      std::copy(an.begin() + 1, an.begin() + 1 + natoms, num_angle.begin());
+      const int *src[4] = {d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3};
+      std::vector<int> *dst[4] = {&angle_type, &angle_a1, &angle_a2, &angle_a3};
+      for (int q = 0; q < 4; q++) {
+        HIP_CHECK(hipMemcpy(ag.data(), src[q], nt * apa * sizeof(int), hipMemcpyDeviceToHost));
+        std::copy(ag.begin() + apa, ag.begin() + apa + (size_t)natoms * apa, dst[q]->begin());
+      }
+    }
     host_current = true;
     return;
   }
@@ -655,6 +667,7 @@ ThermoRow Engine::eval_thermo() {
   if (angles_active()) {       // thermo's emol = ebond + eangle (src/thermo.cpp), the pressure's virial includes the angles'
     double a8[8];
     reduce_angle_partials(d, a8);
+    if (world > 1) comm->allreduce_host_sum(a8, 8);
     r.ebond += a8[0];
     for (int k = 0; k < 6; k++) r.virial[k] += a8[1 + k];
   }
@@ -754,7 +767,7 @@ void Engine::iterate(long nsteps) {
   // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
   for (int b = 1; b <= nbondtypes; b++) if (bondtab.style[b] == 3) fusable = false;
   // angles (semiflexible chains): a kernel of their own writes the angle forces right before the fused step
-  // kernel, which adds them to its sums (one GPU; decomposed runs refuse angles)
+  // kernel, which adds them to its sums (decomposed runs too: every rank for the beads it owns)
   const bool ang = angles_active();
   if (ang && !step_fuses_angles(d, pair_lj)) fusable = false;      // (no pair style: force kernel -> angle kernel -> integrate kernels)
   bool ident = d.ident_order;
@@ -764,6 +777,7 @@ void Engine::iterate(long nsteps) {
   // LAMMPS_LE_OVERLAP_RCCL=1 says otherwise
   bool overlap = getenv("LAMMPS_LE_OVERLAP") != nullptr && atoi(getenv("LAMMPS_LE_OVERLAP")) != 0;
   if (overlap && comm && comm->backend == Comm::RCCL && !getenv("LAMMPS_LE_OVERLAP_RCCL")) overlap = false;
+  if (angles_active()) overlap = false;       // (the two-phase launches of the overlap mode do not carry the angle forces)
   // test hook (LAMMPS_LE_TEST_FAIL_AT="rank:step"): this rank stops with an error in the middle of a run, the way a
   // rank-local failure (capacity check, LE fix throw) would; its peers must end with an error too, not hang
   long fail_at = -1;
@@ -1024,8 +1038,8 @@ void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
-  if (angles_active() && (world > 1 || respa_levels > 0))
-    throw LammpsError("MI355X engine: angle styles run on one GPU with run_style verlet only");
+  if (angles_active() && respa_levels > 0)
+    throw LammpsError("MI355X engine: angle styles run with run_style verlet only");
   for (int a = 1; a <= nangletypes && apa > 0 && nangles > 0 && !angle_style_name.empty() && angle_style_name != "none" && angle_style_name != "zero"; a++)
     if (!angtab.style[a]) throw LammpsError("All angle coeffs are not set");
   // a run that ended in an error tore the communicator down (below); halo sequence numbers and arrival counters of the

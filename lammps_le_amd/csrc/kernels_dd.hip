@@ -145,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
                                                       const int *__restrict__ bond_atom, int *__restrict__ list_dn,
                                                       int *__restrict__ list_up, int *__restrict__ flags,
                                                       unsigned char *__restrict__ phase, int *__restrict__ sendslot,
-                                                      RngValidateArgs V) {
+                                                      RngValidateArgs V, int whole_shell) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   bool active = p < n;
   if (active && V.late) rng_validate_bead(V, tag[p], flags);      // do this rank's pools hold the draws of what it owns now?
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(BLOCK) void k_dd_borders(int n, const double4 *__re
   bool far_dn = active && !dn && zc < cutghost, far_up = active && !up && zc >= width - cutghost;
   if (far_dn || far_up) {
     int t = tag[p], nb = num_bond[t];
-    bool remote = false;      // map[] holds owned beads only at this point
+    // (runs with an angle style: the whole ghost-cutoff shell, as the reference sends it - an angle's far end is two bonds
+    //  away from the bead it moves and need not be bonded to anything on the other side)
+    bool remote = whole_shell != 0;      // map[] holds owned beads only at this point
     for (int m = 0; m < nb; m++) remote = remote || map[bond_atom[(size_t)t * bpa + m]] < 0;
     dn = dn || (far_dn && remote);
     up = up || (far_up && remote);
@@ -631,7 +633,7 @@ void dd_reneighbor(DeviceState &d, Comm &comm, double cutneighsq, const double s
   // ---- 3. borders ----
   hipLaunchKernelGGL(k_dd_borders, dim3(nb), dim3(BLOCK), 0, st, n, d.pos, d.box, d.slab_lo, width,
                      std::min(sqrt(cutneighsq), d.cutghost), d.cutghost, d.bpa, d.tag, d.map, d.num_bond, d.bond_atom,
-                     d.sendlist[0], d.sendlist[1], d.flags, d.phase, d.sendslot, rng_validate_args(d));
+                     d.sendlist[0], d.sendlist[1], d.flags, d.phase, d.sendslot, rng_validate_args(d), d.ghost_whole_shell ? 1 : 0);
   swap_counts(FLAG_COUNT_A, FLAG_COUNT_B);
   d.nsend[0] = d.flags_h[FLAG_COUNT_A];
   d.nsend[1] = d.flags_h[FLAG_COUNT_B];

@@ -862,7 +862,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 // copies in place that adds up to one evaluation per atom, with copies out of step it is what the reference computes
 // (found by the mixed sweep, tests/test_gpu_fuzz2.py seeds 17, 74, 125).
 __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, int npad, const int *__restrict__ crank,
-                                                      const int *__restrict__ map, const double4 *__restrict__ pos, Box box,
+                                                      const int *__restrict__ map, const double4 *__restrict__ pos, Box box, int n_owned,
                                                       const int *__restrict__ num_angle, const int *__restrict__ angle_type,
                                                       const int *__restrict__ a1, const int *__restrict__ a2,
                                                       const int *__restrict__ a3, int *__restrict__ eff_n,
@@ -878,6 +878,10 @@ __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, 
     // the bead's own index: the force kernel reads them coalesced and gathers positions without a tag -> index lookup
     const int p[3] = {map[t[0]], map[t[1]], map[t[2]]};
     const int pi = map[i];
+    // decomposed runs (n_owned >= 0; the angle tables are replicated): only angles that move a bead this rank OWNS matter here;
+    // all three atoms of such an angle must be present (owned or ghost: the ghost shell of a run with angles holds every bead
+    // within the ghost cutoff of a face, k_dd_borders)
+    if (n_owned >= 0 && !((p[0] >= 0 && p[0] < n_owned) || (p[1] >= 0 && p[1] < n_owned) || (p[2] >= 0 && p[2] < n_owned))) continue;
     if (p[0] < 0 || p[1] < 0 || p[2] < 0 || pi < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
     const double4 ri = pos[pi];
     bool listed = true, ghost[3];
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, 
     if (!listed) continue;
     const int4 rec = make_int4(angle_type[c], p[0], p[1], p[2]);
     for (int q = 0; q < 3; q++) {
-      if (ghost[q]) continue;
+      if (ghost[q] || (n_owned >= 0 && p[q] >= n_owned)) continue;
       const int slot = atomicAdd(&eff_n[p[q]], 1);
       if (slot >= ecap) { flags[FLAG_ERROR] = ERR_ANGLES; continue; }
       eff_rec[(size_t)slot * npad + p[q]] = rec;
@@ -926,7 +930,7 @@ void launch_angle_list(DeviceState &d) {
   const int T = d.maxtag, nb = std::max(1, (T + BLOCK - 1) / BLOCK);
   HIP_CHECK(hipMemsetAsync(d.eff_n, 0, (size_t)d.npad * sizeof(int), d.stream));
   hipLaunchKernelGGL(k_angle_list, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, d.ecap, d.npad, d.ident_order ? (const int *)nullptr : d.crank,
-                     d.map, d.pos, d.box, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
+                     d.map, d.pos, d.box, d.dd ? d.n : -1, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
   hipLaunchKernelGGL(k_angle_sort, dim3(std::max(1, (d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.npad, d.eff_n,
                      (int4 *)d.eff_rec);
 }
@@ -1036,7 +1040,7 @@ void reduce_angle_partials(DeviceState &d, double *out8) {
 }
 
 // can the fused step kernel take the angle forces of a run (launch_step's angle_forces)?  Needs the pair-style instantiations
-bool step_fuses_angles(const DeviceState &d, bool has_pair) { return has_pair && !d.dd; }
+bool step_fuses_angles(const DeviceState &d, bool has_pair) { (void)d; return has_pair; }
 
 // sum the per-block partials on the host in block order (deterministic)
 void reduce_partials(DeviceState &d, double *out16) {

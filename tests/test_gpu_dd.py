@@ -52,6 +52,10 @@ def run_ranks_local(world, system, script, tmp_path):
                        nspecial=lmp.gather("nspecial"), special=lmp.gather("special"),
                        thermo=np.array([lmp.get_thermo(k) for k in ("temp", "epair", "emol", "etotal", "press", "bonds")]),
                        neigh_pairs=np.array([lmp.stat("neigh_pairs")]), builds=np.array([lmp.stat("neigh_builds")]))
+            if lmp.extract_setting("angle_per_atom") > 0:
+                res.update(num_angle=lmp.gather("num_angle"), angle_type=lmp.gather("angle_type"), angle_atom1=lmp.gather("angle_atom1"),
+                           angle_atom2=lmp.gather("angle_atom2"), angle_atom3=lmp.gather("angle_atom3"),
+                           nangles=np.array([lmp.extract_setting("nangles")]))
             for fid in ("loop", "loading", "unloading"):
                 try:
                     res["f_" + fid] = np.array([lmp.extract_fix(fid, 0, 1, 0), lmp.extract_fix(fid, 0, 1, 1)])
@@ -518,3 +522,40 @@ def test_langevin_stream_segments_are_skipped_not_lost(tmp_path, monkeypatch, gh
         assert out[r][3] == nseg and 0 < out[r][2] < nseg, out[r][2:]
     if not ghost_margin:
         assert sum(out[r][4] for r in range(world)) > 0, [out[r][4] for r in range(world)]     # late generations happened
+
+
+@pytest.mark.parametrize("world,style", [(2, "harmonic"), (3, "cosine")])
+def test_semiflexible_chains_across_slabs(tmp_path, world, style):
+    """Angles in a decomposed run (in-process transport): the ghost shell of a run with an angle style holds every bead
+    within the ghost cutoff of a slab face, each rank lists the angles that move a bead it owns, the LE fixes keep the
+    replicated angle tables (`ex_load ... atype 2`, angle breaking in ex_unload).  Bond topology, angle tables, angle count,
+    thermo (emol = bond + angle energy, pressure with the angle virial) and trajectory against the one-rank oracle."""
+    from test_gpu_angle import ANGLE_SCRIPT, semiflexible
+    n = 9000 if world == 2 else 27000
+    s = semiflexible(n, 3, seed=4, steps=300)
+    coeffs = ("angle_coeff 1 1.5 160.0", "angle_coeff 2 1.0 100.0") if style == "harmonic" else ("angle_coeff 1 1.5", "angle_coeff 2 0.5")
+    script = ANGLE_SCRIPT.replace("bond_coeff 2 5.0 10.0 1.0 1.0", "bond_coeff 2 8.0 5.0 1.0 1.0") + """angle_style %s
+%s
+%s
+fix 1 all nve
+fix 2 all langevin 1.0 1.0 1.0 904297
+fix loop all extrusion 19 1 1 1 1.0 2
+fix loading all ex_load 5 1 1 1.12 2 prob 0.3 684474 iparam 1 1 jparam 1 1 atype 2
+fix unloading all ex_unload 6 2 0.5 prob 0.4 456456
+thermo 20
+run 50
+""" % ((style,) + coeffs)     # (few extrusion steps: an extruder bond of a stiff chain must stay inside the 5.0 ghost shell)
+    o = run_oracle(script, s)
+    r = run_ranks_local(world, s, script, tmp_path)
+    assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+    na, at, a1, a2, a3 = o.angle_table()
+    assert (r["num_angle"] == na).all()
+    for name, ref in (("angle_type", at), ("angle_atom1", a1), ("angle_atom2", a2), ("angle_atom3", a3)):
+        for i in np.nonzero(na)[0]:
+            assert list(r[name][i, :na[i]]) == list(ref[i, :na[i]]), (name, i + 1)
+    assert int(r["nangles"][0]) == o.nangles()
+    assert any(a[0] == 2 for a in o.angle_set())
+    assert np.abs(r["x"] - o.x()).max() < 1e-8
+    to = o.thermo()
+    assert np.abs(r["thermo"][:5] - to[:5]).max() < 1e-8
+    assert r["builds"][0] == o.neigh_builds()

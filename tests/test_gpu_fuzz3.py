@@ -39,6 +39,21 @@ def dd_scenario(seed):
     s["ntypes"], s["mass"] = 4, [1.0] * 4
     flavour = str(rng.choice(["plain", "sort", "newton", "sort+newton", "convert"]))
     base = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 8.0 5.0 1.0 1.0")
+    rng3 = np.random.RandomState(31000 + seed)      # (drawn apart: the scenarios of the first decomposed sweep keep their seeds)
+    angle_lines, atype = "", ""
+    if rng3.rand() < 0.3:                            # semiflexible chains: angles in a decomposed run
+        per = n // nchains
+        ang = [(1, i, i + 1, i + 2) for i in range(1, n - 1) if (i - 1) // per == (i + 1) // per]
+        s["nangletypes"], s["angles"], s["extra_angle"] = 2, np.array(ang, dtype=np.int32), 24
+        s["atom_style"] = "molecular"
+        base = base.replace("atom_style bond", "atom_style molecular")
+        if rng3.rand() < 0.5:
+            angle_lines = "angle_style harmonic\nangle_coeff 1 %.2f %.1f\nangle_coeff 2 %.2f %.1f\n" % (
+                rng3.uniform(0.5, 4.0), rng3.uniform(120.0, 180.0), rng3.uniform(0.5, 2.0), rng3.uniform(90.0, 150.0))
+        else:
+            angle_lines = "angle_style cosine\nangle_coeff 1 %.2f\nangle_coeff 2 %.2f\n" % (rng3.uniform(0.5, 3.0), rng3.uniform(0.2, 1.5))
+        atype = str(rng3.choice(["", " atype 1", " atype 2"]))
+        flavour += "+angles"
     if "sort" in flavour:
         base = base.replace("atom_modify sort 0 0", "atom_modify sort %d 0" % int(rng.randint(3, 16)))
     if "newton" in flavour:
@@ -53,7 +68,7 @@ def dd_scenario(seed):
     nt = int(rng.choice([1, 2, 3, 4])) if flavour == "convert" else 1
     fixes = ["fix 1 all nve", "fix 2 all langevin 1.0 1.0 1.0 %d" % int(rng.randint(1, 900000)),
              "fix loop all extrusion %d 1 2 3 %g 2 %s" % (n1, tp, lr),
-             "fix loading all ex_load %d 1 1 1.12 2 %s iparam 1 %d jparam 1 %d" % (nl, lprob, nt, nt),
+             "fix loading all ex_load %d 1 1 1.12 2 %s iparam 1 %d jparam 1 %d%s" % (nl, lprob, nt, nt, atype),
              "fix unloading all ex_unload %d 2 %g %s" % (nu, rmax, uprob)]
     total = int(rng.randint(25, 60))
     cuts = sorted(set(int(c) for c in rng.randint(1, total, size=int(rng.randint(0, 3)))))
@@ -61,7 +76,7 @@ def dd_scenario(seed):
     for c in cuts + [total]:
         runs.append(c - last)
         last = c
-    script = base + "\n".join(fixes) + "\nthermo 10\n" + "".join("run %d\n" % r for r in runs if r > 0)
+    script = base + angle_lines + "\n".join(fixes) + "\nthermo 10\n" + "".join("run %d\n" % r for r in runs if r > 0)
     return s, script, world, flavour
 
 
@@ -85,6 +100,13 @@ def test_random_le_scenarios_mixed_decomposed(tmp_path, seed):
         assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1], (fid, flavour)
     assert np.abs(r["x"] - o.x()).max() < 1e-6, flavour
     assert r["builds"][0] == o.neigh_builds()
+    if "angles" in flavour:
+        na, at, a1, a2, a3 = o.angle_table()
+        assert (r["num_angle"] == na).all()
+        for name, ref in (("angle_type", at), ("angle_atom1", a1), ("angle_atom2", a2), ("angle_atom3", a3)):
+            for i in np.nonzero(na)[0]:
+                assert list(r[name][i, :na[i]]) == list(ref[i, :na[i]]), (name, i + 1)
+        assert int(r["nangles"][0]) == o.nangles()
 
 
 def md_scenario(seed):
