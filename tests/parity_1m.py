@@ -9,22 +9,36 @@ from lammps_le_amd.synth import CHAIN_INPUT, lattice_chains, write_data
 from systems import OracleScript
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2004
-sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
+period = int(sys.argv[3]) if len(sys.argv) > 3 else 1000        # firing period of the three LE fixes (shorter: more firings per CPU minute)
+if len(sys.argv) > 4 and sys.argv[4] == "walk":
+    from lammps_le_amd.synth import scrambled_chains
+    sysd = scrambled_chains(n, nchains=1, seed=1, barrier_every=200)
+else:
+    sysd = lattice_chains(n, nchains=1, seed=1, barrier_every=200)
 data = os.path.join(tempfile.mkdtemp(), "data")
 write_data(data, sysd)
-script = CHAIN_INPUT.format(data=data, n1=1000, left=2, right=3, tp=0.5, lr="4", nload=1000, pload=0.01, punload=0.01)
+script = CHAIN_INPUT.format(data=data, n1=period, left=2, right=3, tp=0.5, lr="4", nload=period, pload=0.01, punload=0.01)
 lmp = lammps(cmdargs=["-screen", "none"])
 for ln in script.split("\n"):
     lmp.command(ln)
+CHUNK = 25 if n > 2000000 else steps       # (both engines issue the same `run` commands: every `run` has a setup that draws)
 t0 = time.time()
-lmp.command("run %d" % steps)
+done = 0
+while done < steps:
+    lmp.command("run %d" % min(CHUNK, steps - done))
+    done += min(CHUNK, steps - done)
 print("product: %d steps in %.1f s, bonds %d" % (steps, time.time() - t0, lmp.get_thermo("bonds")), flush=True)
 osc = OracleScript(dict(sysd))
 for ln in script.split("\n"):
     if not ln.startswith("thermo_style"):
         osc.line(ln)
 t0 = time.time()
-osc.o.run(steps)
+done = 0
+while done < steps:            # in chunks, with a line per chunk: a silent CPU phase of many minutes looks like a hung run
+    chunk = min(CHUNK, steps - done)
+    osc.o.run(chunk)
+    done += chunk
+    print("oracle: step %d after %.1f s" % (done, time.time() - t0), flush=True)
 print("oracle: %d steps in %.1f s, bonds %d" % (steps, time.time() - t0, osc.o.nbonds()), flush=True)
 pb, ob = lmp.bond_set(), osc.o.bond_set()
 ext = [b for b in ob if b[0] == 2]
