@@ -185,6 +185,7 @@ struct DeviceState {
   int *sendlist[2] = {nullptr, nullptr};                // owned indices sent down / up every step
   int *sendlist_alt[2] = {nullptr, nullptr};            // ... and the buffers the next rebuild writes its reordered lists into
   bool bpart_fresh = false;                             // the permute pass of this rebuild has written the bond-partner table
+  void *angtab_dev = nullptr;                           // AngleTable in device memory (fused angle step)
   bool ghost_whole_shell = false;                       // every bead within the ghost cutoff of a face is sent (runs with an angle style)
   bool map_stale = true;                                // map[] was not left by a decomposed rebuild: fill it before the next one
   int nsend[2] = {0, 0}, nrecv[2] = {0, 0};
@@ -251,6 +252,7 @@ void launch_ke(DeviceState &d, const TypeTables &tt);
 // angle forces added to f (after launch_force); eflag: energy / virial thirds into partial_a (reduce_angle_partials)
 void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwrite = false);
 void launch_angle_list(DeviceState &d);       // at every reneighbor of a run with an angle style
+void upload_angle_table(DeviceState &d, const AngleTable &at);   // before the first fused step of a run with an angle style
 bool step_fuses_angles(const DeviceState &d, bool has_pair);
 void reduce_angle_partials(DeviceState &d, double *out8);
 // reductions: returns sums of `partial` columns on the host (synchronises the stream)

@@ -770,6 +770,7 @@ void Engine::iterate(long nsteps) {
   // kernel, which adds them to its sums (decomposed runs too: every rank for the beads it owns)
   const bool ang = angles_active();
   if (ang && !step_fuses_angles(d, pair_lj)) fusable = false;      // (no pair style: force kernel -> angle kernel -> integrate kernels)
+  if (ang && fusable) upload_angle_table(d, angtab);
   bool ident = d.ident_order;
   bool pre_integrated = false;
   // halo/compute overlap issues the per-step halo on a second stream.  With RCCL that means two streams feeding ONE
@@ -834,7 +835,9 @@ void Engine::iterate(long nsteps) {
         d.halo_ahead = true;
         std::swap(d.pos, d.pos_tmp);
       } else {
-        if (ang) launch_angle(d, angtab, false, true);
+        // (a whole step evaluates the listed angles inside the step kernel; the last step of a run, which stores forces,
+        //  takes them from the angle kernel)
+        if (ang && !next) launch_angle(d, angtab, false, true);
         launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
                     timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang);
         if (!finish_reneighbor()) {
@@ -842,7 +845,7 @@ void Engine::iterate(long nsteps) {
           // Undo the launch on the host side, grow the table, rebuild, launch again.
           if (next) std::swap(d.pos, d.pos_tmp);
           regrow_lists();
-          if (ang) launch_angle(d, angtab, false, true);
+          if (ang && !next) launch_angle(d, angtab, false, true);
           launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
                       timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang);
         }

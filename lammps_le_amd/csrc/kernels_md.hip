@@ -505,6 +505,62 @@ __global__ __launch_bounds__(BLOCK) void k_force(ForceArgs A, BondTable bt, Box 
 // ANG: runs with an angle style - the angle forces of this step were written into fx / fy / fz by k_angle<.., OVERWRITE>
 // right before this launch and are added to the bead's sums (a template parameter, not a run-time test: the step kernel's
 // schedule is sensitive - a pointer test here cost every run 2 us per launch)
+#define ANGLE_SMALL 0.001
+// the listed angles of one bead (records of k_angle_list): its own share of every one - f1 as atom 1, -(f1 + f3) as the
+// centre, f3 as atom 3 - and, EFLAG, a third of the energy / virial each (Angle::ev_tally, newton_bond off)
+template <bool EFLAG, typename TABLE>
+__device__ __forceinline__ void bead_angles(int p, const double4 &rp, int na, const int4 *__restrict__ rec, int npad,
+                                            const double4 *__restrict__ pos, const Box &box, const TABLE &at, double &f0, double &f1v,
+                                            double &f2, double (&acc)[8]) {
+  for (int m = 0; m < na; m++) {
+    const int4 r = rec[(size_t)m * npad + p];
+    const int type = r.x;
+    if (type <= 0 || at.style[type] == 0) continue;
+    const int p1 = r.y, p2 = r.z, p3 = r.w;
+    const double4 r1 = (p1 == p) ? rp : pos[p1], r2 = (p2 == p) ? rp : pos[p2], r3 = (p3 == p) ? rp : pos[p3];
+    double delx1 = r1.x - r2.x, dely1 = r1.y - r2.y, delz1 = r1.z - r2.z;
+    double delx2 = r3.x - r2.x, dely2 = r3.y - r2.y, delz2 = r3.z - r2.z;
+    const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
+    if (delx1 > hx) delx1 -= box.prd[0]; else if (delx1 < -hx) delx1 += box.prd[0];
+    if (dely1 > hy) dely1 -= box.prd[1]; else if (dely1 < -hy) dely1 += box.prd[1];
+    if (delz1 > hz) delz1 -= box.prd[2]; else if (delz1 < -hz) delz1 += box.prd[2];
+    if (delx2 > hx) delx2 -= box.prd[0]; else if (delx2 < -hx) delx2 += box.prd[0];
+    if (dely2 > hy) dely2 -= box.prd[1]; else if (dely2 < -hy) dely2 += box.prd[1];
+    if (delz2 > hz) delz2 -= box.prd[2]; else if (delz2 < -hz) delz2 += box.prd[2];
+    const double rsq1 = delx1 * delx1 + dely1 * dely1 + delz1 * delz1, ra = sqrt(rsq1);
+    const double rsq2 = delx2 * delx2 + dely2 * dely2 + delz2 * delz2, rb = sqrt(rsq2);
+    double cs = delx1 * delx2 + dely1 * dely2 + delz1 * delz2;
+    cs /= ra * rb;
+    if (cs > 1.0) cs = 1.0;
+    if (cs < -1.0) cs = -1.0;
+    double a, eangle = 0.0;
+    if (at.style[type] == 1) {
+      double sn = sqrt(1.0 - cs * cs);
+      if (sn < ANGLE_SMALL) sn = ANGLE_SMALL;
+      sn = 1.0 / sn;
+      const double dtheta = acos(cs) - at.theta0[type], tk = at.k[type] * dtheta;
+      if (EFLAG) eangle = tk * dtheta;
+      a = -2.0 * tk * sn;
+    } else {
+      if (EFLAG) eangle = at.k[type] * (1.0 + cs);
+      a = at.k[type];
+    }
+    const double a11 = a * cs / rsq1, a12 = -a / (ra * rb), a22 = a * cs / rsq2;
+    const double f1x = a11 * delx1 + a12 * delx2, f1y = a11 * dely1 + a12 * dely2, f1z = a11 * delz1 + a12 * delz2;
+    const double f3x = a22 * delx2 + a12 * delx1, f3y = a22 * dely2 + a12 * dely1, f3z = a22 * delz2 + a12 * delz1;
+    if (p == p1) { f0 += f1x; f1v += f1y; f2 += f1z; }
+    else if (p == p2) { f0 -= f1x + f3x; f1v -= f1y + f3y; f2 -= f1z + f3z; }
+    else { f0 += f3x; f1v += f3y; f2 += f3z; }
+    if (EFLAG) {
+      const double third = 1.0 / 3.0;
+      acc[0] += third * eangle;
+      acc[1] += third * (delx1 * f1x + delx2 * f3x); acc[2] += third * (dely1 * f1y + dely2 * f3y);
+      acc[3] += third * (delz1 * f1z + delz2 * f3z); acc[4] += third * (delx1 * f1y + delx2 * f3y);
+      acc[5] += third * (delx1 * f1z + delx2 * f3z); acc[6] += third * (dely1 * f1z + dely2 * f3z);
+    }
+  }
+}
+
 // EF: a thermo step - the same pass also sums the energies and the virial of the pair and bond terms into `partial`
 // (rows of 16 per block, as k_force<EFLAG> writes them), so that a step with thermo output is not a pass of k_force
 // plus a Langevin / integrate kernel.  Only for NEXT = false, one lane per bead (the velocities thermo reads are those
@@ -549,7 +605,14 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
     for (int o = 1; o < LPB; o <<= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); }
     if (sub) return;
   }
-  if (ANG) { f0 += fx[p]; f1 += fy[p]; f2 += fz[p]; }     // Angle::compute follows Bond::compute
+  if (ANG && !NEXT) { f0 += fx[p]; f1 += fy[p]; f2 += fz[p]; }     // Angle::compute follows Bond::compute (k_angle wrote them)
+  if (ANG && NEXT) {
+    // whole steps of a run with an angle style evaluate the bead's listed angles right here; a NEXT launch stores no forces,
+    // so its three force pointers carry the angle data instead: records, counts, coefficient table (launch_step)
+    double acc8[8];
+    const AngleTable &at = *reinterpret_cast<const AngleTable *>(fz);
+    bead_angles<false>(p, ri, reinterpret_cast<const int *>(fy)[p], reinterpret_cast<const int4 *>(fx), A.npad, A.pos, box, at, f0, f1, f2, acc8);
+  }
   const int type = (int)ri.w;
   if (LANGEVIN) {
     double gamma1 = tt.g1[type], gamma2 = tt.g2[type];
@@ -797,10 +860,17 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   int grid = xcd_grid(A.nblocks);
   // ev_start / ev_stop (sampled launches only) take the kernel's own begin / end timestamps from its dispatch packet,
   // the same clock rocprofv3 --kernel-trace reports
+  // a whole step of a run with an angle style (NEXT) evaluates the listed angles inside the kernel: records, counts and the
+  // coefficient table travel in the three force pointers, which a NEXT launch does not otherwise use (step_body)
+  double *pf0 = d.f[0], *pf1 = d.f[1], *pf2 = d.f[2];
+  if (angle_forces && next) {
+    if (!d.eff_rec || !d.eff_n || !d.angtab_dev) throw LammpsError("internal: fused angle step without angle records");
+    pf0 = reinterpret_cast<double *>(d.eff_rec); pf1 = reinterpret_cast<double *>(d.eff_n); pf2 = reinterpret_cast<double *>(d.angtab_dev);
+  }
 #define STPL(L, N, I, P, W, D, H) STPA(L, N, I, P, W, D, H, false)
 #define STPA(L, N, I, P, W, D, H, G)                                                                         \
   hipExtLaunchKernelGGL((k_step<L, N, I, P, W, D, H, G>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, ev_start, ev_stop, 0, A, bt, \
-                        d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],    \
+                        d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], pf0, pf1, pf2,    \
                         d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which)
 #define STP(L, N, I, P) do { if (angle_forces) { if (ahead) STPA(L, N, I, true, 1, false, true, true); else STPA(L, N, I, true, 1, false, false, true); } \
     else if (lpb4) STPL(L, N, I, P, 4, false, true); else if (ahead) STPL(L, N, I, P, 1, false, true); else STPL(L, N, I, P, 1, false, false); } while (0)
@@ -935,7 +1005,6 @@ void launch_angle_list(DeviceState &d) {
                      (int4 *)d.eff_rec);
 }
 
-#define ANGLE_SMALL 0.001
 template <bool EFLAG, bool OVERWRITE = false>
 __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, AngleTable at, const double4 *__restrict__ pos,
                                                  int npad, const int *__restrict__ num_angle, const int4 *__restrict__ rec,
@@ -950,53 +1019,7 @@ __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, Angle
     const int na = num_angle[p];
     const double4 rp = pos[p];
     double f0 = 0.0, f1v = 0.0, f2 = 0.0;
-    for (int m = 0; m < na; m++) {
-      const int4 r = rec[(size_t)m * npad + p];
-      const int type = r.x;
-      if (type <= 0 || at.style[type] == 0) continue;
-      const int p1 = r.y, p2 = r.z, p3 = r.w;
-      const double4 r1 = (p1 == p) ? rp : pos[p1], r2 = (p2 == p) ? rp : pos[p2], r3 = (p3 == p) ? rp : pos[p3];
-      double delx1 = r1.x - r2.x, dely1 = r1.y - r2.y, delz1 = r1.z - r2.z;
-      double delx2 = r3.x - r2.x, dely2 = r3.y - r2.y, delz2 = r3.z - r2.z;
-      const double hx = box.half[0], hy = box.half[1], hz = box.half[2];
-      if (delx1 > hx) delx1 -= box.prd[0]; else if (delx1 < -hx) delx1 += box.prd[0];
-      if (dely1 > hy) dely1 -= box.prd[1]; else if (dely1 < -hy) dely1 += box.prd[1];
-      if (delz1 > hz) delz1 -= box.prd[2]; else if (delz1 < -hz) delz1 += box.prd[2];
-      if (delx2 > hx) delx2 -= box.prd[0]; else if (delx2 < -hx) delx2 += box.prd[0];
-      if (dely2 > hy) dely2 -= box.prd[1]; else if (dely2 < -hy) dely2 += box.prd[1];
-      if (delz2 > hz) delz2 -= box.prd[2]; else if (delz2 < -hz) delz2 += box.prd[2];
-      const double rsq1 = delx1 * delx1 + dely1 * dely1 + delz1 * delz1, ra = sqrt(rsq1);
-      const double rsq2 = delx2 * delx2 + dely2 * dely2 + delz2 * delz2, rb = sqrt(rsq2);
-      double cs = delx1 * delx2 + dely1 * dely2 + delz1 * delz2;
-      cs /= ra * rb;
-      if (cs > 1.0) cs = 1.0;
-      if (cs < -1.0) cs = -1.0;
-      double a, eangle = 0.0;
-      if (at.style[type] == 1) {
-        double sn = sqrt(1.0 - cs * cs);
-        if (sn < ANGLE_SMALL) sn = ANGLE_SMALL;
-        sn = 1.0 / sn;
-        const double dtheta = acos(cs) - at.theta0[type], tk = at.k[type] * dtheta;
-        if (EFLAG) eangle = tk * dtheta;
-        a = -2.0 * tk * sn;
-      } else {
-        if (EFLAG) eangle = at.k[type] * (1.0 + cs);
-        a = at.k[type];
-      }
-      const double a11 = a * cs / rsq1, a12 = -a / (ra * rb), a22 = a * cs / rsq2;
-      const double f1x = a11 * delx1 + a12 * delx2, f1y = a11 * dely1 + a12 * dely2, f1z = a11 * delz1 + a12 * delz2;
-      const double f3x = a22 * delx2 + a12 * delx1, f3y = a22 * dely2 + a12 * dely1, f3z = a22 * delz2 + a12 * delz1;
-      if (p == p1) { f0 += f1x; f1v += f1y; f2 += f1z; }
-      else if (p == p2) { f0 -= f1x + f3x; f1v -= f1y + f3y; f2 -= f1z + f3z; }
-      else { f0 += f3x; f1v += f3y; f2 += f3z; }
-      if (EFLAG) {
-        const double third = 1.0 / 3.0;
-        acc[0] += third * eangle;
-        acc[1] += third * (delx1 * f1x + delx2 * f3x); acc[2] += third * (dely1 * f1y + dely2 * f3y);
-        acc[3] += third * (delz1 * f1z + delz2 * f3z); acc[4] += third * (delx1 * f1y + delx2 * f3y);
-        acc[5] += third * (delx1 * f1z + delx2 * f3z); acc[6] += third * (dely1 * f1z + dely2 * f3z);
-      }
-    }
+    bead_angles<EFLAG>(p, rp, na, rec, npad, pos, box, at, f0, f1v, f2, acc);
     if (OVERWRITE) { fx[p] = f0; fy[p] = f1v; fz[p] = f2; }      // the fused step kernel adds them to its own sums
     else { fx[p] += f0; fy[p] += f1v; fz[p] += f2; }
   }
@@ -1016,6 +1039,12 @@ __global__ __launch_bounds__(BLOCK) void k_angle(int n, int ecap, Box box, Angle
       partial_a[(size_t)blockIdx.x * 8 + threadIdx.x] = v;
     }
   }
+}
+// the coefficient table in device memory, for the fused step (kernel arguments of k_step are not to be touched)
+void upload_angle_table(DeviceState &d, const AngleTable &at) {
+  if (!d.angtab_dev) HIP_CHECK(hipMalloc((void **)&d.angtab_dev, sizeof(AngleTable)));
+  HIP_CHECK(hipMemcpyAsync(d.angtab_dev, &at, sizeof(AngleTable), hipMemcpyHostToDevice, d.stream));
+  HIP_CHECK(hipStreamSynchronize(d.stream));      // (`at` is the caller's object)
 }
 void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwrite) {
   if (d.apa <= 0) return;
