@@ -126,6 +126,7 @@ void dev_free(DeviceState &d) {
   dfree(d.map); dfree(d.type_t); dfree(d.crank);
   dfree(d.num_bond); dfree(d.bond_type); dfree(d.bond_atom); dfree(d.nspecial); dfree(d.special); dfree(d.num_bond0); dfree(d.bond_type0); dfree(d.bond_atom0); dfree(d.bond_pack); dfree(d.bond_pack_p[0]); dfree(d.bond_pack_p[1]);
   if (d.angtab_dev) { (void)hipFree(d.angtab_dev); d.angtab_dev = nullptr; }
+  dfree(d.gmask); dfree(d.lgrank);
   dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
   dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial); dfree(d.partial_a);
   dfree(d.num_angle); dfree(d.angle_type); dfree(d.angle_a1); dfree(d.angle_a2); dfree(d.angle_a3); dfree(d.eff_n); dfree(d.eff_rec);

@@ -185,6 +185,8 @@ struct DeviceState {
   int *sendlist[2] = {nullptr, nullptr};                // owned indices sent down / up every step
   int *sendlist_alt[2] = {nullptr, nullptr};            // ... and the buffers the next rebuild writes its reordered lists into
   bool bpart_fresh = false;                             // the permute pass of this rebuild has written the bond-partner table
+  int *gmask = nullptr;                                 // [maxtag+2] group bits by tag (bit 0 = all); only when a fix acts on a group
+  int *lgrank = nullptr;                                // [maxtag+2] rank of a bead among the members of fix langevin's group (local order)
   void *angtab_dev = nullptr;                           // AngleTable in device memory (fused angle step)
   bool ghost_whole_shell = false;                       // every bead within the ghost cutoff of a face is sent (runs with an angle style)
   bool map_stale = true;                                // map[] was not left by a decomposed rebuild: fill it before the next one
@@ -238,7 +240,7 @@ void dev_free(DeviceState &d);
 void dev_alloc_neigh(DeviceState &d, int maxneigh);
 
 // integrate (kernels_md.hip)
-void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check);
+void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check, int groupbit = 1);
 void launch_force(DeviceState &d, const BondTable &bt, const double special_lj[4], bool eflag, bool has_pair, int parts = 3);
 void launch_flevel_copy(DeviceState &d, double *flevel, bool to_level, bool add);
 void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4], const TypeTables &tt, bool langevin,
@@ -246,8 +248,8 @@ void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4]
                  hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true, bool angle_forces = false,
                  bool eflag = false);
 bool step_fuses_energy(const DeviceState &d, bool has_pair);   // a thermo step can be one launch of the step kernel's energy variant
-void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final);
-void launch_final_integrate(DeviceState &d, const TypeTables &tt);
+void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final, int groupbit = 1);
+void launch_final_integrate(DeviceState &d, const TypeTables &tt, int groupbit = 1);
 void launch_ke(DeviceState &d, const TypeTables &tt);
 // angle forces added to f (after launch_force); eflag: energy / virial thirds into partial_a (reduce_angle_partials)
 void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwrite = false);

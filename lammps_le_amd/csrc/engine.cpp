@@ -235,6 +235,37 @@ void Engine::upload() {
   up(d.map, mp.data(), nt * sizeof(int));
   up(d.type_t, ty.data(), nt * sizeof(int));
   up(d.crank, cr.data(), nt * sizeof(int));
+  // fixes on groups: masks by tag, and the rank of every bead among the members of fix langevin's group in LOCAL order (the
+  // order its draws are handed out in)
+  const int members_before = langevin_members;
+  langevin_members = natoms;
+  std::vector<int> gm, lr;
+  {
+    int lgbit = 1;
+    bool grouped = false;
+    for (auto &f : fixes) {
+      if (f->groupbit != 1) grouped = true;
+      if (dynamic_cast<FixLangevin *>(f.get())) lgbit = f->groupbit;
+    }
+    if (grouped) {
+      if ((int)gmask.size() != natoms) throw LammpsError("internal: group masks do not match the atom count");
+      gm.assign(nt, 0); lr.assign(nt, 0);
+      for (int i = 0; i < n; i++) gm[i + 1] = gmask[i];
+      if (lgbit != 1) {
+        std::vector<int> order(n);
+        for (int i = 0; i < n; i++) order[crank[i]] = i;          // local index -> atom
+        int m = 0;
+        for (int k = 0; k < n; k++) { const int i = order[k]; if (gmask[i] & lgbit) lr[i + 1] = m++; }
+        langevin_members = m;
+      }
+      if (!d.gmask) { HIP_CHECK(hipMalloc((void **)&d.gmask, nt * sizeof(int))); HIP_CHECK(hipMalloc((void **)&d.lgrank, nt * sizeof(int))); }
+      up(d.gmask, gm.data(), nt * sizeof(int));
+      up(d.lgrank, lr.data(), nt * sizeof(int));
+    }
+  }
+  if (langevin_members != members_before)       // the stream is cut into calls of 3 * members draws
+    for (auto &f : fixes)
+      if (auto *l = dynamic_cast<FixLangevin *>(f.get())) l->dev_ready = false;
   // topology: host index t-1 -> device index t
   std::vector<int> nb(nt, 0), bt(nt * bpa, 0), ba(nt * bpa, 0), ns(nt * 3, 0), sp(nt * (size_t)maxspecial, 0);
   std::copy(num_bond.begin(), num_bond.end(), nb.begin() + 1);
@@ -592,6 +623,21 @@ static int count_nve(Engine *e) {
   for (auto &f : e->fixes) if (dynamic_cast<FixNVE *>(f.get())) c++;
   return c;
 }
+static std::vector<int> nve_bits(Engine *e) {      // the group of every fix nve, in fix order
+  std::vector<int> b;
+  for (auto &f : e->fixes) if (dynamic_cast<FixNVE *>(f.get())) b.push_back(f->groupbit);
+  return b;
+}
+// what the uploaded masks depend on beyond the atoms themselves: which fixes act on which group
+std::string Engine::group_signature() const {
+  std::string sig;
+  for (auto &f : fixes) if (f->groupbit != 1) sig += f->id + ":" + f->style + ":" + std::to_string(f->groupbit) + ";";
+  return sig;
+}
+static bool fixes_on_groups(Engine *e) {
+  for (auto &f : e->fixes) if (f->groupbit != 1) return true;
+  return false;
+}
 
 static bool timed_begin(Engine *e) {
   DeviceState &d = *e->dev;
@@ -630,21 +676,23 @@ double Engine::stat_neigh_pairs() {
 // advance the Langevin stream by one post_force call: 3N draws into rng_out (canonical order)
 static void langevin_draws(Engine *e, FixLangevin *lg) {
   DeviceState &d = *e->dev;
+  if (e->langevin_members == 0) return;      // (a group without members: nobody draws)
   if (!lg->dev_ready) {
     // position a host generator at the first draw of this call and cut the stream into blocks
     RanMarsInt r;
     r.seed(lg->seed);
     r.jump(lg->draws);
-    rng_langevin_setup(d, r, e->natoms);
+    rng_langevin_setup(d, r, e->langevin_members);
     lg->dev_ready = true;
   }
   launch_rng_langevin(d, lg->draws + 1);     // raw index of draw k is k+1 (constructor warm-up)
-  lg->draws += 3ull * e->natoms;
+  lg->draws += 3ull * e->langevin_members;   // (three draws per MEMBER of the fix's group and call, src/fix_langevin.cpp:660-674)
 }
 static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
   langevin_draws(e, lg);
   TypeTables tt = make_tables(e, lg);
-  launch_langevin(*e->dev, tt, e->dev->ident_order, fuse_final);
+  if (e->langevin_members == 0) return;
+  launch_langevin(*e->dev, tt, e->dev->ident_order, fuse_final, lg->groupbit);
   rng_langevin_consumed(*e->dev);
 }
 
@@ -763,6 +811,9 @@ void Engine::iterate(long nsteps) {
   int nnve = count_nve(this);
   double triggersq = 0.25 * skin * skin;
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
+  // fix nve / fix langevin on a group other than all: the unfused kernels, which test the bead's group bits
+  const std::vector<int> nbits = nve_bits(this);
+  if (fixes_on_groups(this)) fusable = false;
   // bond morse (the reference's unit-test partner of bond hybrid, not a style of the chromatin model) lives in the
   // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
   for (int b = 1; b <= nbondtypes; b++) if (bondtab.style[b] == 3) fusable = false;
@@ -796,7 +847,7 @@ void Engine::iterate(long nsteps) {
     stamp();
     if (!pre_integrated) {
       bool will_check = neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
-      for (int k = 0; k < nnve; k++) launch_initial_integrate(d, tt, dt, triggersq, will_check && k == nnve - 1);
+      for (int k = 0; k < nnve; k++) launch_initial_integrate(d, tt, dt, triggersq, will_check && k == nnve - 1, nbits[k]);
     }
     for (auto &f : fixes) if (f->has_post_integrate) f->post_integrate();
     stamp(T_MODIFY);
@@ -874,9 +925,11 @@ void Engine::iterate(long nsteps) {
       if (d.dd) dd_halo_wait(d);
       compute_forces(eflag);
       stamp(T_PAIR);          // k_force: pair + bond in one pass
-      if (lg) langevin_post_force(this, lg, nnve == 1);
-      if (!(lg && nnve == 1))
-        for (int k = 0; k < nnve; k++) launch_final_integrate(d, tt);
+      // (Langevin and the final half-kick in one kernel only when both fixes act on the same atoms)
+      const bool lg_fused_final = lg && nnve == 1 && nbits[0] == lg->groupbit && langevin_members > 0;
+      if (lg) langevin_post_force(this, lg, lg_fused_final);
+      if (!lg_fused_final)
+        for (int k = 0; k < nnve; k++) launch_final_integrate(d, tt, nbits[k]);
       pre_integrated = false;
       stamp(T_MODIFY);
       if (eflag) {
@@ -1041,6 +1094,12 @@ void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
+  if (fixes_on_groups(this)) {
+    if (world > 1 || respa_levels > 0) throw LammpsError("MI355X engine: fixes on a group other than all run on one GPU with run_style verlet");
+    for (auto &f : fixes)
+      if (dynamic_cast<FixLangevin *>(f.get()) && f->groupbit != 1 && sortfreq > 0)
+        throw LammpsError("MI355X engine: fix langevin on a group needs atom_modify sort 0 0 (its draws follow the local order)");
+  }
   if (angles_active() && respa_levels > 0)
     throw LammpsError("MI355X engine: angle styles run with run_style verlet only");
   for (int a = 1; a <= nangletypes && apa > 0 && nangles > 0 && !angle_style_name.empty() && angle_style_name != "none" && angle_style_name != "zero"; a++)
@@ -1052,7 +1111,10 @@ void Engine::run(long nsteps) {
   double tr0 = wall();
   init();
   double tr1 = wall();
+  // (a fix on a group that was defined since the last upload: the masks and the member ranks travel with an upload)
+  if (dev && dev_current && fixes_on_groups(this) && group_sig != group_signature()) { download(); dev_current = false; }
   if (!dev_current || !dev || !dev->pos) upload();
+  group_sig = group_signature();
   if (dev->dd) dd_fast_halo_switch(*dev);
   for (int k = 1; k <= 3; k++) dev->sflag[k] = special_flag(k);
   dev->ident_order = local_order_is_tag_order();

@@ -93,6 +93,7 @@ class Engine;
 
 struct Fix {
   std::string id, group, style;
+  int groupbit = 1;          // bit of the fix's group in Engine::gmask (1 = all)
   Engine *eng = nullptr;
   bool force_reneighbor = false;
   virtual ~Fix() {}
@@ -304,6 +305,14 @@ class Engine {
   void read_data(const std::string &path);
   void write_data(const std::string &path);
   void velocity(std::vector<std::string> &arg);
+  // groups (src/group.cpp): static bit masks by atom; bit 0 = all.  fix nve / fix langevin act on them (unfused kernels)
+  std::vector<std::string> group_names = {"all"};
+  std::vector<int> gmask;                          // by atom index (ID - 1); empty until a group is defined
+  std::string group_sig;                           // group_signature() of the last upload
+  std::string group_signature() const;
+  int langevin_members = 0;                        // atoms in fix langevin's group (its draws per call / 3); set by upload()
+  int group_bit(const std::string &name) const;    // 1 << index, or 0 if there is no such group
+  void group_command(std::vector<std::string> &arg);
   void set_command(std::vector<std::string> &arg);   // set atom|type|mol|group ... (src/set.cpp)   // velocity all create|set|scale|zero (src/velocity.cpp)
   // ---- dumps (src/dump_custom.cpp, dump_atom.cpp, dump_local.cpp; compute_property_local.cpp) ----
   struct Dump {

@@ -12,7 +12,12 @@ void dd_gather_positions(DeviceState &d, Comm &comm);
 void dd_gather_needed(DeviceState &d, Comm &comm, int btype, bool with_nbrs);
 
 static void need_all(const std::vector<std::string> &arg) {
-  if (arg[1] != "all") throw LammpsError("MI355X engine: fix group must be 'all' (got " + arg[1] + ")");
+  if (arg[1] != "all") throw LammpsError("MI355X engine: the group of this fix style must be 'all' (got " + arg[1] + ")");
+}
+static int fix_group(Engine *e, const std::vector<std::string> &arg) {      // src/fix.cpp:67-69
+  const int bit = e->group_bit(arg[1]);
+  if (!bit) throw LammpsError("Could not find fix group ID");
+  return bit;
 }
 
 // The LE fixes count on every bond being stored with BOTH of its atoms (`num_bond == 2` for a free backbone bead,
@@ -28,7 +33,7 @@ static void need_newton_bond_off(Engine *e, const std::string &style) {
 FixNVE::FixNVE(Engine *e, const std::vector<std::string> &arg) {
   eng = e; id = arg[0]; group = arg[1]; style = arg[2];
   if (arg.size() < 3) throw LammpsError("Illegal fix nve command");
-  need_all(arg);
+  groupbit = fix_group(e, arg);
   has_initial_integrate = has_final_integrate = true;
 }
 
@@ -36,7 +41,7 @@ FixNVE::FixNVE(Engine *e, const std::vector<std::string> &arg) {
 FixLangevin::FixLangevin(Engine *e, const std::vector<std::string> &arg) {
   eng = e; id = arg[0]; group = arg[1]; style = arg[2];
   if (arg.size() < 7) throw LammpsError("Illegal fix langevin command");
-  need_all(arg);
+  groupbit = fix_group(e, arg);
   t_start = numeric(arg[3]);
   t_stop = numeric(arg[4]);
   t_period = numeric(arg[5]);

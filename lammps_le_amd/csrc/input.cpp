@@ -852,9 +852,9 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
       else throw LammpsError("Illegal timer command");
     }
   } else if (cmd == "processors" || cmd == "package" ||
-             cmd == "suffix" || cmd == "group" || cmd == "velocity_zero") {
-    if (cmd == "group" && !(arg.size() >= 1 && arg[0] == "all"))
-      throw LammpsError("MI355X engine: only group all is supported");
+             cmd == "suffix" || cmd == "velocity_zero") {
+  } else if (cmd == "group") {
+    group_command(arg);
   } else if (cmd == "clear") {
     throw LammpsError("MI355X engine: clear is not supported; open a new instance");
   } else {
@@ -1318,6 +1318,75 @@ void Engine::velocity(std::vector<std::string> &arg) {
 // styles atom | type | mol (ranges N, N*M, *M, N*, *) and group all; keywords type, type/fraction, mol, x y z, vx vy vz,
 // image.  Host-side like the reference; used for marking barrier (CTCF) beads and the like.
 // ---------------------------------------------------------------------------------------------
+// group ID style args (src/group.cpp:81-535): type | id | molecule with values and ranges a:b[:stride], union, subtract,
+// intersect, empty.  Static masks (no `dynamic`), no region / variable styles; a group cannot be deleted.
+int Engine::group_bit(const std::string &name) const {
+  for (size_t k = 0; k < group_names.size(); k++) if (group_names[k] == name) return 1 << k;
+  return 0;
+}
+void Engine::group_command(std::vector<std::string> &arg) {
+  if (!box_exist) throw LammpsError("Group command before simulation box is defined");
+  if (arg.size() < 2) throw LammpsError("Illegal group command");
+  const std::string &name = arg[0], &style = arg[1];
+  if (name == "all") throw LammpsError("Cannot change the group all");     // (src/group.cpp: "all" is fixed)
+  if (style == "delete" || style == "clear" || style == "region" || style == "variable" || style == "dynamic" || style == "static" ||
+      style == "include")
+    throw LammpsError("MI355X engine: group style " + style + " is not supported");
+  download();
+  if (gmask.empty()) gmask.assign(natoms, 1);
+  int bit = group_bit(name);
+  if (!bit) {
+    if (group_names.size() >= 31) throw LammpsError("Too many groups");
+    group_names.push_back(name);
+    bit = 1 << (group_names.size() - 1);
+  }
+  auto inum = [&](const std::string &t) {
+    char *end; long v = strtol(t.c_str(), &end, 10);
+    if (end == t.c_str() || *end) throw LammpsError("Expected integer parameter instead of '" + t + "' in input script or data file");
+    return v;
+  };
+  if (style == "type" || style == "id" || style == "molecule") {
+    if (arg.size() < 3) throw LammpsError("Illegal group command");
+    if (style == "molecule" && molecule.empty()) throw LammpsError("Group molecule command requires atom attribute molecule");
+    if (arg[2] == "<" || arg[2] == ">" || arg[2] == "<=" || arg[2] == ">=" || arg[2] == "==" || arg[2] == "!=" || arg[2] == "<>")
+      throw LammpsError("MI355X engine: group " + style + " with a comparison operator is not supported");
+    for (size_t k = 2; k < arg.size(); k++) {
+      long lo, hi, stride = 1;
+      const std::string &t = arg[k];
+      size_t c1 = t.find(':');
+      if (c1 == std::string::npos) lo = hi = inum(t);
+      else {
+        size_t c2 = t.find(':', c1 + 1);
+        lo = inum(t.substr(0, c1));
+        hi = inum(c2 == std::string::npos ? t.substr(c1 + 1) : t.substr(c1 + 1, c2 - c1 - 1));
+        if (c2 != std::string::npos) stride = inum(t.substr(c2 + 1));
+        if (stride < 1 || lo > hi) throw LammpsError("Illegal range increment value");
+      }
+      for (int i = 0; i < natoms; i++) {
+        const long v = style == "type" ? type[i] : style == "id" ? i + 1 : molecule[i];
+        if (v >= lo && v <= hi && (v - lo) % stride == 0) gmask[i] |= bit;
+      }
+    }
+  } else if (style == "union" || style == "subtract" || style == "intersect") {
+    if (arg.size() < 3) throw LammpsError("Illegal group command");
+    std::vector<int> bits;
+    for (size_t k = 2; k < arg.size(); k++) {
+      const int b = group_bit(arg[k]);
+      if (!b) throw LammpsError("Group ID does not exist");
+      bits.push_back(b);
+    }
+    for (int i = 0; i < natoms; i++) {
+      bool in;
+      if (style == "union") { in = false; for (int b : bits) in = in || (gmask[i] & b); }
+      else if (style == "intersect") { in = true; for (int b : bits) in = in && (gmask[i] & b); }
+      else { in = gmask[i] & bits[0]; for (size_t k = 1; k < bits.size(); k++) in = in && !(gmask[i] & bits[k]); }
+      if (in) gmask[i] |= bit;       // (an existing group is added to, as in the reference)
+    }
+  } else if (style == "empty") {
+  } else throw LammpsError("Illegal group command");
+  dev_current = false;               // the masks travel with the next upload
+}
+
 void Engine::set_command(std::vector<std::string> &arg) {
   if (!box_exist) throw LammpsError("Set command before simulation box is defined");
   if (natoms == 0) throw LammpsError("Set command with no atoms existing");
@@ -1340,8 +1409,9 @@ void Engine::set_command(std::vector<std::string> &arg) {
     range(2147483647L, lo, hi);
     for (int i = 0; i < natoms; i++) select[i] = (molecule[i] >= lo && molecule[i] <= hi);
   } else if (style == "group") {
-    if (id != "all") throw LammpsError("MI355X engine: only group all is supported");
-    std::fill(select.begin(), select.end(), 1);
+    const int bit = group_bit(id);
+    if (!bit) throw LammpsError("Could not find set group ID");
+    for (int i = 0; i < natoms; i++) select[i] = bit == 1 || (!gmask.empty() && (gmask[i] & bit));
   } else if (style == "region") throw LammpsError("MI355X engine: set region is not supported");
   else throw LammpsError("Illegal set command");
   auto need = [&](size_t k, size_t n) { if (k + n > arg.size()) throw LammpsError("Illegal set command"); };

@@ -46,20 +46,25 @@ __global__ __launch_bounds__(BLOCK) void k_initial_integrate(int n, double4 *__r
                                                              const double *__restrict__ fz,
                                                              const double4 *__restrict__ xhold, TypeTables tt,
                                                              double dtv, double triggersq, int check,
-                                                             int *__restrict__ flags) {
+                                                             int *__restrict__ flags, const int *__restrict__ tag,
+                                                             const int *__restrict__ gmask, int groupbit) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
   double4 r = pos[p];
-  double dtfm = tt.dtfm[(int)r.w];
-  double a = vx[p], b = vy[p], c = vz[p];
-  a += dtfm * fx[p];
-  b += dtfm * fy[p];
-  c += dtfm * fz[p];
-  r.x += dtv * a;
-  r.y += dtv * b;
-  r.z += dtv * c;
-  vx[p] = a; vy[p] = b; vz[p] = c;
-  pos[p] = r;
+  // fix nve on a group (`mask[i] & groupbit`, src/fix_nve.cpp:82): the others are not moved by THIS fix - the displacement
+  // test below (Neighbor::check_distance, every atom) still looks at them: another fix nve may have moved them
+  if (!gmask || (gmask[tag[p]] & groupbit)) {
+    double dtfm = tt.dtfm[(int)r.w];
+    double a = vx[p], b = vy[p], c = vz[p];
+    a += dtfm * fx[p];
+    b += dtfm * fy[p];
+    c += dtfm * fz[p];
+    r.x += dtv * a;
+    r.y += dtv * b;
+    r.z += dtv * c;
+    vx[p] = a; vy[p] = b; vz[p] = c;
+    pos[p] = r;
+  }
   if (check) {
     double4 h = xhold[p];
     double dx = r.x - h.x, dy = r.y - h.y, dz = r.z - h.z;
@@ -72,9 +77,12 @@ __global__ __launch_bounds__(BLOCK) void k_final_integrate(int n, const double4 
                                                            double *__restrict__ vx, double *__restrict__ vy,
                                                            double *__restrict__ vz, const double *__restrict__ fx,
                                                            const double *__restrict__ fy,
-                                                           const double *__restrict__ fz, TypeTables tt) {
+                                                           const double *__restrict__ fz, TypeTables tt,
+                                                           const int *__restrict__ tag, const int *__restrict__ gmask,
+                                                           int groupbit) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
+  if (gmask && !(gmask[tag[p]] & groupbit)) return;
   double dtfm = tt.dtfm[(int)pos[p].w];
   vx[p] += dtfm * fx[p];
   vy[p] += dtfm * fy[p];
@@ -88,11 +96,15 @@ __global__ __launch_bounds__(BLOCK) void k_langevin(int n, const double4 *__rest
                                                     const uint32_t *__restrict__ draws, double *__restrict__ vx,
                                                     double *__restrict__ vy, double *__restrict__ vz,
                                                     double *__restrict__ fx, double *__restrict__ fy,
-                                                    double *__restrict__ fz, TypeTables tt) {
+                                                    double *__restrict__ fz, TypeTables tt, const int *__restrict__ gmask,
+                                                    int groupbit) {
   int p = blockIdx.x * BLOCK + threadIdx.x;
   if (p >= n) return;
   int type = (int)pos[p].w;
   int t = tag[p];
+  // fix langevin on a group: only members draw (src/fix_langevin.cpp:660-661), in local order - `crank` is then the rank
+  // among the members (DeviceState::lgrank)
+  if (gmask && !(gmask[t] & groupbit)) return;
   int rank = IDENT ? (t - 1) : crank[t];
   double gamma1 = tt.g1[type], gamma2 = tt.g2[type];
   const double inv = 1.0 / 16777216.0;
@@ -707,22 +719,27 @@ __global__ __launch_bounds__(BLOCK, ((AHEAD || EF) ? 1 : STEP_WAVES_PER_SIMD)) v
 }
 
 // ------------------------------------------------------------------------------------------
-void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check) {
+// `groupbit` != 1: the fix acts on a group (DeviceState::gmask by tag)
+void launch_initial_integrate(DeviceState &d, const TypeTables &tt, double dtv, double triggersq, bool check, int groupbit) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
   d.bins_ready = false;     // the positions move: bins a step kernel may have left behind are stale
   hipLaunchKernelGGL(k_initial_integrate, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2],
-                     d.f[0], d.f[1], d.f[2], d.xhold, tt, dtv, triggersq, check ? 1 : 0, d.flags);
+                     d.f[0], d.f[1], d.f[2], d.xhold, tt, dtv, triggersq, check ? 1 : 0, d.flags, d.tag,
+                     groupbit != 1 ? d.gmask : (const int *)nullptr, groupbit);
 }
-void launch_final_integrate(DeviceState &d, const TypeTables &tt) {
+void launch_final_integrate(DeviceState &d, const TypeTables &tt, int groupbit) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(k_final_integrate, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2],
-                     d.f[0], d.f[1], d.f[2], tt);
+                     d.f[0], d.f[1], d.f[2], tt, d.tag, groupbit != 1 ? d.gmask : (const int *)nullptr, groupbit);
 }
-void launch_langevin(DeviceState &d, const TypeTables &tt, bool ident, bool fuse_final) {
+void launch_langevin(DeviceState &d, const TypeTables &tt, bool ident, bool fuse_final, int groupbit) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
+  const int *gm = groupbit != 1 ? d.gmask : (const int *)nullptr;
+  const int *rk = groupbit != 1 ? d.lgrank : d.crank;       // rank among the members of the group
+  if (groupbit != 1) ident = false;
 #define LGV(F, I)                                                                                               \
-  hipLaunchKernelGGL((k_langevin<F, I>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.tag, d.crank,       \
-                     d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2], tt)
+  hipLaunchKernelGGL((k_langevin<F, I>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.tag, rk,       \
+                     d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2], tt, gm, groupbit)
   if (fuse_final) { if (ident) LGV(true, true); else LGV(true, false); }
   else { if (ident) LGV(false, true); else LGV(false, false); }
 #undef LGV

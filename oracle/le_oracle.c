@@ -37,6 +37,7 @@ typedef struct {
   int *bc_tag; int counted;
   /* counters */
   int lastcount; long totalcount;
+  int *gmask;               /* fix nve / fix langevin on a group: by tag, 1 = member (NULL: group all) */
 } leo_fix;
 
 struct leo {
@@ -66,7 +67,6 @@ struct leo {
   int unload_angleflag;                 /* FixExUnload::init: angles exist -> broken bonds take their angles with them */
   int nanglelist, maxanglelist; int *al_i; signed char *al_s;        /* anglelist: 4 ints (i1 i2 i3 type) + 9 image shifts per entry */
   double eangle, vangle[6];
-  int *nve_mask;                        /* by tag: 1 = integrated by fix nve (nullptr: group all) */
   /* neighbor */
   double skin, cutneighmax, triggersq; int every, delay, check, ago;
   int newton_pair;        /* `newton on|off [bond]`: who stores an owned-owned pair (half/bin/newton vs newtoff); bonds are always newton off */
@@ -201,7 +201,7 @@ void leo_free(leo_t *s) {
   free(s->bondcount); free(s->ia); free(s->ib); free(s->ic); free(s->id); free(s->ie);
   free(s->da); free(s->db); free(s->copy);
   free(s->num_angle); free(s->angle_type); free(s->angle_a1); free(s->angle_a2); free(s->angle_a3);
-  free(s->astyle); free(s->ak); free(s->atheta0); free(s->al_i); free(s->al_s); free(s->nve_mask);
+  free(s->astyle); free(s->ak); free(s->atheta0); free(s->al_i); free(s->al_s); for (int k = 0; k < s->nfix; k++) free(s->fix[k].gmask);
   free(s);
 }
 /* src/update.cpp:132-200 (set_units) */
@@ -356,13 +356,20 @@ void leo_set_angles(leo_t *s, int nangletypes, int nangles, const int *atype, co
 void leo_angle_coeff(leo_t *s, int type, int style, double k, double theta0_deg) {
   s->astyle[type] = style; s->ak[type] = k; s->atheta0[type] = theta0_deg / 180.0 * 3.14159265358979323846;
 }
-/* fix nve on a group: flag by tag (1 = integrated).  The reference's group mask, fix_nve.cpp:82 */
-void leo_nve_group(leo_t *s, const int *flag_by_tag) {
-  free(s->nve_mask);
-  s->nve_mask = malloc(((size_t)s->maxtag + 1) * sizeof(int));
-  s->nve_mask[0] = 0;
-  memcpy(s->nve_mask + 1, flag_by_tag, (size_t)s->maxtag * sizeof(int));
+/* fix nve / fix langevin on a group: flag by tag (1 = member) for the most recently defined fix of that style.
+   The reference's group mask, fix_nve.cpp:82, fix_langevin.cpp:661 (only members draw, in local order) */
+static void set_fix_group(leo_t *s, int kind, const int *flag_by_tag) {
+  for (int k = s->nfix - 1; k >= 0; k--)
+    if (s->fix[k].kind == kind) {
+      free(s->fix[k].gmask);
+      s->fix[k].gmask = malloc(((size_t)s->maxtag + 1) * sizeof(int));
+      s->fix[k].gmask[0] = 0;
+      memcpy(s->fix[k].gmask + 1, flag_by_tag, (size_t)s->maxtag * sizeof(int));
+      return;
+    }
 }
+void leo_nve_group(leo_t *s, const int *flag_by_tag) { set_fix_group(s, FIX_NVE, flag_by_tag); }
+void leo_langevin_group(leo_t *s, const int *flag_by_tag) { set_fix_group(s, FIX_LANGEVIN, flag_by_tag); }
 void leo_ex_load_atype(leo_t *s, int fix_index, int atype) { s->fix[fix_index].atype = atype; }
 long leo_nangles(leo_t *s) { return s->nangles; }
 int leo_angle_per_atom(leo_t *s) { return s->apa; }
@@ -1014,18 +1021,18 @@ static int bond_compute(leo_t *s, int eflag) {
 
 /* ===================== fix nve / langevin ===================== */
 /* src/fix_nve.cpp:64-104, :108-141 ; dtv = dt, dtf = 0.5*dt*ftm2v (:51-58) */
-static void nve_initial(leo_t *s) {
+static void nve_initial(leo_t *s, const leo_fix *fx) {
   double dtv = s->dt, dtf = 0.5 * s->dt * s->ftm2v;
   for (int i = 0; i < s->n; i++) {
-    if (s->nve_mask && !s->nve_mask[s->tag[i]]) continue;          /* group mask, fix_nve.cpp:82 */
+    if (fx->gmask && !fx->gmask[s->tag[i]]) continue;          /* group mask, fix_nve.cpp:82 */
     double dtfm = dtf / s->mass[s->type[i]];
     for (int d = 0; d < 3; d++) { s->v[3 * i + d] += dtfm * s->f[3 * i + d]; s->x[3 * i + d] += dtv * s->v[3 * i + d]; }
   }
 }
-static void nve_final(leo_t *s) {
+static void nve_final(leo_t *s, const leo_fix *fx) {
   double dtf = 0.5 * s->dt * s->ftm2v;
   for (int i = 0; i < s->n; i++) {
-    if (s->nve_mask && !s->nve_mask[s->tag[i]]) continue;
+    if (fx->gmask && !fx->gmask[s->tag[i]]) continue;
     double dtfm = dtf / s->mass[s->type[i]];
     for (int d = 0; d < 3; d++) s->v[3 * i + d] += dtfm * s->f[3 * i + d];
   }
@@ -1046,6 +1053,7 @@ static void langevin_post_force(leo_t *s, leo_fix *fx) {
   double t_target = fx->t_start + delta * (fx->t_stop - fx->t_start);
   fx->tsqrt = sqrt(t_target);
   for (int i = 0; i < s->n; i++) {
+    if (fx->gmask && !fx->gmask[s->tag[i]]) continue;          /* mask[i] & groupbit, :661 */
     double gamma1 = fx->gfactor1[s->type[i]], gamma2 = fx->gfactor2[s->type[i]] * fx->tsqrt;
     double fran[3], fdrag[3];
     fran[0] = gamma2 * (leo_ranmars_uniform(&fx->rng) - 0.5);
@@ -1755,7 +1763,7 @@ int leo_run(leo_t *s, int nsteps) {
     s->ntimestep++;
     int eflag = (s->ntimestep == s->endstep) || (s->thermo_every > 0 && s->ntimestep % s->thermo_every == 0);
     t0 = now();
-    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_initial(s);
+    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_initial(s, &s->fix[k]);
     for (int k = 0; k < s->nfix; k++) {
       leo_fix *fx = &s->fix[k];
       if (fx->kind < FIX_EXTRUSION) continue;
@@ -1777,7 +1785,7 @@ int leo_run(leo_t *s, int nsteps) {
     t0 = now(); if (bond_compute(s, eflag)) return 1; angle_compute(s, eflag); s->t_bond += now() - t0;
     t0 = now();
     for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_post_force(s, &s->fix[k]);
-    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_final(s);
+    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_final(s, &s->fix[k]);
     s->t_modify += now() - t0;
     if (eflag) thermo_record(s);
   }

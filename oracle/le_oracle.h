@@ -70,6 +70,8 @@ void   leo_set_angles(leo_t *s, int nangletypes, int nangles, const int *atype, 
 void   leo_angle_coeff(leo_t *s, int type, int style, double k, double theta0_deg);
 /* fix ID group nve with a group other than all: flag_by_tag[t-1] = 1 for integrated atoms */
 void   leo_nve_group(leo_t *s, const int *flag_by_tag);
+/* fix ID group langevin with a group other than all: only members draw (and feel drag / noise), in local order */
+void   leo_langevin_group(leo_t *s, const int *flag_by_tag);
 /* fix ex_load ... atype N (fix_ex_load.cpp:855-954): angles of type N are created around every new bond */
 void   leo_ex_load_atype(leo_t *s, int fix_index, int atype);
 long   leo_nangles(leo_t *s);

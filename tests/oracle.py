@@ -109,6 +109,10 @@ class Oracle:
         f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
         self.L.leo_nve_group(self.h, _ip(f))
 
+    def langevin_group(self, flag_by_tag):
+        f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
+        self.L.leo_langevin_group(self.h, _ip(f))
+
     def ex_load_atype(self, fix_id, atype):
         self.L.leo_ex_load_atype(self.h, C.c_int(self.fix_ids[fix_id]), C.c_int(atype))
 

@@ -137,6 +137,38 @@ class OracleScript:
         o.special_bonds(*self.special, coul=self.special_coul)
         self.o = o
 
+    def group_define(self, a):
+        n = len(self.sys["x"])
+        groups = self.__dict__.setdefault("groups", {"all": np.ones(n, dtype=bool)})
+        name, style = a[0], a[1]
+        cur = groups.get(name, np.zeros(n, dtype=bool))
+        if style in ("type", "id", "molecule"):
+            vals = (np.asarray(self.o.types()) if self.o else np.asarray(self.sys["type"])) if style == "type" else \
+                np.arange(1, n + 1) if style == "id" else np.asarray(self.sys["mol"])
+            for t in a[2:]:
+                q = [int(v) for v in t.split(":")]
+                lo, hi, st = (q[0], q[0], 1) if len(q) == 1 else (q[0], q[1], q[2] if len(q) > 2 else 1)
+                cur = cur | ((vals >= lo) & (vals <= hi) & ((vals - lo) % st == 0))
+        elif style == "union":
+            for g in a[2:]:
+                cur = cur | groups[g]
+        elif style == "intersect":
+            sel = np.ones(n, dtype=bool)
+            for g in a[2:]:
+                sel &= groups[g]
+            cur = cur | sel
+        elif style == "subtract":
+            sel = groups[a[2]].copy()
+            for g in a[3:]:
+                sel &= ~groups[g]
+            cur = cur | sel
+        elif style != "empty":
+            raise ValueError("oracle script: group style " + style)
+        groups[name] = cur
+
+    def group_flags(self, name):
+        return self.groups[name].astype(np.int32)
+
     def line(self, text):
         text = text.split("#")[0].strip()
         if not text:
@@ -152,6 +184,8 @@ class OracleScript:
                 o.newton_pair(self.newton_pair)
         elif c in ("atom_style", "comm_modify", "boundary", "thermo_style", "thermo_modify", "echo", "log"):
             pass
+        elif c == "group":               # group ID type | id | molecule values / a:b[:stride] | union | subtract | intersect
+            self.group_define(a)
         elif c == "run_style":
             if o is None:
                 raise ValueError("oracle script: run_style before read_data")
@@ -245,10 +279,16 @@ class OracleScript:
                         o.pair_coeff(i, j, float(a[2]), float(a[3]), float(a[4]) if len(a) > 4 else -1.0)
         elif c == "fix":
             fid, style, p = a[0], a[2], a[3:]
+            if a[1] != "all" and style not in ("nve", "langevin"):
+                raise RuntimeError("the group of this fix style must be 'all'")
             if style == "nve":
                 o.fix_nve(fid)
+                if a[1] != "all":
+                    o.nve_group(self.group_flags(a[1]))
             elif style == "langevin":
                 o.fix_langevin(float(p[0]), float(p[1]), float(p[2]), int(p[3]), fid)
+                if a[1] != "all":
+                    o.langevin_group(self.group_flags(a[1]))
             elif style == "extrusion":
                 o.fix_extrusion(int(p[0]), int(p[1]), int(p[2]), int(p[3]), float(p[4]), int(p[5]),
                                 int(p[6]) if len(p) > 6 else -1, fid)

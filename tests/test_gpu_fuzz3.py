@@ -149,9 +149,26 @@ def md_scenario(seed):
     if ntypes > 1 and rng.rand() < 0.5:
         lines.append("pair_coeff 1 2 %g %g" % (rng.uniform(0.5, 1.5), rng.uniform(0.9, 1.0)))
     lines.append("timestep %g" % float(rng.choice([0.003, 0.005, 0.008])))
-    lines.append("fix 1 all nve")
+    rng4 = np.random.RandomState(41000 + seed)          # (drawn apart: the scenarios of the first MD sweep keep their seeds)
+    gn = gl = "all"
+    if rng4.rand() < 0.3 and "sort 0 0" in lines[3]:    # fixes on groups (fix langevin on a group wants atom_modify sort 0 0)
+        kind = str(rng4.choice(["type", "id", "molecule"]))
+        if kind == "type":
+            lines.append("group g type %d" % int(rng4.randint(1, ntypes + 1)))
+        elif kind == "id":
+            lo = int(rng4.randint(1, n // 2))
+            lines.append("group g id %d:%d:%d" % (lo, int(rng4.randint(lo, n + 1)), int(rng4.choice([1, 2, 3]))))
+        else:
+            lines.append("group g molecule %d" % int(rng4.randint(1, nchains + 1)))
+        if rng4.rand() < 0.5:
+            lines.append("group h subtract all g")
+            gn = "h"
+        else:
+            gn = "g"
+        gl = gn if rng4.rand() < 0.7 else "all"
+    lines.append("fix 1 %s nve" % gn)
     if rng.rand() < 0.7:
-        lines.append("fix 2 all langevin %g %g %g %d" % (rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5), float(rng.choice([0.5, 1.0, 10.0])), int(rng.randint(1, 900000))))
+        lines.append("fix 2 %s langevin %g %g %g %d" % (gl, rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5), float(rng.choice([0.5, 1.0, 10.0])), int(rng.randint(1, 900000))))
     if rng.rand() < 0.3:
         lines.append("thermo_modify norm %s" % str(rng.choice(["yes", "no"])))
     lines.append("thermo %d" % int(rng.choice([5, 10, 25, 1000])))

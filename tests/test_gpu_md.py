@@ -251,3 +251,52 @@ def test_fourmol_bond_known_answers(tmp_path, style, fixture):
     assert abs(lmp.get_thermo("ebond") - g["run_energy"]) / abs(g["run_energy"]) < 5e-11
     assert relerr(lmp.gather("f"), g["run_forces"]) < 1e-10
     lmp.close()
+
+
+@pytest.mark.parametrize("case", ["frozen-type", "id-stride", "langevin-all", "two-nve", "molecule+LE"])
+def test_fixes_on_groups(tmp_path, case):
+    """`group` (type / id ranges with stride / molecule / union / subtract) and fix nve / fix langevin on a group other than all
+    (src/fix_nve.cpp:82, src/fix_langevin.cpp:661): atoms outside fix nve's group stay where they are, only the members of fix
+    langevin's group draw - three draws per member and call, handed out in local order.  Against the oracle."""
+    n = 6000
+    types = 1 + (np.arange(n) % 7 == 0).astype(np.int32)
+    s = lattice_chain(n, nchains=3, seed=23, jitter=0.04, types=types)
+    s["mass"] = [1.0, 1.0]
+    head = CHAIN_SCRIPT
+    if case == "frozen-type":        # every seventh bead is an anchor: neither integrated nor thermostatted
+        body = "group mobile type 1\nfix 1 mobile nve\nfix 2 mobile langevin 1.0 1.0 1.0 5544\n"
+    elif case == "id-stride":
+        body = "group a id 1:3000:2 4000 4500:5000\ngroup b id 3001:3999\ngroup ab union a b\nfix 1 ab nve\nfix 2 ab langevin 1.0 1.2 2.0 91\n"
+    elif case == "langevin-all":     # thermostat on everything, integration on a subset (forces on the others are simply unused)
+        body = "group anchors type 2\ngroup mobile subtract all anchors\nfix 1 mobile nve\nfix 2 all langevin 1.0 1.0 1.0 77\n"
+    elif case == "two-nve":          # two integrators on disjoint groups, one thermostat on one of them
+        body = "group lo id 1:2999\ngroup hi id 3000:6000\nfix 1 lo nve\nfix 3 hi nve\nfix 2 hi langevin 0.8 0.8 1.0 313\n"
+    else:                            # the first chain frozen, loop extrusion on everything
+        body = ("group free molecule 2 3\nfix 1 free nve\nfix 2 free langevin 1.0 1.0 1.0 904297\n"
+                "fix loop all extrusion 7 1 1 1 1.0 2\nfix loading all ex_load 5 1 1 1.12 2 prob 0.5 684474 iparam 1 1 jparam 1 1\n"
+                "fix unloading all ex_unload 6 2 0.5 prob 0.3 456456\n")
+        head = head.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0")
+    script = head + body + "thermo 20\nrun 35\nrun 25\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert relerr(p.gather("x"), o.x()) < 1e-9
+    assert relerr(p.gather("v"), o.v()) < 1e-8
+    to = o.thermo()
+    for k, key in enumerate(("temp", "epair", "emol", "etotal", "press")):
+        assert abs(p.get_thermo(key) - to[k]) <= 1e-9 * max(1.0, abs(to[k])), key
+    assert p.stat("neigh_builds") == o.neigh_builds()
+    if case == "frozen-type":
+        frozen = types == 2
+        assert np.array_equal(p.gather("x")[frozen], s["x"][frozen])
+    if case == "molecule+LE":
+        assert p.bond_set() == o.bond_set() and len([b for b in o.bond_set() if b[0] == 2]) > 3
+
+
+def test_group_command_errors(tmp_path):
+    from lammps_le_amd import LammpsError
+    s = lattice_chain(3000, seed=3)
+    for bad, msg in (("group all type 1\n", "Cannot change the group all"), ("fix 1 nosuch nve\n", "Could not find fix group ID"),
+                     ("group g region box\n", "not supported"), ("group g union nosuch\n", "Group ID does not exist"),
+                     ("group g type 1\nfix loop g extrusion 7 1 1 1 1.0 2\n", "must be 'all'")):
+        with pytest.raises(LammpsError, match=msg):
+            run_product(CHAIN_SCRIPT + bad + "run 1\n", s, tmp_path)
