@@ -304,15 +304,18 @@ struct ExLoadParams {
   int iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype;
   double cutsq, fraction;
   int atype;        // angle type created around every new bond (0: none)
+  int groupbit = 1; // both atoms of a candidate pair must be in the fix's group (fix_ex_load.cpp:435,450)
 };
 struct ExUnloadParams {
   int btype;
   double cutsq, fraction;
   int angleflag;    // angles exist: a broken bond takes the angles it is part of with it (fix_ex_unload.cpp:149-152)
+  int groupbit = 1; // both ends of a bond must be in the fix's group (fix_ex_unload.cpp:228-229)
 };
 struct ExtrusionParams {
   int neutral, ctcf_left, ctcf_right, ctcf_lr, btype;
   double through_prob;
+  int groupbit = 1; // both ends of an extruder bond must be in the fix's group (fix_extrusion.cpp:373-376)
 };
 void le_rng_upload(DeviceState &d, int slot, const RanMarsInt &r);
 void le_rng_download(DeviceState &d, int slot, RanMarsInt &r);

@@ -638,6 +638,11 @@ static bool fixes_on_groups(Engine *e) {
   for (auto &f : e->fixes) if (f->groupbit != 1) return true;
   return false;
 }
+static bool md_fixes_on_groups(Engine *e) {      // fix nve / fix langevin: the ones the fused step kernel stands for
+  for (auto &f : e->fixes)
+    if (f->groupbit != 1 && (dynamic_cast<FixNVE *>(f.get()) || dynamic_cast<FixLangevin *>(f.get()))) return true;
+  return false;
+}
 
 static bool timed_begin(Engine *e) {
   DeviceState &d = *e->dev;
@@ -813,7 +818,7 @@ void Engine::iterate(long nsteps) {
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
   // fix nve / fix langevin on a group other than all: the unfused kernels, which test the bead's group bits
   const std::vector<int> nbits = nve_bits(this);
-  if (fixes_on_groups(this)) fusable = false;
+  if (md_fixes_on_groups(this)) fusable = false;
   // bond morse (the reference's unit-test partner of bond hybrid, not a style of the chromatin model) lives in the
   // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
   for (int b = 1; b <= nbondtypes; b++) if (bondtab.style[b] == 3) fusable = false;
@@ -1095,7 +1100,9 @@ void Engine::run(long nsteps) {
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
   if (fixes_on_groups(this)) {
-    if (world > 1 || respa_levels > 0) throw LammpsError("MI355X engine: fixes on a group other than all run on one GPU with run_style verlet");
+    if (world > 1) throw LammpsError("MI355X engine: fixes on a group other than all run on one GPU");
+    if (respa_levels > 0 && md_fixes_on_groups(this))
+      throw LammpsError("MI355X engine: fix nve / fix langevin on a group other than all run with run_style verlet");
     for (auto &f : fixes)
       if (dynamic_cast<FixLangevin *>(f.get()) && f->groupbit != 1 && sortfreq > 0)
         throw LammpsError("MI355X engine: fix langevin on a group needs atom_modify sort 0 0 (its draws follow the local order)");

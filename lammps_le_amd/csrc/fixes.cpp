@@ -11,9 +11,6 @@ namespace lmp_le {
 void dd_gather_positions(DeviceState &d, Comm &comm);
 void dd_gather_needed(DeviceState &d, Comm &comm, int btype, bool with_nbrs);
 
-static void need_all(const std::vector<std::string> &arg) {
-  if (arg[1] != "all") throw LammpsError("MI355X engine: the group of this fix style must be 'all' (got " + arg[1] + ")");
-}
 static int fix_group(Engine *e, const std::vector<std::string> &arg) {      // src/fix.cpp:67-69
   const int bit = e->group_bit(arg[1]);
   if (!bit) throw LammpsError("Could not find fix group ID");
@@ -58,7 +55,7 @@ FixLangevin::FixLangevin(Engine *e, const std::vector<std::string> &arg) {
 FixExtrusion::FixExtrusion(Engine *e, const std::vector<std::string> &arg) {
   eng = e; id = arg[0]; group = arg[1]; style = arg[2];
   if (arg.size() < 9) throw LammpsError("Illegal fix extrusion command");
-  need_all(arg);
+  groupbit = fix_group(e, arg);
   nevery = inumeric(arg[3]);
   if (nevery <= 0) throw LammpsError("Illegal fix extrusion command, n_steps <= 0");
   neutral = inumeric(arg[4]); ctcf_left = inumeric(arg[5]); ctcf_right = inumeric(arg[6]);
@@ -92,7 +89,7 @@ FixExLoad::FixExLoad(Engine *e, const std::vector<std::string> &arg) {
   phase = stock ? 0 : 3;                                  // src/MC/fix_bond_create.cpp:356 vs src/USER-LE/fix_ex_load.cpp:338
   const std::string ill = "Illegal fix " + style + " command";
   if (arg.size() < 8) throw LammpsError(ill);
-  need_all(arg);
+  groupbit = fix_group(e, arg);
   nevery = inumeric(arg[3]);
   if (nevery <= 0) throw LammpsError(ill);
   iatomtype = inumeric(arg[4]); jatomtype = inumeric(arg[5]);
@@ -172,7 +169,7 @@ FixExUnload::FixExUnload(Engine *e, const std::vector<std::string> &arg) {
   phase = (style == "bond/break") ? 0 : 2;
   const std::string ill = "Illegal fix " + style + " command";
   if (arg.size() < 6) throw LammpsError(ill);
-  need_all(arg);
+  groupbit = fix_group(e, arg);
   nevery = inumeric(arg[3]);
   if (nevery <= 0) throw LammpsError(ill);
   btype = inumeric(arg[4]);
@@ -239,7 +236,7 @@ void FixExtrusion::post_integrate() {
     // bead's (tag, x, xhold) only when the visit order is not the canonical one
     if (dd_le_fast(d)) dd_gather_needed(d, *eng->comm, btype, true); else dd_gather_positions(d, *eng->comm);
   }
-  ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob};
+  ExtrusionParams p{neutral, ctcf_left, ctcf_right, ctcf_lr, btype, through_prob, groupbit};
   launch_extrusion(d, p, slot);
   d.topo_dirty = true;
   d.bond_pack_dirty = true;
@@ -260,7 +257,7 @@ void FixExLoad::post_integrate() {
   // angles around new bonds only `if (atype && force->angle)` (fix_ex_load.cpp:236-240)
   const int angle_type_new = (atype > 0 && eng->angles_active()) ? atype : 0;
   if (angle_type_new > eng->nangletypes) throw LammpsError("Fix " + style + " angle type is invalid");
-  ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction, angle_type_new};
+  ExLoadParams p{iatomtype, jatomtype, imaxbond, inewtype, jmaxbond, jnewtype, btype, cutsq, fraction, angle_type_new, groupbit};
   if (stock) {
     if (eng->world > 1) dd_gather_positions(d, *eng->comm);   // current positions by tag (ghost slots lag one step here)
     launch_bond_create(d, p, slot, bondcount.data(), (int)bondcount.size(), eng->comm);
@@ -292,7 +289,7 @@ void FixExUnload::post_integrate() {
   if (eng->world > 1) {
     if (dd_le_fast(d)) dd_gather_needed(d, *eng->comm, btype, false); else dd_gather_positions(d, *eng->comm);
   }
-  ExUnloadParams p{btype, cutsq, fraction, angleflag};
+  ExUnloadParams p{btype, cutsq, fraction, angleflag, groupbit};
   launch_ex_unload(d, p, slot);
   d.topo_dirty = true;
   d.bond_pack_dirty = true;

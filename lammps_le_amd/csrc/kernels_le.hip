@@ -34,11 +34,15 @@ struct Topo {   // tag-indexed topology views
   const int *num_bond0, *bond_type0, *bond_atom0;   // bond tables at the last reneighbor (= neighbor->bondlist)
   int apa;                                           // angles per atom (0: no angle storage)
   int *num_angle, *angle_type, *angle_a1, *angle_a2, *angle_a3;
+  const int *gmask;                                  // the calling fix's group: bits by tag (nullptr: group all)
+  int gbit;
 };
-static Topo topo_of(DeviceState &d) {
+static Topo topo_of(DeviceState &d, int groupbit = 1) {
   return Topo{d.maxtag, d.bpa, d.maxspecial, d.num_bond, d.bond_type, d.bond_atom, d.nspecial, d.special, d.type_t,
-              d.num_bond0, d.bond_type0, d.bond_atom0, d.apa, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3};
+              d.num_bond0, d.bond_type0, d.bond_atom0, d.apa, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3,
+              groupbit != 1 ? d.gmask : (const int *)nullptr, groupbit};
 }
+__device__ __forceinline__ bool in_group(const Topo &tp, int t) { return !tp.gmask || (tp.gmask[t] & tp.gbit); }   // mask[i] & groupbit
 
 // ------------------------------------------------------------------------------------------
 // exclusive scan of in[0..m) -> out[0..m], out[m] = total, also written to *total_slot
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base(Topo tp, ExLoadParams P, 
     // and its neighbor list are the ones consulted (fix_ex_load.cpp:486-488)
     const bool swap = (V.crank || V.newton) && !stores_pair(V, i, j);
     const int is = swap ? j : i, js = swap ? i : j;
+    possible = possible && in_group(tp, i) && in_group(tp, j);        // fix_ex_load.cpp:435,450
     if (possible && tp.num_bond[i] == 2 && tp.num_bond[j] == 2 && tp.num_bond[mid] == 2) {
       const int *sl = tp.special + (size_t)is * tp.ms;
       int n1 = tp.nspecial[3 * (size_t)is];
@@ -444,7 +449,8 @@ __global__ __launch_bounds__(BLOCK) void k_exload_base_dd(Topo tp, ExLoadParams 
       } else if (itype == P.jatomtype && jtype == P.iatomtype) {
         if ((P.jmaxbond == 0 || bc[i] < P.jmaxbond) && (P.imaxbond == 0 || bc[j] < P.imaxbond)) possible = true;
       }
-      if (possible && tp.num_bond[i] == 2 && tp.num_bond[j] == 2 && tp.num_bond[mid] == 2) {
+      possible = possible && in_group(tp, i) && in_group(tp, j);        // fix_ex_load.cpp:435,450
+    if (possible && tp.num_bond[i] == 2 && tp.num_bond[j] == 2 && tp.num_bond[mid] == 2) {
         const int *sl = tp.special + (size_t)i * tp.ms;
         int n1 = tp.nspecial[3 * (size_t)i];
         for (int k = 0; k < n1; k++) if (sl[k] == j) possible = false;
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(BLOCK) void k_exload_create(Topo tp, ExLoadParams P
 }
 
 void launch_ex_load(DeviceState &d, const ExLoadParams &P, int slot, Comm *comm) {
-  Topo tp = topo_of(d);
+  Topo tp = topo_of(d, P.groupbit);
   int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
   hipStream_t st = d.stream;
   int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams
   const int t = tag[p];
   const int itype = tp.type_t[t];
   int best_tag = 0;
-  if (itype == P.iatomtype || itype == P.jatomtype) {
+  if ((itype == P.iatomtype || itype == P.jatomtype) && in_group(tp, t)) {      // fix_bond_create.cpp:421
     const double4 ri = xt ? xt[t] : pos[p];
     const int bci = bc[t];
     const int *sl = tp.special + (size_t)t * tp.ms;
@@ -711,6 +717,7 @@ __global__ __launch_bounds__(BLOCK) void k_bcreate_partner(Topo tp, ExLoadParams
     for (int k = (w >> NN_BOND_SHIFT) & NN_NBOND_MASK; k < nn; k++) {
       const int j = neigh[(size_t)k * npad + p] & NEIGH_MASK;
       const int tj = tag[j];
+      if (!in_group(tp, tj)) continue;                                            // :432
       const int jtype = tp.type_t[tj];
       bool possible = false;
       if (itype == P.iatomtype && jtype == P.jatomtype) {
@@ -739,7 +746,7 @@ __global__ void k_nonzero(int n, const int *__restrict__ a, int *__restrict__ ou
   if (i < n) out[i] = a[i] != 0;
 }
 void launch_bond_create(DeviceState &d, const ExLoadParams &P, int slot, const int *bondcount, int nt_host, Comm *comm) {
-  Topo tp = topo_of(d);
+  Topo tp = topo_of(d, P.groupbit);
   int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
   hipStream_t st = d.stream;
   int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
@@ -785,6 +792,7 @@ __global__ __launch_bounds__(BLOCK) void k_exunload_partner(Topo tp, ExUnloadPar
     for (int m = 0; m < nb; m++) {
       if (tp.bond_type0[(size_t)t * tp.bpa + m] != P.btype) continue;
       int u = tp.bond_atom0[(size_t)t * tp.bpa + m];
+      if (!in_group(tp, t) || !in_group(tp, u)) continue;                       // fix_ex_unload.cpp:228-229
       double4 xj = xt[u], hj = xht[u];
       // partner image frozen at the last reneighbor (closest image then; ntopo_bond_all.cpp:53,64)
       double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
@@ -828,7 +836,7 @@ __global__ __launch_bounds__(BLOCK) void k_exunload_break(Topo tp, ExUnloadParam
   fin[t] = f;
 }
 void launch_ex_unload(DeviceState &d, const ExUnloadParams &P, int slot) {
-  Topo tp = topo_of(d);
+  Topo tp = topo_of(d, P.groupbit);
   int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
   hipStream_t st = d.stream;
   int *bc = d.le_i[I_BC], *partner = d.le_i[I_A], *has = d.le_i[I_B], *didx = d.le_i[I_C], *fin = d.le_i[I_D];
@@ -859,6 +867,7 @@ __global__ __launch_bounds__(BLOCK) void k_ext_listflag(Topo tp, int btype, Box 
     int nb = tp.num_bond0[t];                       // bond-list entries (last reneighbor)
     for (int m = 0; m < nb; m++)
       if (tp.bond_type0[(size_t)t * tp.bpa + m] == btype) { u = tp.bond_atom0[(size_t)t * tp.bpa + m]; break; }
+    if (u && !(in_group(tp, t) && in_group(tp, u))) u = 0;                      // fix_extrusion.cpp:373-376
     if (u) {
       double4 hi = xht[t], hj = xht[u];
       double h0 = hi.x - hj.x, h1 = hi.y - hj.y, h2 = hi.z - hj.z;
@@ -1043,7 +1052,7 @@ __global__ __launch_bounds__(BLOCK) void k_ext_create(Topo tp, int btype, const 
 }
 
 void launch_extrusion(DeviceState &d, const ExtrusionParams &P, int slot) {
-  Topo tp = topo_of(d);
+  Topo tp = topo_of(d, P.groupbit);
   int T = d.maxtag, nt = T + 2, nb = (nt + BLOCK - 1) / BLOCK;
   hipStream_t st = d.stream;
   int *bc = d.le_i[I_BC], *lflag = d.le_i[I_A], *lidx = d.le_i[I_B], *lpart = d.le_i[I_C], *list_l = d.le_i[I_D],

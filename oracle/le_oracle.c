@@ -368,6 +368,16 @@ static void set_fix_group(leo_t *s, int kind, const int *flag_by_tag) {
       return;
     }
 }
+/* any fix by index: the LE fixes test both atoms of a bond / candidate pair against their group
+   (fix_extrusion.cpp:373-376, fix_ex_load.cpp:435,450, fix_ex_unload.cpp:228-229, and their src/MC parents) */
+void leo_fix_group(leo_t *s, int fix_index, const int *flag_by_tag) {
+  leo_fix *f = &s->fix[fix_index];
+  free(f->gmask);
+  f->gmask = malloc(((size_t)s->maxtag + 1) * sizeof(int));
+  f->gmask[0] = 0;
+  memcpy(f->gmask + 1, flag_by_tag, (size_t)s->maxtag * sizeof(int));
+}
+#define IN_GROUP(s, fx, i) (!(fx)->gmask || (fx)->gmask[(s)->tag[i]])
 void leo_nve_group(leo_t *s, const int *flag_by_tag) { set_fix_group(s, FIX_NVE, flag_by_tag); }
 void leo_langevin_group(leo_t *s, const int *flag_by_tag) { set_fix_group(s, FIX_LANGEVIN, flag_by_tag); }
 void leo_ex_load_atype(leo_t *s, int fix_index, int atype) { s->fix[fix_index].atype = atype; }
@@ -1219,6 +1229,7 @@ static int fire_extrusion(leo_t *s, leo_fix *fx) {
   /* Phase 1 (:368-516): loop over the bond list of the last reneighbor */
   for (int k = 0; k < s->nbondlist; k++) {
     int i1 = s->bl_i[k], i2 = s->bl_j[k];
+    if (!IN_GROUP(s, fx, i1) || !IN_GROUP(s, fx, i2)) continue;     /* :373-376 */
     if (s->bl_t[k] != fx->btype) continue;
     if (tag[i1] > tag[i2]) { int t = i1; i1 = i2; i2 = t; }
     else if (tag[i1] == tag[i2]) return seterr(s, "Fix extrusion, bond i-i exists");
@@ -1365,8 +1376,10 @@ static int fire_ex_load(leo_t *s, leo_fix *fx) {
     if (j1 >= 0 && stores_pair(s, i, j1)) cand[ncand++] = j1;      /* the pairs the scan meets in i's list */
     if (j2 >= 0 && stores_pair(s, i, j2)) cand[ncand++] = j2;
     if (ncand == 2 && cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+    if (!IN_GROUP(s, fx, i)) continue;                               /* :435 */
     for (int c = 0; c < ncand; c++) {
       int j = cand[c];
+      if (!IN_GROUP(s, fx, j)) continue;                             /* :450 */
       int itype = s->type[i], jtype = s->type[j], possible = 0;
       if (itype == fx->iatomtype && jtype == fx->jatomtype) {
         if ((fx->imaxbond == 0 || s->bondcount[i] < fx->imaxbond) && (fx->jmaxbond == 0 || s->bondcount[j] < fx->jmaxbond)) possible = 1;
@@ -1450,8 +1463,10 @@ static int fire_bond_create(leo_t *s, leo_fix *fx) {
   if (s->pair_on)
     for (int i = 0; i < n; i++) {
       int itype = s->type[i];
+      if (!IN_GROUP(s, fx, i)) continue;                             /* fix_bond_create.cpp:421 */
       for (int p = s->firstneigh[i]; p < s->firstneigh[i + 1]; p++) {
         int j = PJ_INDEX(s->pj[p]);
+        if (!IN_GROUP(s, fx, j)) continue;                           /* :432 */
         int jtype = s->type[j], possible = 0;
         if (itype == fx->iatomtype && jtype == fx->jatomtype) {
           if ((fx->imaxbond == 0 || s->bondcount[i] < fx->imaxbond) && (fx->jmaxbond == 0 || s->bondcount[j] < fx->jmaxbond)) possible = 1;
@@ -1513,6 +1528,7 @@ static int fire_ex_unload(leo_t *s, leo_fix *fx) {
   for (int i = 0; i < n; i++) { partner[i] = 0; finalpartner[i] = 0; distsq[i] = 0.0; }
   for (int k = 0; k < s->nbondlist; k++) {
     int i1 = s->bl_i[k], i2 = s->bl_j[k];
+    if (!IN_GROUP(s, fx, i1) || !IN_GROUP(s, fx, i2)) continue;     /* fix_ex_unload.cpp:228-229 */
     if (s->bl_t[k] != fx->btype) continue;
     const signed char *sh = s->bl_s + 3 * k;
     int ghost = sh[0] || sh[1] || sh[2];

@@ -69,6 +69,8 @@ void   leo_set_angles(leo_t *s, int nangletypes, int nangles, const int *atype, 
 /* angle_coeff: style 1 = harmonic (K, theta0 in degrees), 2 = cosine (K) */
 void   leo_angle_coeff(leo_t *s, int type, int style, double k, double theta0_deg);
 /* fix ID group nve with a group other than all: flag_by_tag[t-1] = 1 for integrated atoms */
+/* the group of fix number fix_index (LE fixes and their src/MC parents: both atoms of a bond / candidate pair must be members) */
+void   leo_fix_group(leo_t *s, int fix_index, const int *flag_by_tag);
 void   leo_nve_group(leo_t *s, const int *flag_by_tag);
 /* fix ID group langevin with a group other than all: only members draw (and feel drag / noise), in local order */
 void   leo_langevin_group(leo_t *s, const int *flag_by_tag);

@@ -109,6 +109,10 @@ class Oracle:
         f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
         self.L.leo_nve_group(self.h, _ip(f))
 
+    def fix_group(self, fix_id, flag_by_tag):
+        f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
+        self.L.leo_fix_group(self.h, C.c_int(self.fix_ids[fix_id]), _ip(f))
+
     def langevin_group(self, flag_by_tag):
         f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
         self.L.leo_langevin_group(self.h, _ip(f))

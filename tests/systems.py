@@ -279,8 +279,6 @@ class OracleScript:
                         o.pair_coeff(i, j, float(a[2]), float(a[3]), float(a[4]) if len(a) > 4 else -1.0)
         elif c == "fix":
             fid, style, p = a[0], a[2], a[3:]
-            if a[1] != "all" and style not in ("nve", "langevin"):
-                raise RuntimeError("the group of this fix style must be 'all'")
             if style == "nve":
                 o.fix_nve(fid)
                 if a[1] != "all":
@@ -326,6 +324,8 @@ class OracleScript:
                 (o.fix_ex_unload if style == "ex_unload" else o.fix_bond_break)(int(p[0]), int(p[1]), float(p[2]), fid=fid, **kw)
             else:
                 raise ValueError("oracle script: unknown fix " + style)
+            if a[1] != "all" and style not in ("nve", "langevin"):
+                o.fix_group(fid, self.group_flags(a[1]))
         elif c == "velocity":
             self._velocity(a)
         elif c == "timestep":

@@ -86,6 +86,14 @@ def scenario(seed):
     if rng.rand() < 0.3:
         fixes.append("fix unloading2 all ex_unload %d 2 0.9 prob 0.3 %d" % (int(rng.randint(5, 14)), 400 + seed))
         ids.append("unloading2")
+    rng5 = np.random.RandomState(51000 + seed)      # (drawn apart, as above)
+    group_line = ""
+    if rng5.rand() < 0.2:                            # the LE fixes on a group: both atoms of a bond / candidate pair must be members
+        lo = int(rng5.randint(1, n // 2))
+        group_line = "group g id %d:%d\n" % (lo, int(rng5.randint(lo + n // 4, n + 1)))
+        which = rng5.rand(len(fixes)) < 0.7
+        fixes = [f.replace(" all ", " g ", 1) if (k >= 2 and which[k]) else f for k, f in enumerate(fixes)]
+    fixes = [group_line.strip()] + fixes if group_line else fixes
     tail = "thermo 10\n"
     if flavour == "respa":
         tail += str(rng.choice(RESPA)) + "\n"

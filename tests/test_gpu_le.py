@@ -416,3 +416,35 @@ def test_le_fixes_degenerate_inputs(tmp_path, case):
         assert loads > 0 and o.fix_vector("unloading")[1] > 0
     else:
         assert loads > 0
+
+
+@pytest.mark.parametrize("which", ["all-three", "loader-only", "stock"])
+def test_le_fixes_on_a_group(tmp_path, which):
+    """The LE fixes (and their src/MC parents) on a group other than all: a bond / a candidate pair counts only if BOTH of its
+    atoms are members (fix_extrusion.cpp:373-376, fix_ex_load.cpp:435,450, fix_ex_unload.cpp:228-229).  Three chains, the
+    fixes on two of them; against the oracle, and no extruder ever touches the third chain."""
+    n = 3600
+    s = melted(n, nchains=3, seed=1, types=barrier_types(n, 5))
+    grp = "group two molecule 1 2\n"
+    if which == "all-three":
+        script = le_script(tp=0.5, n1=5, nl=4, nu=6).replace("fix loop all", "fix loop two").replace("fix loading all", "fix loading two") \
+            .replace("fix unloading all", "fix unloading two").replace("fix 1 all nve", grp + "fix 1 all nve") + "run 60\n"
+        ids = ("loop", "loading", "unloading")
+    elif which == "loader-only":
+        script = le_script(tp=0.5, n1=5, nl=4, nu=6).replace("fix loading all", "fix loading two").replace("fix 1 all nve", grp + "fix 1 all nve") + "run 60\n"
+        ids = ("loop", "loading", "unloading")
+    else:
+        s["type"] = np.where(np.random.RandomState(3).rand(n) < 0.3, 2, 1).astype(np.int32)
+        s["ntypes"], s["mass"] = 3, [1.0, 1.0, 1.0]
+        script = CHAIN_SCRIPT.replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 5.0 10.0 1.0 1.0") + grp + (
+            "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
+            "fix creating two bond/create 10 2 2 1.1 2 iparam 1 3 jparam 1 3 prob 0.5 8847\n"
+            "fix breaking two bond/break 15 2 1.3 prob 0.5 2211\nthermo 10\nrun 65\n")
+        ids = ("creating", "breaking")
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ids)
+    ext = [b for b in o.bond_set() if b[0] == 2]
+    assert len(ext) > 3
+    per = n // 3
+    assert all(b[1] <= 2 * per and b[2] <= 2 * per for b in ext)          # nothing on the third chain
