@@ -70,6 +70,10 @@ def dd_scenario(seed):
              "fix loop all extrusion %d 1 2 3 %g 2 %s" % (n1, tp, lr),
              "fix loading all ex_load %d 1 1 1.12 2 %s iparam 1 %d jparam 1 %d%s" % (nl, lprob, nt, nt, atype),
              "fix unloading all ex_unload %d 2 %g %s" % (nu, rmax, uprob)]
+    if rng3.rand() < 0.25:                           # the LE fixes on a group (masks replicated by tag, like the topology)
+        lo = int(rng3.randint(1, n // 2))
+        fixes = ["group g id %d:%d" % (lo, int(rng3.randint(lo + n // 4, n + 1)))] + [f.replace(" all ", " g ", 1) if k >= 2 else f for k, f in enumerate(fixes)]
+        flavour += "+group"
     total = int(rng.randint(25, 60))
     cuts = sorted(set(int(c) for c in rng.randint(1, total, size=int(rng.randint(0, 3)))))
     runs, last = [], 0
