@@ -949,7 +949,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 // copies in place that adds up to one evaluation per atom, with copies out of step it is what the reference computes
 // (found by the mixed sweep, tests/test_gpu_fuzz2.py seeds 17, 74, 125).
 __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, int npad, const int *__restrict__ crank,
-                                                      const int *__restrict__ map, const double4 *__restrict__ pos, Box box, int n_owned,
+                                                      const int *__restrict__ map, const float4 *__restrict__ pos, Box box, int n_owned,
                                                       const int *__restrict__ num_angle, const int *__restrict__ angle_type,
                                                       const int *__restrict__ a1, const int *__restrict__ a2,
                                                       const int *__restrict__ a3, int *__restrict__ eff_n,
@@ -970,11 +970,13 @@ __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, 
     // within the ghost cutoff of a face, k_dd_borders)
     if (n_owned >= 0 && !((p[0] >= 0 && p[0] < n_owned) || (p[1] >= 0 && p[1] < n_owned) || (p[2] >= 0 && p[2] < n_owned))) continue;
     if (p[0] < 0 || p[1] < 0 || p[2] < 0 || pi < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
-    const double4 ri = pos[pi];
+    // (the float copy of the build-time positions decides "more than half a box away": an angle's arms are a few sigma long)
+    const float4 ri = pos[pi];
     bool listed = true, ghost[3];
     for (int q = 0; q < 3; q++) {
-      const double4 rq = pos[p[q]];
-      ghost[q] = fabs(ri.x - rq.x) > box.half[0] || fabs(ri.y - rq.y) > box.half[1] || fabs(ri.z - rq.z) > box.half[2];
+      const float4 rq = pos[p[q]];
+      ghost[q] = fabs((double)ri.x - (double)rq.x) > box.half[0] || fabs((double)ri.y - (double)rq.y) > box.half[1] ||
+                 fabs((double)ri.z - (double)rq.z) > box.half[2];
       listed = listed && (ghost[q] || li <= (crank ? crank[t[q]] : t[q]));
     }
     if (!listed) continue;
@@ -1017,7 +1019,7 @@ void launch_angle_list(DeviceState &d) {
   const int T = d.maxtag, nb = std::max(1, (T + BLOCK - 1) / BLOCK);
   HIP_CHECK(hipMemsetAsync(d.eff_n, 0, (size_t)d.npad * sizeof(int), d.stream));
   hipLaunchKernelGGL(k_angle_list, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, d.ecap, d.npad, d.ident_order ? (const int *)nullptr : d.crank,
-                     d.map, d.pos, d.box, d.dd ? d.n : -1, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
+                     d.map, d.posf, d.box, d.dd ? d.n : -1, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
   hipLaunchKernelGGL(k_angle_sort, dim3(std::max(1, (d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.npad, d.eff_n,
                      (int4 *)d.eff_rec);
 }
