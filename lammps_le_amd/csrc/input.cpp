@@ -1694,7 +1694,6 @@ void Engine::write_periodic_restart(long step) {
 
 void Engine::write_restart(const std::string &path) {
   if (!box_exist) throw LammpsError("Write_restart command before simulation box is defined");   // src/write_restart.cpp:62
-  if (apa) throw LammpsError("MI355X engine: restart files do not hold angles yet (use write_data)");
   download();
   // the LE fixes' generators live on the device while a run has used them
   int slot = 0;
@@ -1735,6 +1734,19 @@ void Engine::write_restart(const std::string &path) {
     else continue;
     w.str(f->id); w.str(f->style); w.vec(b);
   }
+  // optional tagged sections behind the round-2 layout (a reader without them stops at the end of the file)
+  if (!gmask.empty()) {        // groups: names in bit order + masks (as the reference's restart files carry them, src/group.cpp)
+    w.str("GROUPS");
+    uint64_t ng = group_names.size(); w.pod(ng);
+    for (auto &g : group_names) w.str(g);
+    w.vec(gmask);
+  }
+  if (apa) {                   // angles: tables, style and coefficients
+    w.str("ANGLES");
+    w.pod(nangletypes); w.pod(extra_angle); w.pod(apa); w.pod(nangles);
+    w.vec(num_angle); w.vec(angle_type); w.vec(angle_a1); w.vec(angle_a2); w.vec(angle_a3);
+    w.str(angle_style_name); w.pod(angtab);
+  }
   fclose(fp);
 }
 
@@ -1770,9 +1782,31 @@ void Engine::read_restart(const std::string &path) {
       b.insert(b.begin() + style.size(), (unsigned char)0);
       restart_fix_state[id] = b;
     }
+    group_names = {"all"}; gmask.clear();
+    nangletypes = 0; extra_angle = 0; apa = 0; nangles = 0;
+    num_angle.clear(); angle_type.clear(); angle_a1.clear(); angle_a2.clear(); angle_a3.clear(); angle_style_name.clear();
+    for (;;) {                  // optional tagged sections
+      int c = fgetc(fp);
+      if (c == EOF) break;
+      ungetc(c, fp);
+      std::string tag;
+      r.str(tag);
+      if (tag == "GROUPS") {
+        uint64_t ng; r.pod(ng);
+        if (ng < 1 || ng > 31) throw LammpsError("Restart file is inconsistent");
+        group_names.resize(ng);
+        for (auto &g : group_names) r.str(g);
+        r.vec(gmask);
+      } else if (tag == "ANGLES") {
+        r.pod(nangletypes); r.pod(extra_angle); r.pod(apa); r.pod(nangles);
+        r.vec(num_angle); r.vec(angle_type); r.vec(angle_a1); r.vec(angle_a2); r.vec(angle_a3);
+        r.str(angle_style_name); r.pod(angtab);
+      } else throw LammpsError("Restart file holds a section this build does not know: " + tag);
+    }
   } catch (...) { fclose(fp); throw; }
   fclose(fp);
   if (x.size() != 3 * (size_t)natoms || num_bond.size() != (size_t)natoms) throw LammpsError("Restart file is inconsistent");
+  if ((!gmask.empty() && gmask.size() != (size_t)natoms) || (apa && num_angle.size() != (size_t)natoms)) throw LammpsError("Restart file is inconsistent");
   f.assign(3 * (size_t)natoms, 0.0);
   box_exist = true;
   host_current = true;

@@ -213,21 +213,20 @@ def test_random_md_settings(tmp_path, seed):
 
 @pytest.mark.parametrize("seed", _seeds("LE_FUZZ3_RESTART_SEEDS", 8))
 def test_random_restart_continuity(tmp_path, seed):
-    """A mixed LE scenario (test_gpu_fuzz2.py; not the angle and r-RESPA ones, which write_restart refuses / which is not a
-    fix) cut at a random step by write_restart + read_restart into a NEW instance: bit-identical to the uninterrupted run of the
+    """A mixed LE scenario (test_gpu_fuzz2.py; not the r-RESPA ones: run_style is not part of the file) cut at a random step by write_restart + read_restart into a NEW instance: bit-identical to the uninterrupted run of the
     same two `run` commands - positions, velocities, images, types, bonds, special lists, fix counters - whatever the local
     order (`atom_modify sort N`: the sorted order and the next sort step are part of the state), and equal to the oracle."""
     from lammps_le_amd import lammps
     from test_gpu_fuzz2 import scenario
     s, script, ids, flavour = scenario(seed)
-    if flavour in ("angles", "respa"):
-        pytest.skip("no restart for this flavour")
+    if flavour == "respa":
+        pytest.skip("run_style is not part of a restart file")
     lines = [ln for ln in script.split("\n") if not ln.startswith("run ")]
     total = sum(int(ln.split()[1]) for ln in script.split("\n") if ln.startswith("run "))
     rng = np.random.RandomState(23000 + seed)
     a_steps = int(rng.randint(1, total))
     head = "\n".join(lines) + "\n"
-    later = "\n".join(ln for ln in lines if ln.startswith(("group ", "fix ", "thermo "))) + "\n"      # (a restart file carries no groups)
+    later = "\n".join(ln for ln in lines if ln.startswith(("fix ", "thermo "))) + "\n"      # (groups, angles and their coefficients travel in the file)
     full = head + "run %d\nrun %d\n" % (a_steps, total - a_steps)
     try:
         o = run_oracle(full, s)
@@ -241,7 +240,8 @@ def test_random_restart_continuity(tmp_path, seed):
     b.command("read_restart " + rfile)
     for ln in (later + "run %d\n" % (total - a_steps)).split("\n"):
         b.command(ln)
-    for name in ("x", "v", "image", "type", "num_bond", "bond_type", "bond_atom", "nspecial", "special"):
+    for name in ("x", "v", "image", "type", "num_bond", "bond_type", "bond_atom", "nspecial", "special") + \
+            (("num_angle", "angle_type", "angle_atom1", "angle_atom2", "angle_atom3") if flavour == "angles" else ()):
         assert np.array_equal(a.gather(name), b.gather(name)), (name, flavour)
     for fid in ids:
         assert a.extract_fix(fid, 0, 1, 0) == b.extract_fix(fid, 0, 1, 0) and a.extract_fix(fid, 0, 1, 1) == b.extract_fix(fid, 0, 1, 1), fid
