@@ -279,6 +279,14 @@ double lammps_le_stat(void *handle, const char *name) {
   if (k == "comm_bytes_allgather") return e->comm ? e->comm->bytes_allgather : 0.0;
   if (k == "comm_bytes_allreduce") return e->comm ? e->comm->bytes_allreduce : 0.0;
   if (k == "halo_window_mismatches") return e->dev ? (double)dd_halo_mismatches(*e->dev) : 0.0;   // LAMMPS_LE_FAST_HALO_VERIFY
+  if (k == "angle_records" || k == "angle_records_max") {     // listed-angle records of the owned beads (sum / longest), as of the last reneighbor
+    if (!e->dev || !e->dev->eff_n || e->dev->n <= 0) return 0.0;
+    std::vector<int> c((size_t)e->dev->n);
+    HIP_CHECK(hipMemcpy(c.data(), e->dev->eff_n, c.size() * sizeof(int), hipMemcpyDeviceToHost));
+    double sum = 0.0, mx = 0.0;
+    for (int v : c) { sum += v; mx = std::max(mx, (double)v); }
+    return k == "angle_records" ? sum : mx;
+  }
   if (k == "special_asym") return e->dev ? (double)e->dev->flags_h[FLAG_SPECIAL_ASYM] : 0.0;   // some 1-2 list lost an entry its partner still has (sticky)
   if (k == "halo_fused") return e->dev && e->dev->fast_halo && e->dev->halo_fused ? 1.0 : 0.0;   // counters + window copy in one launch
   if (k == "halo_window_exchanges") return e->dev ? (double)e->dev->halo_seq : 0.0;   // per-step halos that went through the peer windows
