@@ -69,6 +69,9 @@ int  lammps_has_style(void *handle, const char *category, const char *name);
  * "halo_window_exchanges", "halo_window_mismatches", "halo_fused", "rng_segments", "rng_segments_held",
  * "rng_late_generations".  An unknown name returns 0. */
 double lammps_le_stat(void *handle, const char *name);
+/* the thermo lines printed so far as numbers: rows of 7 doubles (step, temp, epair, emol, etotal, press, bonds); returns the
+ * number of rows, writes at most max_rows (the reference's counterpart is parsing its log file) */
+int    lammps_le_thermo_log(void *handle, double *out, int max_rows);
 
 /* ranks: one process per GPU.  Replaces the MPI_Comm argument of the reference's `lammps_open` entry point
  * (library.h:91; there is no MPI here, so that entry point itself is not exported): the launcher creates a 128-byte RCCL unique

@@ -203,6 +203,17 @@ class lammps(object):
     def stat(self, name):
         return self.lib.lammps_le_stat(self.lmp, name.encode())
 
+    def thermo_history(self):
+        """Every thermo line printed so far: array of rows (step, temp, epair, emol, etotal, press, bonds)."""
+        import numpy as np
+        self.lib.lammps_le_thermo_log.restype = C.c_int
+        self.lib.lammps_le_thermo_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        n = self.lib.lammps_le_thermo_log(self.lmp, None, 0)
+        out = np.zeros((n, 7))
+        if n:
+            self.lib.lammps_le_thermo_log(self.lmp, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
     # -- ranks: one process per GPU, z-slab spatial decomposition (engine extension, see DESIGN.md §6) --
     def comm_init(self, backend, rank, world, unique_id=b"", session="default"):
         """Join a group of `world` engine instances.  backend "rccl": unique_id = the 128-byte ncclUniqueId

@@ -256,6 +256,18 @@ int lammps_has_style(void *, const char *category, const char *name) {
   return 0;
 }
 
+// every thermo line the engine has printed since it was opened, as numbers: rows of 7 doubles (step, temp, epair, emol,
+// etotal, press, bonds).  Returns the number of rows there are; writes at most max_rows of them.
+int lammps_le_thermo_log(void *handle, double *out, int max_rows) {
+  Engine *e = (Engine *)handle;
+  const int n = (int)e->thermo_log.size();
+  for (int k = 0; k < n && k < max_rows; k++) {
+    const ThermoRow &r = e->thermo_log[(size_t)k];
+    double *o = out + 7 * (size_t)k;
+    o[0] = (double)r.step; o[1] = r.temp; o[2] = r.epair; o[3] = r.emol; o[4] = r.etotal; o[5] = r.press; o[6] = (double)r.nbonds;
+  }
+  return n;
+}
 double lammps_le_stat(void *handle, const char *name) {
   Engine *e = (Engine *)handle;
   std::string k = name;

@@ -136,6 +136,12 @@ def test_random_le_scenarios_mixed(tmp_path, seed):
     p = run_product(script, s, tmp_path)
     compare(p, o, ids)
     assert p.stat("neigh_builds") == o.neigh_builds(), flavour
+    hp, ho = p.thermo_history(), o.thermo_history()        # every thermo line: step, temp, epair, emol, etotal, press, bonds
+    assert len(hp) == len(ho)
+    for rp, ro in zip(hp, ho):
+        assert rp[0] == ro[0] and rp[6] == ro[15], (flavour, int(rp[0]))
+        for k in range(1, 6):
+            assert abs(rp[k] - ro[k]) <= 1e-6 * max(1.0, abs(ro[k])), (flavour, int(rp[0]), k)
     if flavour == "angles":
         na, at, a1, a2, a3 = o.angle_table()
         assert (p.gather("num_angle") == na).all()

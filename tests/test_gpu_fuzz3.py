@@ -209,6 +209,14 @@ def test_random_md_settings(tmp_path, seed):
         assert abs(p.get_thermo(key) - to[k]) <= 1e-8 * max(1.0, abs(to[k])), key
     assert p.stat("neigh_builds") == o.neigh_builds()
     assert p.stat("neigh_pairs") == 2 * o.neigh_pairs()
+    # every thermo line of every run, not only the last one (thermo steps take other kernels than ordinary steps)
+    hp, ho = p.thermo_history(), o.thermo_history()
+    assert len(hp) == len(ho) and len(hp) >= 2
+    scale = len(xo) if "thermo_modify norm no" in script else 1.0
+    for rp, ro in zip(hp, ho):
+        assert rp[0] == ro[0]
+        for k, f in ((1, 1.0), (2, scale), (3, scale), (4, scale), (5, 1.0)):
+            assert abs(rp[k] - f * ro[k]) <= 1e-8 * max(1.0, abs(f * ro[k])), (int(rp[0]), k)
 
 
 @pytest.mark.parametrize("seed", _seeds("LE_FUZZ3_RESTART_SEEDS", 8))
