@@ -300,3 +300,15 @@ def test_group_command_errors(tmp_path):
                      ("fix loop nosuch extrusion 7 1 1 1 1.0 2\n", "Could not find fix group ID")):
         with pytest.raises(LammpsError, match=msg):
             run_product(CHAIN_SCRIPT + bad + "run 1\n", s, tmp_path)
+
+
+def test_set_selects_by_group(tmp_path):
+    """`set group ID type N` acts on the members of a group defined by `group` (src/set.cpp:60-65)."""
+    n = 3000
+    s = lattice_chain(n, nchains=3, seed=5)
+    s["ntypes"], s["mass"] = 2, [1.0, 1.0]
+    p = run_product(CHAIN_SCRIPT + "group mid molecule 2\ngroup tail id 2500:3000:100\ngroup both union mid tail\nset group both type 2\nfix 1 all nve\nrun 1\n", s, tmp_path)
+    want = np.ones(n, dtype=np.int32)
+    want[1000:2000] = 2
+    want[np.arange(2499, 3000, 100)] = 2
+    assert (p.gather("type") == want).all()
