@@ -1151,7 +1151,8 @@ void Engine::velocity(std::vector<std::string> &arg) {
   if (arg.size() < 2) throw LammpsError("Illegal velocity command");
   if (!box_exist) throw LammpsError("Velocity command before simulation box is defined");
   if (natoms == 0) throw LammpsError("Velocity command with no atoms existing");
-  if (arg[0] != "all") throw LammpsError("MI355X engine: only group all is supported");
+  const int gbit = group_bit(arg[0]);
+  if (!gbit) throw LammpsError("Could not find velocity group ID");      // src/velocity.cpp:64-65
   const std::string style = arg[1];
   size_t nfix;
   if (style == "create") nfix = 4;
@@ -1183,31 +1184,40 @@ void Engine::velocity(std::vector<std::string> &arg) {
   std::vector<int> order(natoms);
   for (int i = 0; i < natoms; i++) order[crank[i]] = i;
   auto m_of = [&](int i) { return mass[type[i]]; };
+  // the command acts on the members of its group (`mask[i] & groupbit` throughout src/velocity.cpp); sums, the centre of mass
+  // and the temperature (a compute temp on the same group: dof = 3 * members - 3) run over them
+  auto in = [&](int i) { return gbit == 1 || (!gmask.empty() && (gmask[i] & gbit)); };
+  long members = 0;
+  for (int i = 0; i < natoms; i++) members += in(i) ? 1 : 0;
   auto temperature = [&]() {   // compute temp, group all: src/compute_temp.cpp:60-101, extra_dof = 3 (src/compute.cpp:91)
     double t = 0.0;
     for (int r = 0; r < natoms; r++) {
       int i = order[r];
+      if (!in(i)) continue;
       t += (v[3 * i] * v[3 * i] + v[3 * i + 1] * v[3 * i + 1] + v[3 * i + 2] * v[3 * i + 2]) * m_of(i);
     }
-    double dof = 3.0 * natoms - 3.0;
+    double dof = 3.0 * members - 3.0;
     double tfactor = dof > 0.0 ? mvv2e / (dof * boltz) : 0.0;
     return t * tfactor;
   };
-  auto masstotal = [&]() { double m = 0.0; for (int r = 0; r < natoms; r++) m += m_of(order[r]); return m; };
+  auto masstotal = [&]() { double m = 0.0; for (int r = 0; r < natoms; r++) if (in(order[r])) m += m_of(order[r]); return m; };
   auto zero_momentum = [&]() {   // src/velocity.cpp:756-780, src/group.cpp:1125-1163
+    if (members == 0) throw LammpsError("Cannot zero momentum of no atoms");
     double mt = masstotal(), p[3] = {0, 0, 0};
-    for (int r = 0; r < natoms; r++) { int i = order[r]; double mo = m_of(i); for (int k = 0; k < 3; k++) p[k] += v[3 * i + k] * mo; }
+    for (int r = 0; r < natoms; r++) { int i = order[r]; if (!in(i)) continue; double mo = m_of(i); for (int k = 0; k < 3; k++) p[k] += v[3 * i + k] * mo; }
     if (mt > 0.0) for (int k = 0; k < 3; k++) p[k] /= mt;
-    for (int i = 0; i < natoms; i++) for (int k = 0; k < 3; k++) v[3 * i + k] -= p[k];
+    for (int i = 0; i < natoms; i++) if (in(i)) for (int k = 0; k < 3; k++) v[3 * i + k] -= p[k];
   };
   auto zero_rotation = [&]() {   // src/velocity.cpp:786-830, src/group.cpp:1018-1062, :1426-1459, :1583-1625, :1682-1728
+    if (members == 0) throw LammpsError("Cannot zero momentum of no atoms");
     double mt = masstotal(), xcm[3] = {0, 0, 0}, L[3] = {0, 0, 0}, I[3][3] = {{0}};
     auto unwrap = [&](int i, double *u) { for (int k = 0; k < 3; k++) u[k] = x[3 * i + k] + image[3 * i + k] * box.prd[k]; };
     double u[3];
-    for (int r = 0; r < natoms; r++) { int i = order[r]; unwrap(i, u); for (int k = 0; k < 3; k++) xcm[k] += u[k] * m_of(i); }
+    for (int r = 0; r < natoms; r++) { int i = order[r]; if (!in(i)) continue; unwrap(i, u); for (int k = 0; k < 3; k++) xcm[k] += u[k] * m_of(i); }
     if (mt > 0.0) for (int k = 0; k < 3; k++) xcm[k] /= mt;
     for (int r = 0; r < natoms; r++) {
       int i = order[r];
+      if (!in(i)) continue;
       unwrap(i, u);
       double dx = u[0] - xcm[0], dy = u[1] - xcm[1], dz = u[2] - xcm[2], mo = m_of(i);
       L[0] += mo * (dy * v[3 * i + 2] - dz * v[3 * i + 1]);
@@ -1234,6 +1244,7 @@ void Engine::velocity(std::vector<std::string> &arg) {
     for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) inv[a][b] /= det; }
     for (int a = 0; a < 3; a++) w[a] = inv[a][0] * L[0] + inv[a][1] * L[1] + inv[a][2] * L[2];
     for (int i = 0; i < natoms; i++) {
+      if (!in(i)) continue;
       unwrap(i, u);
       double dx = u[0] - xcm[0], dy = u[1] - xcm[1], dz = u[2] - xcm[2];
       v[3 * i] -= w[1] * dz - w[2] * dy;
@@ -1244,7 +1255,7 @@ void Engine::velocity(std::vector<std::string> &arg) {
   auto rescale = [&](double t_old, double t_new) {
     if (t_old == 0.0) throw LammpsError("Attempting to rescale a 0.0 temperature");
     double factor = sqrt(t_new / t_old);
-    for (auto &c : v) c *= factor;
+    for (int i = 0; i < natoms; i++) if (in(i)) for (int k = 0; k < 3; k++) v[3 * i + k] *= factor;
   };
   auto num = [&](const std::string &s) {
     char *end = nullptr;
@@ -1267,7 +1278,8 @@ void Engine::velocity(std::vector<std::string> &arg) {
     if (loop == 0) {          // loop all: one stream walked in ID order
       RanPark rn(seed);
       for (int i = 0; i < natoms; i++) {
-        draw3(rn, o);
+        draw3(rn, o);                       // (a triple for every ID, assigned to the members: src/velocity.cpp:279-300)
+        if (!in(i)) continue;
         double factor = 1.0 / sqrt(m_of(i));
         for (int k = 0; k < 3; k++) v[3 * i + k] = o[k] * factor;
       }
@@ -1276,6 +1288,7 @@ void Engine::velocity(std::vector<std::string> &arg) {
       for (int k = 0; k < 100; k++) rn.uniform();
       for (int r = 0; r < natoms; r++) {
         int i = order[r];
+        if (!in(i)) continue;               // (only members draw: :315-331)
         draw3(rn, o);
         double factor = 1.0 / sqrt(m_of(i));
         for (int k = 0; k < 3; k++) v[3 * i + k] = o[k] * factor;
@@ -1283,6 +1296,7 @@ void Engine::velocity(std::vector<std::string> &arg) {
     } else {                  // loop geom: stream re-seeded from each bead's coordinates
       RanPark rn(1);
       for (int i = 0; i < natoms; i++) {
+        if (!in(i)) continue;
         rn.reset(seed, &x[3 * i]);
         draw3(rn, o);
         double factor = 1.0 / sqrt(m_of(i));
@@ -1292,14 +1306,14 @@ void Engine::velocity(std::vector<std::string> &arg) {
     if (mom) zero_momentum();
     if (rot) zero_rotation();
     rescale(temperature(), t_desired);
-    if (sum) for (size_t k = 0; k < v.size(); k++) v[k] += vhold[k];
+    if (sum) for (int i = 0; i < natoms; i++) if (in(i)) for (int k = 0; k < 3; k++) v[3 * i + k] += vhold[3 * i + k];
   } else if (style == "set") {
     for (int k = 0; k < 3; k++) {
       const std::string &s = arg[2 + k];
       if (s.rfind("v_", 0) == 0) throw LammpsError("MI355X engine: velocity set with variables is not supported");
       if (s == "NULL") continue;
       double val = num(s);
-      for (int i = 0; i < natoms; i++) { if (sum) v[3 * i + k] += val; else v[3 * i + k] = val; }
+      for (int i = 0; i < natoms; i++) { if (!in(i)) continue; if (sum) v[3 * i + k] += val; else v[3 * i + k] = val; }
     }
   } else if (style == "scale") {
     double t_desired = num(arg[2]);

@@ -65,14 +65,17 @@ class RanPark:
 
 
 def temperature(v, m, order, boltz=1.0, mvv2e=1.0):
+    """(`order` = the members of the command's group in local order: compute temp on that group, dof = 3 * members - 3)"""
     t = 0.0
     for i in order:
         t += (v[i, 0] * v[i, 0] + v[i, 1] * v[i, 1] + v[i, 2] * v[i, 2]) * m[i]
-    dof = 3.0 * len(m) - 3.0
-    return t * (mvv2e / (dof * boltz))
+    dof = 3.0 * len(order) - 3.0
+    return t * (mvv2e / (dof * boltz)) if dof > 0.0 else 0.0          # (src/compute_temp.cpp dof_compute: tfactor = 0)
 
 
 def zero_momentum(v, m, order):
+    if len(order) == 0:
+        raise RuntimeError("Cannot zero momentum of no atoms")       # src/velocity.cpp:759-760
     mt = 0.0
     for i in order:
         mt += m[i]
@@ -81,10 +84,12 @@ def zero_momentum(v, m, order):
         for k in range(3):
             p[k] += v[i, k] * m[i]
     for k in range(3):
-        v[:, k] -= p[k] / mt
+        v[order, k] -= p[k] / mt
 
 
 def zero_rotation(v, m, xu, order):
+    if len(order) == 0:
+        raise RuntimeError("Cannot zero momentum of no atoms")       # src/velocity.cpp:792-793
     mt = 0.0
     for i in order:
         mt += m[i]
@@ -108,19 +113,23 @@ def zero_rotation(v, m, xu, order):
     I[1, 0], I[2, 1], I[2, 0] = I[0, 1], I[1, 2], I[0, 2]
     w = np.linalg.solve(I, L)        # the reference inverts by cofactors; same w up to rounding
     d = xu - xcm
-    v[:, 0] -= w[1] * d[:, 2] - w[2] * d[:, 1]
-    v[:, 1] -= w[2] * d[:, 0] - w[0] * d[:, 2]
-    v[:, 2] -= w[0] * d[:, 1] - w[1] * d[:, 0]
+    o = np.asarray(order)
+    v[o, 0] -= w[1] * d[o, 2] - w[2] * d[o, 1]
+    v[o, 1] -= w[2] * d[o, 0] - w[0] * d[o, 2]
+    v[o, 2] -= w[0] * d[o, 1] - w[1] * d[o, 0]
 
 
 def velocity_create(x, image, prd, mass_of_atom, t_desired, seed, dist="uniform", mom=True, rot=False, loop="all",
-                    vold=None, order=None):
+                    vold=None, order=None, member=None, vcur=None):
     """x [n,3] wrapped, image [n,3], mass_of_atom [n] — all in ID order; `order` = local order (ID-1 per local index).
-    Returns v [n,3] in ID order.  `vold` given = `sum yes`."""
+    Returns v [n,3] in ID order.  `vold` given = `sum yes`.  `member` [n] bool: the command's group (`mask[i] & groupbit`,
+    src/velocity.cpp:279-355) - the others keep `vcur`; loop all draws a triple for EVERY ID, loop local / geom only for members."""
     n = len(x)
     order = list(range(n)) if order is None else list(order)
     m = np.asarray(mass_of_atom, dtype=np.float64)
-    v = np.zeros((n, 3))
+    member = np.ones(n, dtype=bool) if member is None else np.asarray(member, dtype=bool)
+    v = np.zeros((n, 3)) if vcur is None else np.array(vcur, dtype=np.float64)
+    order = [i for i in order if member[i]]
 
     def draw3(rn):
         if dist == "uniform":
@@ -130,7 +139,9 @@ def velocity_create(x, image, prd, mass_of_atom, t_desired, seed, dist="uniform"
     if loop == "all":
         rn = RanPark(seed)
         for i in range(n):
-            v[i] = np.array(draw3(rn)) * (1.0 / math.sqrt(m[i]))
+            d3 = draw3(rn)
+            if member[i]:
+                v[i] = np.array(d3) * (1.0 / math.sqrt(m[i]))
     elif loop == "local":
         rn = RanPark(seed)
         for _ in range(100):
@@ -140,13 +151,18 @@ def velocity_create(x, image, prd, mass_of_atom, t_desired, seed, dist="uniform"
     else:
         rn = RanPark(1)
         for i in range(n):
+            if not member[i]:
+                continue
             rn.reset(seed, x[i])
             v[i] = np.array(draw3(rn)) * (1.0 / math.sqrt(m[i]))
     if mom:
         zero_momentum(v, m, order)
     if rot:
         zero_rotation(v, m, np.asarray(x) + np.asarray(image) * np.asarray(prd), order)
-    v *= math.sqrt(t_desired / temperature(v, m, order))
+    t_old = temperature(v, m, order)
+    if t_old == 0.0:
+        raise RuntimeError("Attempting to rescale a 0.0 temperature")   # src/velocity.cpp:735 (an empty or one-atom group)
+    v[order] *= math.sqrt(t_desired / t_old)
     if vold is not None:
-        v += vold
+        v[order] += np.asarray(vold)[order]
     return v

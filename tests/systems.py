@@ -344,7 +344,8 @@ class OracleScript:
         import sys
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
         from velocity_oracle import velocity_create
-        assert a[0] == "all" and a[1] == "create", "oracle script: velocity create only"
+        assert a[1] == "create", "oracle script: velocity create only"
+        member = None if a[0] == "all" else self.groups[a[0]]
         kw = dict(zip(a[4::2], a[5::2]))
         o = self.o
         box = np.asarray(self.sys["box"])
@@ -352,7 +353,8 @@ class OracleScript:
         v = velocity_create(o.x(), o.image(), box[:, 1] - box[:, 0], m, float(a[2]), int(a[3]),
                             dist=kw.get("dist", "uniform"), mom=kw.get("mom", "yes") == "yes",
                             rot=kw.get("rot", "no") == "yes", loop=kw.get("loop", "all"),
-                            vold=o.v() if kw.get("sum", "no") == "yes" else None, order=o.local_order() - 1)
+                            vold=o.v() if kw.get("sum", "no") == "yes" else None, order=o.local_order() - 1,
+                            member=member, vcur=o.v())
         o.set_v(v)
 
     def run(self, script):

@@ -113,8 +113,9 @@ def scenario(seed):
             if what == "reset":          # shifts the phase of every firing period (and of the next Atom::sort)
                 body += "reset_timestep %d\n" % int(rng2.choice([0, 7, 100, 1000]))
             elif what == "velocity":
-                body += "velocity all create %g %d %s\n" % (rng2.uniform(0.5, 1.5), int(rng2.randint(1, 900000)),
-                                                             str(rng2.choice(["dist gaussian", "loop local", ""])))
+                who = "g" if group_line and rng5.rand() < 0.6 else "all"     # (`velocity <group>`: members only)
+                body += "velocity %s create %g %d %s\n" % (who, rng2.uniform(0.5, 1.5), int(rng2.randint(1, 900000)),
+                                                            str(rng2.choice(["dist gaussian", "loop local", ""])))
             elif what == "timestep":
                 body += "timestep %g\n" % float(rng2.choice([0.003, 0.004, 0.006]))
             else:

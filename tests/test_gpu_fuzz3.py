@@ -182,6 +182,12 @@ def md_scenario(seed):
     for c in cuts + [total]:
         if c > last:
             lines.append("run %d" % (c - last))
+            if c < total and rng4.rand() < 0.4:       # new velocities between two runs, for everyone or for the members of a group
+                lines.append("velocity %s create %g %d %s" % (gn if rng4.rand() < 0.6 else "all", rng4.uniform(0.5, 1.5),
+                                                              int(rng4.randint(1, 900000)),
+                                                              str(rng4.choice(["", "dist gaussian", "loop local", "mom no", "rot yes", "sum yes"]))))
+                # (not `loop geom` here: it seeds each atom from its coordinates' decimal digits, so after a run the 1e-12
+                #  differences between two correct integrations give unrelated velocities; tests/test_host_cpu.py covers it)
         last = c
     return s, "\n".join(lines) + "\n"
 

@@ -248,6 +248,55 @@ def test_velocity_set_scale_zero_sum(tmp_path):
         lmp.command("velocity all scale 1.0")
 
 
+@pytest.mark.parametrize("opts", ["", "dist gaussian loop local", "loop geom rot yes", "sum yes"])
+def test_velocity_on_a_group(tmp_path, opts):
+    """`velocity <group> ...` (src/velocity.cpp: `mask[i] & groupbit` in every loop): loop all draws a triple for every ID and
+    assigns the members', loop local / geom draw for members only; the temperature, the momentum and the angular momentum are the
+    group's; everyone else keeps the velocity it had."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from velocity_oracle import velocity_create
+    from lammps_le_amd import LammpsError
+    n = 600
+    lmp, s, m = _velocity_case(tmp_path, n, "group heavy type 2", v0=True)
+    lmp.command("group odd id 1:%d:2" % n)
+    lmp.command("group sel union heavy odd")
+    member = (np.arange(n) % 3 == 0) | (np.arange(n) % 2 == 0)
+    v0 = lmp.gather("v").reshape(n, 3).copy()
+    x = lmp.gather("x").reshape(n, 3)
+    lmp.command("velocity sel create 0.9 31337 " + opts)
+    v = lmp.gather("v").reshape(n, 3)
+    kw = dict(dist="gaussian" if "gaussian" in opts else "uniform", rot="rot yes" in opts,
+              loop="local" if "local" in opts else "geom" if "geom" in opts else "all")
+    prd = s["box"][:, 1] - s["box"][:, 0]
+    ref = velocity_create(x, s["image"], prd, m, 0.9, 31337, member=member, vcur=v0,
+                          vold=v0 if "sum yes" in opts else None, **kw)
+    assert np.abs(v - ref).max() < 1e-13
+    assert np.array_equal(v[~member], v0[~member])
+    w = v[member] - (v0[member] if "sum yes" in opts else 0.0)
+    mm = m[member]
+    assert abs((mm[:, None] * w * w).sum() / (3 * member.sum() - 3) - 0.9) < 1e-12
+    assert np.abs((mm[:, None] * w).sum(axis=0)).max() < 1e-10
+    # set / scale / zero act on the members only
+    lmp.command("velocity heavy set NULL 0.25 NULL")
+    v2 = lmp.gather("v").reshape(n, 3)
+    heavy = np.arange(n) % 3 == 0
+    assert (v2[heavy, 1] == 0.25).all() and np.array_equal(v2[~heavy], v[~heavy]) and np.array_equal(v2[:, 0], v[:, 0])
+    lmp.command("velocity odd scale 0.4")
+    v3 = lmp.gather("v").reshape(n, 3)
+    odd = np.arange(n) % 2 == 0
+    assert abs((m[odd][:, None] * v3[odd] ** 2).sum() / (3 * odd.sum() - 3) - 0.4) < 1e-12
+    assert np.array_equal(v3[~odd], v2[~odd])
+    lmp.command("velocity heavy zero linear")
+    v4 = lmp.gather("v").reshape(n, 3)
+    assert np.abs((m[heavy][:, None] * v4[heavy]).sum(axis=0)).max() < 1e-10 and np.array_equal(v4[~heavy], v3[~heavy])
+    with pytest.raises(LammpsError, match="Could not find velocity group ID"):     # src/velocity.cpp:65
+        lmp.command("velocity nobody create 1.0 5")
+    lmp.command("group none empty")
+    with pytest.raises(LammpsError, match="Cannot zero momentum of no atoms"):     # src/velocity.cpp:760
+        lmp.command("velocity none zero linear")
+
+
 # ------------------------------------------------------------------------------------------------------------
 # script control flow: variable index / loop / equal, next, label, jump, if, include, $(...) (src/input.cpp, variable.cpp)
 def test_script_control_flow(tmp_path):
