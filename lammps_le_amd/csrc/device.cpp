@@ -90,6 +90,7 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   d.nred_blocks = (n + 255) / 256 + 8;
   dalloc(d.partial, (size_t)d.nred_blocks * 16);
   dalloc(d.partial_a, (size_t)d.nred_blocks * 8);
+  dalloc(d.lgsum, ((size_t)d.nred_blocks + 1) * 16);
   HIP_CHECK(hipHostMalloc((void **)&d.partial_h, (size_t)d.nred_blocks * 16 * sizeof(double)));
   dalloc(d.flags, NFLAGS);
   HIP_CHECK(hipHostMalloc((void **)&d.flags_h, (FLAG_SEQ_SLOT + 16) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
@@ -128,7 +129,7 @@ void dev_free(DeviceState &d) {
   if (d.angtab_dev) { (void)hipFree(d.angtab_dev); d.angtab_dev = nullptr; }
   dfree(d.gmask); dfree(d.lgrank);
   dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
-  dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial); dfree(d.partial_a);
+  dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial); dfree(d.partial_a); dfree(d.lgsum);
   dfree(d.num_angle); dfree(d.angle_type); dfree(d.angle_a1); dfree(d.angle_a2); dfree(d.angle_a3); dfree(d.eff_n); dfree(d.eff_rec);
   if (d.partial_h) (void)hipHostFree(d.partial_h);
   d.partial_h = nullptr;

@@ -82,6 +82,7 @@ struct DeviceState {
   int apa = 0;
   int *num_angle = nullptr, *angle_type = nullptr, *angle_a1 = nullptr, *angle_a2 = nullptr, *angle_a3 = nullptr;
   double *partial_a = nullptr;     // [nblocks][8] angle energy + virial block sums
+  double *lgsum = nullptr;         // fix langevin `zero yes`: [nred_blocks + 1][16] block sums of the random forces + their mean
   // the angle LIST of the last reneighbor as every bead sees it (NTopoAngleAll::build, src/ntopo_angle_all.cpp:37-93): an
   // angle acts - on all three of its atoms - iff the one with the lowest local index holds a copy of it, whatever copies
   // the other two hold (copies go out of step when fix ex_unload's influence rule spares one atom).  eff_*[t]: the listed
@@ -249,6 +250,8 @@ void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4]
                  bool eflag = false);
 bool step_fuses_energy(const DeviceState &d, bool has_pair);   // a thermo step can be one launch of the step kernel's energy variant
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final, int groupbit = 1);
+// `zero yes`: after launch_langevin and before the draws are released - the members' mean random force off every member
+void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool identity_rank, int groupbit, long members);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt, int groupbit = 1);
 void launch_ke(DeviceState &d, const TypeTables &tt);
 // angle forces added to f (after launch_force); eflag: energy / virial thirds into partial_a (reduce_angle_partials)

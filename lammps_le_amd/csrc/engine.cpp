@@ -596,8 +596,8 @@ static TypeTables make_tables(Engine *e, FixLangevin *lg) {
       // src/fix_langevin.cpp:296-310 (init) and :784-797 (compute_target), :662-663
       double g1 = -e->mass[t] / lg->t_period / e->ftm2v;
       double g2 = std::sqrt(e->mass[t]) * std::sqrt(24.0 * e->boltz / lg->t_period / e->dt / e->mvv2e) / e->ftm2v;
-      g1 *= 1.0 / 1.0;
-      g2 *= 1.0 / std::sqrt(1.0);
+      g1 *= 1.0 / lg->ratio[t];
+      g2 *= 1.0 / std::sqrt(lg->ratio[t]);
       double delta = (double)(e->ntimestep - e->beginstep);
       if (delta != 0.0) delta /= (double)(e->endstep - e->beginstep);
       double t_target = lg->t_start + delta * (lg->t_stop - lg->t_start);
@@ -696,8 +696,13 @@ static void langevin_draws(Engine *e, FixLangevin *lg) {
 static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
   langevin_draws(e, lg);
   TypeTables tt = make_tables(e, lg);
-  if (e->langevin_members == 0) return;
-  launch_langevin(*e->dev, tt, e->dev->ident_order, fuse_final, lg->groupbit);
+  if (e->langevin_members == 0) {
+    if (lg->zeroflag) throw LammpsError("Cannot zero Langevin force of 0 atoms");      // src/fix_langevin.cpp:633-634
+    return;
+  }
+  launch_langevin(*e->dev, tt, e->dev->ident_order, fuse_final && !lg->zeroflag, lg->groupbit);
+  // `zero yes`: the members' mean random force comes off every member (:752-772); block sums in block order, one total
+  if (lg->zeroflag) launch_langevin_zero(*e->dev, tt, e->dev->ident_order, lg->groupbit, e->langevin_members);
   rng_langevin_consumed(*e->dev);
 }
 
@@ -819,6 +824,7 @@ void Engine::iterate(long nsteps) {
   // fix nve / fix langevin on a group other than all: the unfused kernels, which test the bead's group bits
   const std::vector<int> nbits = nve_bits(this);
   if (md_fixes_on_groups(this)) fusable = false;
+  if (lg && lg->zeroflag) fusable = false;         // (`zero yes` needs the group's summed random force before final_integrate)
   // bond morse (the reference's unit-test partner of bond hybrid, not a style of the chromatin model) lives in the
   // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
   for (int b = 1; b <= nbondtypes; b++) if (bondtab.style[b] == 3) fusable = false;
@@ -931,7 +937,7 @@ void Engine::iterate(long nsteps) {
       compute_forces(eflag);
       stamp(T_PAIR);          // k_force: pair + bond in one pass
       // (Langevin and the final half-kick in one kernel only when both fixes act on the same atoms)
-      const bool lg_fused_final = lg && nnve == 1 && nbits[0] == lg->groupbit && langevin_members > 0;
+      const bool lg_fused_final = lg && nnve == 1 && nbits[0] == lg->groupbit && langevin_members > 0 && !lg->zeroflag;
       if (lg) langevin_post_force(this, lg, lg_fused_final);
       if (!lg_fused_final)
         for (int k = 0; k < nnve; k++) launch_final_integrate(d, tt, nbits[k]);
@@ -1108,6 +1114,9 @@ void Engine::run(long nsteps) {
   }
   if (angles_active() && respa_levels > 0)
     throw LammpsError("MI355X engine: angle styles run with run_style verlet only");
+  for (auto &f : fixes)
+    if (auto *l = dynamic_cast<FixLangevin *>(f.get()))
+      if (l->zeroflag && world > 1) throw LammpsError("MI355X engine: fix langevin zero yes runs on one GPU");
   for (int a = 1; a <= nangletypes && apa > 0 && nangles > 0 && !angle_style_name.empty() && angle_style_name != "none" && angle_style_name != "zero"; a++)
     if (!angtab.style[a]) throw LammpsError("All angle coeffs are not set");
   // a run that ended in an error tore the communicator down (below); halo sequence numbers and arrival counters of the

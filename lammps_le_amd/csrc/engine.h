@@ -119,6 +119,8 @@ struct FixLangevin : Fix {
   RanMarsInt rng;          // host mirror of the stream position (kept in sync by draw counting)
   uint64_t draws = 0;      // Langevin draws consumed so far (3 per atom per post_force call)
   bool dev_ready = false;  // device block states initialised
+  std::vector<double> ratio;   // keyword `scale itype ratio`: per-type divisor of the damping time (src/fix_langevin.cpp:135-141)
+  bool zeroflag = false;       // keyword `zero yes`: the mean random force of the group is taken off every member (:752-772)
   FixLangevin(Engine *e, const std::vector<std::string> &arg);
 };
 
@@ -318,6 +320,8 @@ class Engine {
   struct Dump {
     std::string id, style, path, label = "ENTRIES";
     long every = 0, last = -1;
+    int groupbit = 1;              // rows = the members of the dump's group (`mask[i] & groupbit`: src/dump_custom.cpp:607-612,
+                                   // dump_atom.cpp:356, dump_dcd.cpp:69,200); dump local takes its rows from the compute's group
     bool unwrap = false;           // dcd: coordinates unwrapped by the image flags (dump_modify unwrap yes)
     int nframes = 0;               // dcd: snapshots written so far (header fields are patched after each one)
     std::vector<std::string> cols;
@@ -325,6 +329,7 @@ class Engine {
   };
   std::vector<Dump> dumps;
   std::map<std::string, std::vector<std::string>> computes_local;   // compute ID -> property/local attributes
+  std::map<std::string, int> computes_local_bit;                    // compute ID -> group bit (both atoms of a bond must be members)
   // ---- restart: own binary format, bit-continuous incl. the RNG streams of the fixes ----
   void write_restart(const std::string &path);
   void read_restart(const std::string &path);

@@ -45,7 +45,28 @@ FixLangevin::FixLangevin(Engine *e, const std::vector<std::string> &arg) {
   seed = inumeric(arg[6]);
   if (t_period <= 0.0) throw LammpsError("Fix langevin period must be > 0.0");
   if (seed <= 0) throw LammpsError("Illegal fix langevin command");
-  if (arg.size() > 7) throw LammpsError("MI355X engine: fix langevin optional keywords are not supported: " + arg[7]);
+  // optional keywords (src/fix_langevin.cpp:105-155): `scale` and `zero` are implemented, the others only at their defaults
+  ratio.assign(e->ntypes + 1, 1.0);
+  for (size_t k = 7; k < arg.size();) {
+    const std::string &kw = arg[k];
+    if (kw == "scale") {
+      if (k + 3 > arg.size()) throw LammpsError("Illegal fix langevin command");
+      int itype = inumeric(arg[k + 1]);
+      double sc = numeric(arg[k + 2]);
+      if (itype <= 0 || itype > e->ntypes) throw LammpsError("Illegal fix langevin command");
+      ratio[itype] = sc;
+      k += 3;
+    } else if (kw == "zero" || kw == "tally" || kw == "omega" || kw == "angmom" || kw == "gjf") {
+      if (k + 2 > arg.size()) throw LammpsError("Illegal fix langevin command");
+      const std::string &val = arg[k + 1];
+      if (kw == "zero") {
+        if (val != "yes" && val != "no") throw LammpsError("Illegal fix langevin command");
+        zeroflag = val == "yes";
+      } else if (val != "no")
+        throw LammpsError("MI355X engine: fix langevin " + kw + " " + val + " is not supported");
+      k += 2;
+    } else throw LammpsError("Illegal fix langevin command");
+  }
   rng.seed(seed);   // seed + comm->me, me = 0
   has_post_force = true;
 }

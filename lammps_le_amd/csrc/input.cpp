@@ -600,22 +600,27 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
   } else if (cmd == "compute") {
     // compute ID group property/local attr...   (src/compute_property_local.cpp:30-180; bond attributes only)
     need(4);
-    if (arg[1] != "all") throw LammpsError("MI355X engine: only group all is supported");
+    const int cbit = group_bit(arg[1]);
+    if (!cbit) throw LammpsError("Could not find compute group ID");         // src/compute.cpp:63-64
     if (arg[2] != "property/local") throw LammpsError("Unknown compute style " + arg[2]);
     std::vector<std::string> attrs(arg.begin() + 3, arg.end());
     for (auto &a : attrs)
       if (a != "btype" && a != "batom1" && a != "batom2")
         throw LammpsError("MI355X engine: compute property/local supports btype batom1 batom2 (got " + a + ")");
     computes_local[arg[0]] = attrs;
+    computes_local_bit[arg[0]] = cbit;
   } else if (cmd == "uncompute") {
     need(1);
     if (!computes_local.erase(arg[0])) throw LammpsError("Could not find uncompute ID");
+    computes_local_bit.erase(arg[0]);
   } else if (cmd == "dump") {
     // dump ID group style N file args   (src/dump.cpp:60-170, dump_custom.cpp:60-250, dump_local.cpp:40-130)
     need(5);
-    if (arg[1] != "all") throw LammpsError("MI355X engine: only group all is supported");
+    const int dbit = group_bit(arg[1]);
+    if (!dbit) throw LammpsError("Could not find dump group ID");            // src/dump.cpp:69-70
     for (auto &dp : dumps) if (dp.id == arg[0]) throw LammpsError("Reuse of dump ID");
     Dump dp;
+    dp.groupbit = dbit;
     dp.id = arg[0]; dp.style = arg[2]; dp.every = atol(arg[3].c_str()); dp.path = arg[4];
     if (dp.every <= 0) throw LammpsError("Invalid dump frequency");
     static const char *atom_cols[] = {"id", "mol", "type", "mass", "x", "y", "z", "xs", "ys", "zs", "xu", "yu", "zu", "ix", "iy",
@@ -1572,6 +1577,9 @@ void Engine::write_dumps(long step) {
       if (dp.fp == nullptr) fp = dp.fp = fopen(dp.path.c_str(), "wb+");
       if (!fp) throw LammpsError("Cannot open dump file " + dp.path);
       auto w32 = [&](uint32_t val) { fwrite(&val, 4, 1, fp); };
+      std::vector<int> rows;                                   // the group's atoms in ID order (src/dump_dcd.cpp:69,200)
+      for (int i = 0; i < natoms; i++) if (dp.groupbit == 1 || (!gmask.empty() && (gmask[i] & dp.groupbit))) rows.push_back(i);
+      const int nrows_dcd = (int)rows.size();
       if (dp.nframes == 0) {
         w32(84); fwrite("CORD", 4, 1, fp);
         w32(0); w32((uint32_t)step); w32((uint32_t)dp.every); w32((uint32_t)step);
@@ -1585,15 +1593,17 @@ void Engine::write_dumps(long step) {
         memset(title, 0, sizeof title); strncpy(title, "Written by LAMMPS", 80); title[79] = 0; fwrite(title, 80, 1, fp);
         memset(title, ' ', 80); memcpy(title, "REMARKS Created by the MI355X engine", 36); fwrite(title, 80, 1, fp);
         w32(164);
-        w32(4); w32((uint32_t)natoms); w32(4);
+        w32(4); w32((uint32_t)nrows_dcd); w32(4);
       }
       double dim[6] = {box.prd[0], 0.0, box.prd[1], 0.0, 0.0, box.prd[2]};
       w32(48); fwrite(dim, 8, 6, fp); w32(48);
-      std::vector<float> c(natoms);
+      std::vector<float> c(nrows_dcd);
       for (int d = 0; d < 3; d++) {
-        for (int i = 0; i < natoms; i++)
-          c[i] = (float)(dp.unwrap ? x[3 * (size_t)i + d] + image[3 * (size_t)i + d] * box.prd[d] : x[3 * (size_t)i + d]);
-        w32((uint32_t)(natoms * 4)); fwrite(c.data(), 4, natoms, fp); w32((uint32_t)(natoms * 4));
+        for (int r = 0; r < nrows_dcd; r++) {
+          const size_t i = (size_t)rows[r];
+          c[r] = (float)(dp.unwrap ? x[3 * i + d] + image[3 * i + d] * box.prd[d] : x[3 * i + d]);
+        }
+        w32((uint32_t)(nrows_dcd * 4)); fwrite(c.data(), 4, nrows_dcd, fp); w32((uint32_t)(nrows_dcd * 4));
       }
       dp.nframes++;
       fseek(fp, 8, SEEK_SET); w32((uint32_t)dp.nframes);      // NFILE
@@ -1602,15 +1612,20 @@ void Engine::write_dumps(long step) {
       fflush(fp);
       continue;
     }
-    long nrows = natoms;
+    auto member = [&](int i, int bit) { return bit == 1 || (!gmask.empty() && (gmask[i] & bit)); };
+    long nrows = 0;
+    for (int i = 0; i < natoms; i++) nrows += member(i, dp.groupbit) ? 1 : 0;
     std::vector<std::array<int, 3>> bonds;     // (type, atom1, atom2) as compute property/local lists them
     if (dp.style == "local") {
+      int cbit = 1;                            // rows come from the computes (all columns of one dump: equal counts, dump_local.cpp:284-325)
+      for (auto &a : dp.cols) if (a != "index") { cbit = computes_local_bit.at(a.substr(2, a.find('[') - 2)); break; }
       // newton_bond off storage: every bond sits with both atoms, listed once from the lower ID
       // (src/compute_property_local.cpp:420-470)
       for (int i = 0; i < natoms; i++)
         for (int m = 0; m < num_bond[i]; m++) {
           int bt = bond_type[(size_t)i * bpa + m], j = bond_atom[(size_t)i * bpa + m];
           if (bt == 0 || i + 1 > j) continue;
+          if (!member(i, cbit) || !member(j - 1, cbit)) continue;       // (both atoms in the compute's group: :477-480)
           bonds.push_back({bt, i + 1, j});
         }
       nrows = (long)bonds.size();
@@ -1640,7 +1655,8 @@ void Engine::write_dumps(long step) {
           fputc(k + 1 < nc ? ' ' : '\n', fp);
         }
     } else {
-      for (int i = 0; i < natoms; i++)
+      for (int i = 0; i < natoms; i++) {
+        if (!member(i, dp.groupbit)) continue;
         for (size_t k = 0; k < nc; k++) {
           const std::string &c = dp.cols[k];
           const double *xi = &x[3 * (size_t)i];
@@ -1657,6 +1673,7 @@ void Engine::write_dumps(long step) {
           else fprintf(fp, "%g", f[3 * (size_t)i + (c[1] - 'x')]);
           fputc(k + 1 < nc ? ' ' : '\n', fp);
         }
+      }
     }
     if (star != std::string::npos) fclose(fp); else fflush(fp);
   }

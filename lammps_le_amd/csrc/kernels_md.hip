@@ -732,6 +732,58 @@ void launch_final_integrate(DeviceState &d, const TypeTables &tt, int groupbit) 
   hipLaunchKernelGGL(k_final_integrate, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2],
                      d.f[0], d.f[1], d.f[2], tt, d.tag, groupbit != 1 ? d.gmask : (const int *)nullptr, groupbit);
 }
+// fix langevin `zero yes` (src/fix_langevin.cpp:725-729, 752-772): the members' random forces summed (block sums, then one
+// workgroup adds them in block order and divides by the member count), and the mean taken off every member's force
+template <bool IDENT>
+__global__ __launch_bounds__(BLOCK) void k_langevin_fsum(int n, const double4 *__restrict__ pos, const int *__restrict__ tag,
+                                                         const int *__restrict__ crank, const uint32_t *__restrict__ draws,
+                                                         TypeTables tt, const int *__restrict__ gmask, int groupbit,
+                                                         double *__restrict__ partial) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  double val[3] = {0.0, 0.0, 0.0};
+  if (p < n) {
+    int t = tag[p];
+    if (!gmask || (gmask[t] & groupbit)) {
+      int rank = IDENT ? (t - 1) : crank[t];
+      double gamma2 = tt.g2[(int)pos[p].w];
+      const double inv = 1.0 / 16777216.0;
+      for (int k = 0; k < 3; k++) val[k] = gamma2 * ((double)draws[3 * (size_t)rank + k] * inv - 0.5);
+    }
+  }
+  block_reduce_store<3>(val, partial, blockIdx.x, 0);
+}
+__global__ __launch_bounds__(BLOCK) void k_langevin_fsum_total(int nblocks, double inv_count, double *__restrict__ partial) {
+  // one workgroup: thread k < 3 walks column k in block order (the same sum on every run)
+  if (threadIdx.x < 3) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; b++) s += partial[(size_t)b * 16 + threadIdx.x];
+    partial[(size_t)nblocks * 16 + threadIdx.x] = s * inv_count;
+  }
+}
+__global__ __launch_bounds__(BLOCK) void k_langevin_zero(int n, const int *__restrict__ tag, const int *__restrict__ gmask,
+                                                         int groupbit, const double *__restrict__ mean,
+                                                         double *__restrict__ fx, double *__restrict__ fy,
+                                                         double *__restrict__ fz) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= n) return;
+  if (gmask && !(gmask[tag[p]] & groupbit)) return;
+  fx[p] -= mean[0]; fy[p] -= mean[1]; fz[p] -= mean[2];
+}
+void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool ident, int groupbit, long members) {
+  int nb = (d.n + BLOCK - 1) / BLOCK;
+  const int *gm = groupbit != 1 ? d.gmask : (const int *)nullptr;
+  const int *rk = groupbit != 1 ? d.lgrank : d.crank;
+  if (groupbit != 1) ident = false;
+  if (ident)
+    hipLaunchKernelGGL((k_langevin_fsum<true>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.tag, rk, d.rng_out, tt, gm,
+                       groupbit, d.lgsum);
+  else
+    hipLaunchKernelGGL((k_langevin_fsum<false>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.tag, rk, d.rng_out, tt, gm,
+                       groupbit, d.lgsum);
+  hipLaunchKernelGGL(k_langevin_fsum_total, dim3(1), dim3(BLOCK), 0, d.stream, nb, 1.0 / (double)members, d.lgsum);
+  hipLaunchKernelGGL(k_langevin_zero, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.tag, gm, groupbit,
+                     d.lgsum + (size_t)nb * 16, d.f[0], d.f[1], d.f[2]);
+}
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool ident, bool fuse_final, int groupbit) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
   const int *gm = groupbit != 1 ? d.gmask : (const int *)nullptr;

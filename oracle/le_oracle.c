@@ -22,6 +22,7 @@ typedef struct {
   /* langevin */
   double t_start, t_stop, t_period; int seed;
   double *gfactor1, *gfactor2; double tsqrt;
+  double *ratio; int zeroflag;   /* keywords `scale itype ratio`, `zero yes` (src/fix_langevin.cpp:135-141, 148-153) */
   leo_ranmars rng;
   /* LE common */
   int nevery, btype;
@@ -456,6 +457,15 @@ void leo_fix_langevin(leo_t *s, double t_start, double t_stop, double damp, int 
   f->next_reneighbor = -1;
   leo_ranmars_init(&f->rng, seed);                          /* src/fix_langevin.cpp:86 (me = 0) */
   f->gfactor1 = calloc(s->ntypes + 1, sizeof(double)); f->gfactor2 = calloc(s->ntypes + 1, sizeof(double));
+  f->ratio = calloc(s->ntypes + 1, sizeof(double));
+  for (int t = 0; t <= s->ntypes; t++) f->ratio[t] = 1.0;   /* :96 */
+}
+/* optional keywords of the most recently defined fix langevin: `scale itype ratio` (:135-141), `zero yes|no` (:148-153) */
+void leo_langevin_scale(leo_t *s, int itype, double ratio) {
+  for (int k = s->nfix - 1; k >= 0; k--) if (s->fix[k].kind == FIX_LANGEVIN) { s->fix[k].ratio[itype] = ratio; return; }
+}
+void leo_langevin_zero(leo_t *s, int flag) {
+  for (int k = s->nfix - 1; k >= 0; k--) if (s->fix[k].kind == FIX_LANGEVIN) { s->fix[k].zeroflag = flag; return; }
 }
 void leo_fix_extrusion(leo_t *s, int nevery, int neutral, int l, int r, double tp, int btype, int lr) {
   leo_fix *f = &s->fix[s->nfix++]; memset(f, 0, sizeof *f);
@@ -1052,12 +1062,19 @@ static void langevin_init(leo_t *s, leo_fix *fx) {
   for (int t = 1; t <= s->ntypes; t++) {
     fx->gfactor1[t] = -s->mass[t] / fx->t_period / s->ftm2v;
     fx->gfactor2[t] = sqrt(s->mass[t]) * sqrt(24.0 * s->boltz / fx->t_period / s->dt / s->mvv2e) / s->ftm2v;
-    fx->gfactor1[t] *= 1.0 / 1.0;
-    fx->gfactor2[t] *= 1.0 / sqrt(1.0);
+    fx->gfactor1[t] *= 1.0 / fx->ratio[t];
+    fx->gfactor2[t] *= 1.0 / sqrt(fx->ratio[t]);
   }
 }
-/* src/fix_langevin.cpp:585-778 post_force_templated<0,0,0,0,0,0>; compute_target :784-797 */
+/* src/fix_langevin.cpp:585-778 post_force_templated<0,0,0,0,0,Tp_ZERO>; compute_target :784-797 */
 static void langevin_post_force(leo_t *s, leo_fix *fx) {
+  double fsum[3] = {0.0, 0.0, 0.0};
+  long count = 0;                                              /* group->count(igroup), :630-635 */
+  if (fx->zeroflag) {
+    long members = 0;
+    for (int i = 0; i < s->n; i++) if (!fx->gmask || fx->gmask[s->tag[i]]) members++;
+    if (members == 0) { seterr(s, "Cannot zero Langevin force of 0 atoms"); return; }
+  }
   double delta = (double)(s->ntimestep - s->beginstep);
   if (delta != 0.0) delta /= (double)(s->endstep - s->beginstep);
   double t_target = fx->t_start + delta * (fx->t_stop - fx->t_start);
@@ -1071,6 +1088,15 @@ static void langevin_post_force(leo_t *s, leo_fix *fx) {
     fran[2] = gamma2 * (leo_ranmars_uniform(&fx->rng) - 0.5);
     fdrag[0] = gamma1 * s->v[3 * i]; fdrag[1] = gamma1 * s->v[3 * i + 1]; fdrag[2] = gamma1 * s->v[3 * i + 2];
     s->f[3 * i] += fdrag[0] + fran[0]; s->f[3 * i + 1] += fdrag[1] + fran[1]; s->f[3 * i + 2] += fdrag[2] + fran[2];
+    fsum[0] += fran[0]; fsum[1] += fran[1]; fsum[2] += fran[2];  /* Tp_ZERO, :725-729 */
+    count++;
+  }
+  if (fx->zeroflag) {                                          /* set total force to zero, :752-772 */
+    for (int k = 0; k < 3; k++) fsum[k] /= (double)count;
+    for (int i = 0; i < s->n; i++) {
+      if (fx->gmask && !fx->gmask[s->tag[i]]) continue;
+      s->f[3 * i] -= fsum[0]; s->f[3 * i + 1] -= fsum[1]; s->f[3 * i + 2] -= fsum[2];
+    }
   }
 }
 
@@ -1640,6 +1666,7 @@ static int verlet_setup(leo_t *s) {
   angle_compute(s, 1);
   /* modify->setup: FixLangevin::setup -> post_force (src/fix_langevin.cpp:372-373) */
   for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_post_force(s, &s->fix[k]);
+  if (s->errflag) return 1;
   for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_BOND_CREATE) bond_create_setup(s, &s->fix[k]);
   thermo_record(s);
   return 0;
@@ -1709,6 +1736,7 @@ static int respa_setup(leo_t *s) {                                 /* Respa::set
      outermost level's array */
   for (int k = 0; k < s->nfix; k++)
     if (s->fix[k].kind == FIX_LANGEVIN) { copy_flevel_f(s, top); langevin_post_force(s, &s->fix[k]); copy_f_flevel(s, top); }
+  if (s->errflag) return 1;
   for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_BOND_CREATE) bond_create_setup(s, &s->fix[k]);
   thermo_record(s);
   return 0;

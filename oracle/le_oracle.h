@@ -74,6 +74,9 @@ void   leo_fix_group(leo_t *s, int fix_index, const int *flag_by_tag);
 void   leo_nve_group(leo_t *s, const int *flag_by_tag);
 /* fix ID group langevin with a group other than all: only members draw (and feel drag / noise), in local order */
 void   leo_langevin_group(leo_t *s, const int *flag_by_tag);
+/* fix langevin keywords `scale itype ratio` and `zero yes|no`, for the most recently defined fix langevin */
+void   leo_langevin_scale(leo_t *s, int itype, double ratio);
+void   leo_langevin_zero(leo_t *s, int flag);
 /* fix ex_load ... atype N (fix_ex_load.cpp:855-954): angles of type N are created around every new bond */
 void   leo_ex_load_atype(leo_t *s, int fix_index, int atype);
 long   leo_nangles(leo_t *s);

@@ -113,6 +113,12 @@ class Oracle:
         f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
         self.L.leo_fix_group(self.h, C.c_int(self.fix_ids[fix_id]), _ip(f))
 
+    def langevin_scale(self, itype, ratio):
+        self.L.leo_langevin_scale(self.h, C.c_int(itype), C.c_double(ratio))
+
+    def langevin_zero(self, flag):
+        self.L.leo_langevin_zero(self.h, C.c_int(1 if flag else 0))
+
     def langevin_group(self, flag_by_tag):
         f = np.ascontiguousarray(flag_by_tag, dtype=np.int32)
         self.L.leo_langevin_group(self.h, _ip(f))

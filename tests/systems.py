@@ -285,6 +285,18 @@ class OracleScript:
                     o.nve_group(self.group_flags(a[1]))
             elif style == "langevin":
                 o.fix_langevin(float(p[0]), float(p[1]), float(p[2]), int(p[3]), fid)
+                k = 4
+                while k < len(p):                   # optional keywords (src/fix_langevin.cpp:105-155)
+                    if p[k] == "scale":
+                        o.langevin_scale(int(p[k + 1]), float(p[k + 2]))
+                        k += 3
+                    elif p[k] == "zero":
+                        o.langevin_zero(p[k + 1] == "yes")
+                        k += 2
+                    elif p[k] in ("tally", "gjf", "omega", "angmom") and p[k + 1] == "no":      # (the defaults)
+                        k += 2
+                    else:
+                        raise ValueError("oracle script: fix langevin keyword " + p[k])
                 if a[1] != "all":
                     o.langevin_group(self.group_flags(a[1]))
             elif style == "extrusion":

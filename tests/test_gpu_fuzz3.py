@@ -173,6 +173,10 @@ def md_scenario(seed):
     lines.append("fix 1 %s nve" % gn)
     if rng.rand() < 0.7:
         lines.append("fix 2 %s langevin %g %g %g %d" % (gl, rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5), float(rng.choice([0.5, 1.0, 10.0])), int(rng.randint(1, 900000))))
+        if rng4.rand() < 0.25:                      # optional keywords: per-type damping, zeroed total random force
+            lines[-1] += " scale %d %g" % (int(rng4.randint(1, ntypes + 1)), rng4.uniform(0.5, 4.0))
+        if rng4.rand() < 0.2:
+            lines[-1] += " zero yes"
     if rng.rand() < 0.3:
         lines.append("thermo_modify norm %s" % str(rng.choice(["yes", "no"])))
     lines.append("thermo %d" % int(rng.choice([5, 10, 25, 1000])))
