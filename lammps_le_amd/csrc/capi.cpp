@@ -57,20 +57,10 @@ double lammps_get_thermo(void *handle, const char *keyword) {
   BEGIN_CAPTURE
     const ThermoRow &r = e->last_thermo;
     std::string k = keyword;
+    bool isint;
     if (k == "step") val = (double)e->ntimestep;
-    else if (k == "temp") val = r.temp;
-    else if (k == "epair" || k == "evdwl") val = r.epair;
-    else if (k == "emol" || k == "ebond") val = r.emol;
-    else if (k == "etotal") val = r.etotal;
-    else if (k == "press") val = r.press;
-    else if (k == "ke") val = r.ke;
-    else if (k == "pe") val = r.pe;
-    else if (k == "bonds") val = (double)e->nbonds;
-    else if (k == "angles") val = (double)e->nangles;
-    else if (k == "atoms") val = (double)e->natoms;
-    else if (k == "vol") val = e->box.prd[0] * e->box.prd[1] * e->box.prd[2];
-    else if (k == "dt") val = e->dt;
-    else throw LammpsError("Unknown keyword in thermo_style custom command: " + k);
+    else if (k.rfind("f_", 0) == 0 || !e->thermo_keyword(r, k, val, isint))
+      throw LammpsError("Unknown keyword in thermo_style custom command: " + k);
   END_CAPTURE
   return val;
 }

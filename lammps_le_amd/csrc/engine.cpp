@@ -726,66 +726,119 @@ ThermoRow Engine::eval_thermo() {
     double a8[8];
     reduce_angle_partials(d, a8);
     if (world > 1) comm->allreduce_host_sum(a8, 8);
-    r.ebond += a8[0];
+    r.eangle = a8[0];
     for (int k = 0; k < 6; k++) r.virial[k] += a8[1 + k];
   }
   double vol = box.prd[0] * box.prd[1] * box.prd[2];
   r.press = (dof * boltz * r.temp + r.virial[0] + r.virial[1] + r.virial[2]) / 3.0 / vol * nktv2p;
-  r.epair = r.evdwl / norm; r.emol = r.ebond / norm;
-  r.pe = (r.evdwl + r.ebond) / norm;
+  const double emol = r.ebond + r.eangle;
+  r.epair = r.evdwl / norm; r.emol = emol / norm;
+  r.pe = (r.evdwl + emol) / norm;
   r.ke = ke / norm;
-  r.etotal = (ke + r.evdwl + r.ebond) / norm;
+  r.etotal = (ke + r.evdwl + emol) / norm;
   r.nbonds = nbonds;
   sync_flags(d);
   check_device_error(this, d);
   return r;
 }
 
-static double thermo_value(Engine *e, const ThermoRow &r, const std::string &k) {
-  if (k == "step") return (double)r.step;
-  if (k == "temp") return r.temp;
-  if (k == "epair") return r.epair;
-  if (k == "emol" || k == "ebond") return r.emol;
-  if (k == "etotal") return r.etotal;
-  if (k == "press") return r.press;
-  if (k == "ke") return r.ke;
-  if (k == "pe") return r.pe;
-  if (k == "evdwl") return r.epair;
-  if (k == "bonds") return (double)r.nbonds;
-  if (k == "atoms") return (double)e->natoms;
-  if (k == "vol") return e->box.prd[0] * e->box.prd[1] * e->box.prd[2];
-  if (k.rfind("f_", 0) == 0) {
+bool Engine::thermo_keyword(const ThermoRow &r, const std::string &k, double &val, bool &isint) {
+  const double norm = thermo_norm ? (double)natoms : 1.0;
+  const double vol = box.prd[0] * box.prd[1] * box.prd[2];
+  isint = false;
+  if (k == "step") { val = (double)r.step; isint = true; }
+  else if (k == "elapsed" || k == "elaplong") { val = (double)(r.step - beginstep); isint = true; }   // firststep = beginstep: no `run start`
+  else if (k == "dt") val = dt;
+  else if (k == "time") val = atime + (double)(r.step - atimestep) * dt;            // src/thermo.cpp:1600-1603
+  else if (k == "cpu") val = thermo_first_line ? 0.0 : wall() - run_wall0;          // :1607-1611
+  else if (k == "atoms") { val = (double)natoms; isint = true; }
+  else if (k == "temp") val = r.temp;
+  else if (k == "press") val = r.press;
+  else if (k == "pe") val = r.pe;
+  else if (k == "ke") val = r.ke;
+  else if (k == "etotal") val = r.etotal;
+  else if (k == "enthalpy") val = r.etotal + r.press * (vol / norm) / nktv2p;       // :1732-1745
+  else if (k == "evdwl" || k == "epair") val = r.epair;                             // (no Coulomb, no tail correction)
+  else if (k == "ecoul" || k == "elong" || k == "etail" || k == "edihed" || k == "eimp") val = 0.0;
+  else if (k == "ebond") val = r.ebond / norm;
+  else if (k == "eangle") val = r.eangle / norm;
+  else if (k == "emol") val = r.emol;
+  else if (k == "vol") val = vol;
+  else if (k == "density") {                                                         // :1882-1887 (mv2d = 1 in lj units)
+    double m = 0.0;
+    for (int i = 0; i < natoms; i++) m += mass[type[i]];
+    val = mv2d * m / vol;
+  }
+  else if (k == "lx" || k == "ly" || k == "lz") val = box.prd[k[1] - 'x'];
+  else if (k == "xlo" || k == "ylo" || k == "zlo") val = box.lo[k[0] - 'x'];
+  else if (k == "xhi" || k == "yhi" || k == "zhi") val = box.hi[k[0] - 'x'];
+  else if (k == "xy" || k == "xz" || k == "yz") val = 0.0;
+  else if (k == "bonds") { val = (double)r.nbonds; isint = true; }
+  else if (k == "angles") { val = (double)nangles; isint = true; }
+  else if (k == "dihedrals" || k == "impropers") { val = 0.0; isint = true; }
+  else if (k == "nbuild") { val = (double)neigh_builds; isint = true; }             // :2099-2110
+  else if (k == "ndanger") { val = (double)neigh_dangerous; isint = true; }
+  else if (k.rfind("f_", 0) == 0) {
     size_t b = k.find('[');
     std::string id = k.substr(2, b == std::string::npos ? std::string::npos : b - 2);
-    Fix *f = e->find_fix(id);
+    Fix *f = find_fix(id);
     if (!f) throw LammpsError("Could not find thermo fix ID " + id);
     int idx = (b == std::string::npos) ? 1 : atoi(k.c_str() + b + 1);
-    return f->compute_vector(idx - 1);
+    val = f->compute_vector(idx - 1);
   }
-  throw LammpsError("Unknown keyword in thermo_style custom command: " + k);
+  else return false;
+  return true;
+}
+
+static const char *thermo_title(const std::string &k) {       // column titles: src/thermo.cpp:716-880
+  static const char *names[][2] = {
+      {"step", "Step"}, {"elapsed", "Elapsed"}, {"elaplong", "Elaplong"}, {"dt", "Dt"}, {"time", "Time"}, {"cpu", "CPU"},
+      {"atoms", "Atoms"}, {"temp", "Temp"}, {"press", "Press"}, {"pe", "PotEng"}, {"ke", "KinEng"}, {"etotal", "TotEng"},
+      {"enthalpy", "Enthalpy"}, {"evdwl", "E_vdwl"}, {"ecoul", "E_coul"}, {"epair", "E_pair"}, {"ebond", "E_bond"},
+      {"eangle", "E_angle"}, {"edihed", "E_dihed"}, {"eimp", "E_impro"}, {"emol", "E_mol"}, {"elong", "E_long"},
+      {"etail", "E_tail"}, {"vol", "Volume"}, {"density", "Density"}, {"lx", "Lx"}, {"ly", "Ly"}, {"lz", "Lz"}, {"xlo", "Xlo"},
+      {"xhi", "Xhi"}, {"ylo", "Ylo"}, {"yhi", "Yhi"}, {"zlo", "Zlo"}, {"zhi", "Zhi"}, {"xy", "Xy"}, {"xz", "Xz"}, {"yz", "Yz"},
+      {"bonds", "Bonds"}, {"angles", "Angles"}, {"dihedrals", "Diheds"}, {"impropers", "Impros"}, {"nbuild", "Nbuild"},
+      {"ndanger", "Ndanger"}};
+  for (auto &n : names) if (k == n[0]) return n[1];
+  return nullptr;
 }
 
 void Engine::print_thermo_header() {
+  thermo_first_line = true;
+  if (thermo_multi) return;                  // (src/thermo.cpp:314: no header line)
   std::string h;
   for (auto &k : thermo_keywords) {
-    std::string n = k;
-    if (k == "step") n = "Step"; else if (k == "temp") n = "Temp"; else if (k == "epair") n = "E_pair";
-    else if (k == "emol") n = "E_mol"; else if (k == "etotal") n = "TotEng"; else if (k == "press") n = "Press";
-    else if (k == "ke") n = "KinEng"; else if (k == "pe") n = "PotEng"; else if (k == "bonds") n = "Bonds";
-    h += n + " ";
+    const char *t = thermo_title(k);
+    h += (t ? std::string(t) : k) + " ";
   }
   say(h + "\n");
 }
 void Engine::print_thermo(const ThermoRow &r) {
   std::string line;
-  char buf[64];
+  char buf[96];
+  if (thermo_multi) {
+    snprintf(buf, sizeof buf, "---------------- Step %8ld ----- CPU = %11.4f (sec) ----------------", r.step,
+             thermo_first_line ? 0.0 : wall() - run_wall0);
+    line = buf;
+  }
+  size_t col = 0;
   for (auto &k : thermo_keywords) {
-    double val = thermo_value(this, r, k);
-    if (k == "step" || k == "bonds" || k == "atoms") snprintf(buf, sizeof buf, "%8ld ", (long)val);
+    double val;
+    bool isint;
+    if (!thermo_keyword(r, k, val, isint)) throw LammpsError("Unknown keyword in thermo_style custom command: " + k);
+    if (thermo_multi) {                      // "\n" before every third value, `%-8s = %14.4f ` (src/thermo.cpp:239-266)
+      if (col % 3 == 0) line += "\n";
+      const char *t = thermo_title(k);
+      if (isint) snprintf(buf, sizeof buf, "%-8s = %14ld ", t ? t : k.c_str(), (long)val);
+      else snprintf(buf, sizeof buf, "%-8s = %14.4f ", t ? t : k.c_str(), val);
+    } else if (isint) snprintf(buf, sizeof buf, "%8ld ", (long)val);
     else snprintf(buf, sizeof buf, "%12.8g ", val);
     line += buf;
+    col++;
   }
   say(line + "\n");
+  thermo_first_line = false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1171,8 +1224,11 @@ void Engine::run(long nsteps) {
     ktime_counter = 0;
     ktime_every = nsteps <= 64 ? 1 : 16;
     t0 = wall();
+    run_wall0 = t0;
     if (respa_levels > 0) respa_iterate(nsteps); else iterate(nsteps);
     loop_time = wall() - t0;
+    atime += (double)(ntimestep - atimestep) * dt;       // Update::update_time at the end of a run (src/verlet.cpp:362)
+    atimestep = ntimestep;
   } catch (...) {
     // a rank that leaves the loop on an error must not keep its peers inside a collective: tear the communicator down
     // (they end with "communicator aborted" or their own copy of the error; see Comm::wait_stream)

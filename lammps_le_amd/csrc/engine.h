@@ -177,8 +177,9 @@ struct FixExUnload : Fix {   // also the stock `bond/break` (src/MC/fix_bond_bre
 struct ThermoRow {
   long step;
   double temp, epair, emol, etotal, press, ke, pe;
-  double evdwl, ebond, virial[6];
+  double evdwl, ebond, virial[6];      // (sums over the system; ebond = bonds only)
   long nbonds;
+  double eangle = 0.0;                 // sum over the listed angles
 };
 
 class Engine {
@@ -193,7 +194,7 @@ class Engine {
 
   // ---- global state ----
   std::string units = "lj", atom_style = "atomic";
-  double boltz = 1, mvv2e = 1, ftm2v = 1, nktv2p = 1, dt = 0.005;
+  double boltz = 1, mvv2e = 1, ftm2v = 1, nktv2p = 1, mv2d = 1, dt = 0.005;
   double skin = 0.3;
   int neigh_every = 1, neigh_delay = 10, neigh_check = 1;
   bool newton_pair = true, newton_bond = true;
@@ -278,6 +279,14 @@ class Engine {
   void compute_forces(bool eflag);
   ThermoRow eval_thermo();
   void print_thermo_header();
+  // one thermo keyword (src/thermo.cpp:1572-2110 compute_*): false when the keyword is unknown.  `r` = the row the energies
+  // come from; `isint` = printed with the integer format (BIGINT fields)
+  bool thermo_keyword(const ThermoRow &r, const std::string &k, double &val, bool &isint);
+  bool thermo_multi = false;           // thermo_style multi (src/thermo.cpp:115-119, 171-180, 361-366)
+  bool thermo_first_line = true;       // the first line of a run prints CPU = 0 (Thermo::firststep)
+  double run_wall0 = 0.0;              // wall clock at the start of the run's loop (Timer::TOTAL)
+  double atime = 0.0;                  // Update::atime / atimestep: simulation time accumulated over runs with changing dt
+  long atimestep = 0;
   void print_thermo(const ThermoRow &);
   ThermoRow last_thermo{};
   std::vector<ThermoRow> thermo_log;

@@ -135,19 +135,12 @@ struct Parser {
       if (name == "max" && two) return a > b ? a : b;
       throw LammpsError("Invalid math function in variable formula: " + name);
     }
-    const ThermoRow &r = e->last_thermo;
     if (name == "step") return (double)e->ntimestep;
-    if (name == "dt") return e->dt;
-    if (name == "atoms") return (double)e->natoms;
-    if (name == "bonds") return (double)e->nbonds;
-    if (name == "vol") return e->box.prd[0] * e->box.prd[1] * e->box.prd[2];
-    if (name == "temp") return r.temp;
-    if (name == "press") return r.press;
-    if (name == "pe") return r.pe;
-    if (name == "ke") return r.ke;
-    if (name == "etotal") return r.etotal;
-    if (name == "epair" || name == "evdwl") return r.epair;
-    if (name == "emol" || name == "ebond") return r.emol;
+    {
+      double val;
+      bool isint;
+      if (name.rfind("f_", 0) != 0 && e->thermo_keyword(e->last_thermo, name, val, isint)) return val;
+    }
     if (name == "PI") return 3.14159265358979323846;
     throw LammpsError("Invalid thermo keyword in variable formula: " + name);
   }
@@ -279,11 +272,11 @@ const char *Engine::one(const std::string &raw) {
 static void set_units(Engine *e, const std::string &u) {
   // src/update.cpp:132-200
   if (u == "lj") {
-    e->boltz = 1.0; e->mvv2e = 1.0; e->ftm2v = 1.0; e->nktv2p = 1.0; e->dt = 0.005; e->skin = 0.3;
+    e->boltz = 1.0; e->mvv2e = 1.0; e->ftm2v = 1.0; e->nktv2p = 1.0; e->mv2d = 1.0; e->dt = 0.005; e->skin = 0.3;
     e->thermo_norm = true;
   } else if (u == "real") {
     e->boltz = 0.0019872067; e->mvv2e = 48.88821291 * 48.88821291; e->ftm2v = 1.0 / 48.88821291 / 48.88821291;
-    e->nktv2p = 68568.415; e->dt = 1.0; e->skin = 2.0;
+    e->nktv2p = 68568.415; e->mv2d = 1.0 / 0.602214129; e->dt = 1.0; e->skin = 2.0;
     e->thermo_norm = false;
   } else throw LammpsError("Illegal units command (MI355X engine supports lj and real)");
   e->units = u;
@@ -547,15 +540,30 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
     if (thermo_every < 0) throw LammpsError("Illegal thermo command");
   } else if (cmd == "thermo_style") {
     need(1);
+    thermo_multi = false;
     if (arg[0] == "one") thermo_keywords = {"step", "temp", "epair", "emol", "etotal", "press"};
-    else if (arg[0] == "custom") {
+    else if (arg[0] == "multi") {                                  // src/thermo.cpp:70, 115-119
+      thermo_keywords = {"etotal", "ke", "temp", "pe", "ebond", "eangle", "edihed", "eimp", "evdwl", "ecoul", "elong", "press"};
+      thermo_multi = true;
+    } else if (arg[0] == "custom") {
       if (arg.size() < 2) throw LammpsError("Illegal thermo style custom command");
+      for (size_t k = 1; k < arg.size(); k++) {                    // (unknown keywords stop here: src/thermo.cpp:884-1040)
+        double val;
+        bool isint;
+        if (arg[k].rfind("f_", 0) != 0 && !thermo_keyword(last_thermo, arg[k], val, isint))
+          throw LammpsError("Unknown keyword in thermo_style custom command: " + arg[k]);
+      }
       thermo_keywords.assign(arg.begin() + 1, arg.end());
     } else throw LammpsError("Illegal thermo_style command");
   } else if (cmd == "thermo_modify") {
     for (size_t i = 0; i < arg.size();) {
       if (i + 2 > arg.size()) throw LammpsError("Illegal thermo_modify command");
       if (arg[i] == "norm") thermo_norm = (arg[i + 1] == "yes");
+      else if (arg[i] == "line") {                                 // src/thermo.cpp:551-556
+        if (arg[i + 1] == "one") thermo_multi = false;
+        else if (arg[i + 1] == "multi") thermo_multi = true;
+        else throw LammpsError("Illegal thermo_modify command");
+      }
       else if (arg[i] == "format") { i += 3; continue; }
       i += 2;
     }
@@ -565,6 +573,8 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
   } else if (cmd == "reset_timestep") {
     need(1);
     ntimestep = atol(arg[0].c_str());
+    if (ntimestep < 0) throw LammpsError("Timestep must be >= 0");      // src/update.cpp:474-482
+    atimestep = ntimestep;
   } else if (cmd == "run") {
     need(1);
     long nrun = atol(arg[0].c_str());

@@ -138,3 +138,64 @@ def test_write_data_round_trip_with_angles(tmp_path):
         q.command("read_data " + out if w and w[0] == "read_data" else ln)
     assert q.angle_set() == p.angle_set() and q.extract_setting("nangles") == p.extract_setting("nangles") == len(s["angles"])
     assert relerr(q.gather("f"), p.gather("f")) < 1e-12
+
+
+def test_thermo_keywords_and_multi_style(tmp_path):
+    """`thermo_style custom` with the keyword set of src/thermo.cpp:716-880 that has a meaning for this model (ebond / eangle /
+    emol apart, enthalpy, density, box, time across a `timestep` change, elapsed, nbuild, cpu ..) and `thermo_style multi`
+    (`---------------- Step ... CPU = ...` + `%-8s = %14.4f`, three values per line: src/thermo.cpp:171-180, 239-266),
+    read back from the log the engine writes; energies against the oracle."""
+    import re
+    from lammps_le_amd import LammpsError
+    n = 3000
+    s = semiflexible(n, 3, seed=8)
+    s["mass"] = [1.5] * s["ntypes"]
+    body = "angle_style harmonic\nangle_coeff 1 3.0 170.0\nangle_coeff 2 1.0 100.0\nfix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
+    log = str(tmp_path / "log.thermo")
+    kws = ("step elapsed dt time cpu atoms temp press pe ke etotal enthalpy evdwl ecoul epair ebond eangle edihed eimp emol elong "
+           "etail vol density lx ly lz xlo xhi ylo yhi zlo zhi bonds angles nbuild ndanger")
+    script = (ANGLE_SCRIPT + body + "log %s\nthermo 10\nthermo_style custom %s\nrun 20\ntimestep 0.002\nrun 10\n"
+              "thermo_style multi\nrun 10\n" % (log, kws))
+    o = run_oracle(ANGLE_SCRIPT + body + "thermo 10\nrun 20\ntimestep 0.002\nrun 10\nrun 10\n", s)
+    p = run_product(script, s, tmp_path)
+    p.command("log none")
+    text = open(log).read()
+    head = ("Step Elapsed Dt Time CPU Atoms Temp Press PotEng KinEng TotEng Enthalpy E_vdwl E_coul E_pair E_bond E_angle E_dihed "
+            "E_impro E_mol E_long E_tail Volume Density Lx Ly Lz Xlo Xhi Ylo Yhi Zlo Zhi Bonds Angles Nbuild Ndanger")
+    assert text.count(head) == 2
+    names = kws.split()
+    rows = [dict(zip(names, [float(v) for v in ln.split()])) for ln in text.split("\n")
+            if len(ln.split()) == len(names) and re.match(r"^\s*\d+ ", ln)]
+    assert [r["step"] for r in rows] == [0, 10, 20, 20, 30]
+    assert [r["elapsed"] for r in rows] == [0, 10, 20, 0, 10]
+    L = float(s["box"][0][1] - s["box"][0][0])
+    ho = o.thermo_history()            # rows (step, temp, epair, emol, etotal, press): three runs -> 0 10 20 | 20 30 | 30 40
+    for r, ref in zip(rows, ho[:5]):
+        assert r["step"] == ref[0]
+        for key, col in (("temp", 1), ("epair", 2), ("emol", 3), ("etotal", 4), ("press", 5)):
+            assert abs(r[key] - ref[col]) <= 2e-7 * max(1.0, abs(ref[col])), (key, r["step"])      # (%12.8g)
+        assert abs(r["ebond"] + r["eangle"] - r["emol"]) < 5e-6 and r["eangle"] > 0.0 and r["evdwl"] == r["epair"]
+        assert abs(r["pe"] - (r["epair"] + r["emol"])) < 5e-6 and abs(r["etotal"] - (r["pe"] + r["ke"])) < 5e-6    # (8 digits each)
+        assert abs(r["enthalpy"] - (r["etotal"] + r["press"] * L ** 3 / n)) < 5e-5
+        assert r["ecoul"] == r["elong"] == r["etail"] == r["edihed"] == r["eimp"] == 0.0
+        assert r["atoms"] == n and r["bonds"] == len(s["bonds"]) and r["angles"] == len(s["angles"])
+        assert abs(r["vol"] - L ** 3) < 1e-3 and abs(r["density"] - 1.5 * n / L ** 3) < 1e-7 and abs(r["lx"] - L) < 1e-6
+        assert abs(r["xhi"] - r["xlo"] - L) < 1e-6 and r["dt"] == (0.005 if r is not rows[3] and r is not rows[4] else 0.002)
+    assert [round(r["time"], 9) for r in rows] == [0.0, 0.05, 0.1, 0.1, 0.12]
+    assert rows[0]["cpu"] == 0.0 and rows[3]["cpu"] == 0.0 and rows[2]["cpu"] > rows[1]["cpu"] > 0.0
+    assert rows[2]["nbuild"] >= rows[1]["nbuild"] >= rows[0]["nbuild"] == 0
+    assert abs(p.get_thermo("eangle") * 1.0 - o.angle_energy() / n) <= 1e-9 * max(1.0, abs(o.angle_energy() / n))
+    # the multi style of the third run
+    blocks = re.findall(r"-{16} Step +(\d+) -{5} CPU = +([0-9.]+) \(sec\) -{16}\n((?:.+\n){4})", text)
+    assert [int(b[0]) for b in blocks] == [30, 40] and float(blocks[0][1]) == 0.0
+    first = blocks[1][2].split("\n")
+    assert re.match(r"^TotEng   = +-?\d+\.\d{4} KinEng   = +-?\d+\.\d{4} Temp     = +-?\d+\.\d{4} $", first[0])
+    assert first[1].startswith("PotEng   = ") and "E_bond   = " in first[1] and "E_angle  = " in first[1]
+    assert first[3].startswith("E_coul   = ") and "E_long   = " in first[3] and "Press    = " in first[3]
+    vals = dict(re.findall(r"(\S+) += +(-?\d+\.\d+)", blocks[1][2]))
+    last = ho[-1]
+    assert abs(float(vals["Temp"]) - last[1]) < 1e-4 and abs(float(vals["TotEng"]) - last[4]) < 1e-4
+    with pytest.raises(LammpsError, match="Unknown keyword in thermo_style custom command"):
+        p.command("thermo_style custom step colour")
+    p.command("thermo_style custom step temp")
+    p.command("thermo_modify line multi")
