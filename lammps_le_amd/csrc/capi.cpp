@@ -104,6 +104,8 @@ void *lammps_extract_global(void *handle, const char *name) {
   std::string k = name;
   if (k == "dt") return &e->dt;
   if (k == "ntimestep") return &e->ntimestep;
+  if (k == "atime") return &e->atime;              // src/library.cpp:1332-1333
+  if (k == "atimestep") return &e->atimestep;
   if (k == "boxlo") return e->box.lo;
   if (k == "boxhi") return e->box.hi;
   if (k == "natoms") { e->scratch_scalar = e->natoms; return &e->scratch_scalar; }

@@ -1214,6 +1214,7 @@ void Engine::run(long nsteps) {
   dev->bond_pack_dirty = true;
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
+  atimestep = ntimestep;            // Integrate::init (src/integrate.cpp:48)
   halo_step = -1;
   host_current = false;
   double t0 = 0.0;

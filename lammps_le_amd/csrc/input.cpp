@@ -1824,6 +1824,7 @@ void Engine::read_restart(const std::string &path) {
       restart_fix_state[id] = b;
     }
     group_names = {"all"}; gmask.clear();
+    atime = 0.0; atimestep = 0;      // (the reference's restart files do not carry the simulation time either)
     nangletypes = 0; extra_angle = 0; apa = 0; nangles = 0;
     num_angle.clear(); angle_type.clear(); angle_a1.clear(); angle_a2.clear(); angle_a3.clear(); angle_style_name.clear();
     for (;;) {                  // optional tagged sections
