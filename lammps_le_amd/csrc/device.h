@@ -254,6 +254,8 @@ void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, b
 void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool identity_rank, int groupbit, long members);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt, int groupbit = 1);
 void launch_ke(DeviceState &d, const TypeTables &tt);
+// sum(m v_i v_j) over the owned beads, order xx yy zz xy xz yz (the kinetic part of the pressure tensor); synchronous
+void ke_tensor(DeviceState &d, const TypeTables &tt, double *out6);
 // angle forces added to f (after launch_force); eflag: energy / virial thirds into partial_a (reduce_angle_partials)
 void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwrite = false);
 void launch_angle_list(DeviceState &d);       // at every reneighbor of a run with an angle style

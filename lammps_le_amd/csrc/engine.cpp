@@ -737,6 +737,13 @@ ThermoRow Engine::eval_thermo() {
   r.ke = ke / norm;
   r.etotal = (ke + r.evdwl + emol) / norm;
   r.nbonds = nbonds;
+  if (want_ptensor) {          // (ke_tensor[i] + virial[i]) / volume * nktv2p, src/compute_pressure.cpp:244-290
+    double k6[6];
+    ke_tensor(d, tt, k6);
+    if (world > 1) comm->allreduce_host_sum(k6, 6);
+    for (int k = 0; k < 6; k++) r.ptensor[k] = (k6[k] * mvv2e + r.virial[k]) / vol * nktv2p;
+    r.has_ptensor = true;
+  }
   sync_flags(d);
   check_device_error(this, d);
   return r;
@@ -773,6 +780,12 @@ bool Engine::thermo_keyword(const ThermoRow &r, const std::string &k, double &va
   else if (k == "xlo" || k == "ylo" || k == "zlo") val = box.lo[k[0] - 'x'];
   else if (k == "xhi" || k == "yhi" || k == "zhi") val = box.hi[k[0] - 'x'];
   else if (k == "xy" || k == "xz" || k == "yz") val = 0.0;
+  else if (k == "pxx" || k == "pyy" || k == "pzz" || k == "pxy" || k == "pxz" || k == "pyz") {   // :2024-2063
+    static const char *names[6] = {"pxx", "pyy", "pzz", "pxy", "pxz", "pyz"};
+    want_ptensor = true;       // (from the next thermo evaluation on; `thermo_style` names its keywords before the run)
+    val = 0.0;
+    for (int c = 0; c < 6; c++) if (k == names[c]) val = r.ptensor[c];
+  }
   else if (k == "bonds") { val = (double)r.nbonds; isint = true; }
   else if (k == "angles") { val = (double)nangles; isint = true; }
   else if (k == "dihedrals" || k == "impropers") { val = 0.0; isint = true; }
@@ -798,7 +811,7 @@ static const char *thermo_title(const std::string &k) {       // column titles: 
       {"eangle", "E_angle"}, {"edihed", "E_dihed"}, {"eimp", "E_impro"}, {"emol", "E_mol"}, {"elong", "E_long"},
       {"etail", "E_tail"}, {"vol", "Volume"}, {"density", "Density"}, {"lx", "Lx"}, {"ly", "Ly"}, {"lz", "Lz"}, {"xlo", "Xlo"},
       {"xhi", "Xhi"}, {"ylo", "Ylo"}, {"yhi", "Yhi"}, {"zlo", "Zlo"}, {"zhi", "Zhi"}, {"xy", "Xy"}, {"xz", "Xz"}, {"yz", "Yz"},
-      {"bonds", "Bonds"}, {"angles", "Angles"}, {"dihedrals", "Diheds"}, {"impropers", "Impros"}, {"nbuild", "Nbuild"},
+      {"pxx", "Pxx"}, {"pyy", "Pyy"}, {"pzz", "Pzz"}, {"pxy", "Pxy"}, {"pxz", "Pxz"}, {"pyz", "Pyz"}, {"bonds", "Bonds"}, {"angles", "Angles"}, {"dihedrals", "Diheds"}, {"impropers", "Impros"}, {"nbuild", "Nbuild"},
       {"ndanger", "Ndanger"}};
   for (auto &n : names) if (k == n[0]) return n[1];
   return nullptr;

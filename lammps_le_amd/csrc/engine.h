@@ -180,6 +180,8 @@ struct ThermoRow {
   double evdwl, ebond, virial[6];      // (sums over the system; ebond = bonds only)
   long nbonds;
   double eangle = 0.0;                 // sum over the listed angles
+  double ptensor[6] = {0, 0, 0, 0, 0, 0};   // pxx pyy pzz pxy pxz pyz (src/compute_pressure.cpp:244-290), when asked for
+  bool has_ptensor = false;
 };
 
 class Engine {
@@ -282,6 +284,7 @@ class Engine {
   // one thermo keyword (src/thermo.cpp:1572-2110 compute_*): false when the keyword is unknown.  `r` = the row the energies
   // come from; `isint` = printed with the integer format (BIGINT fields)
   bool thermo_keyword(const ThermoRow &r, const std::string &k, double &val, bool &isint);
+  bool want_ptensor = false;           // a pressure-tensor keyword was named: thermo steps also reduce the kinetic tensor
   bool thermo_multi = false;           // thermo_style multi (src/thermo.cpp:115-119, 171-180, 361-366)
   bool thermo_first_line = true;       // the first line of a run prints CPU = 0 (Thermo::firststep)
   double run_wall0 = 0.0;              // wall clock at the start of the run's loop (Timer::TOTAL)

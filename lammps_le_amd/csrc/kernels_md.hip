@@ -813,6 +813,29 @@ void launch_flevel_copy(DeviceState &d, double *flevel, bool to_level, bool add)
   hipLaunchKernelGGL(k_flevel_copy, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.tag, d.f[0], d.f[1], d.f[2], flevel,
                      to_level ? 1 : 0, add ? 1 : 0);
 }
+// kinetic-energy tensor sum(m v_i v_j), order xx yy zz xy xz yz (ComputeTemp::compute_vector, src/compute_temp.cpp:108-140):
+// block sums into the scratch rows of DeviceState::lgsum, added on the host in block order
+__global__ __launch_bounds__(BLOCK) void k_ke_tensor(int n, const double4 *__restrict__ pos, const double *__restrict__ vx,
+                                                     const double *__restrict__ vy, const double *__restrict__ vz,
+                                                     TypeTables tt, double *__restrict__ partial) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  double val[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (p < n) {
+    double a = vx[p], b = vy[p], c = vz[p], m = tt.mass[(int)pos[p].w];
+    val[0] = m * a * a; val[1] = m * b * b; val[2] = m * c * c;
+    val[3] = m * a * b; val[4] = m * a * c; val[5] = m * b * c;
+  }
+  block_reduce_store<6>(val, partial, blockIdx.x, 0);
+}
+void ke_tensor(DeviceState &d, const TypeTables &tt, double *out6) {
+  const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
+  hipLaunchKernelGGL(k_ke_tensor, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2], tt, d.lgsum);
+  std::vector<double> h((size_t)nb * 16);
+  HIP_CHECK(hipMemcpyAsync(h.data(), d.lgsum, h.size() * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  stream_sync(d);
+  for (int k = 0; k < 6; k++) out6[k] = 0.0;
+  for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) out6[k] += h[(size_t)b * 16 + k];
+}
 void launch_ke(DeviceState &d, const TypeTables &tt) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
   hipLaunchKernelGGL(k_ke, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2], tt, d.partial);

@@ -153,7 +153,7 @@ def test_thermo_keywords_and_multi_style(tmp_path):
     body = "angle_style harmonic\nangle_coeff 1 3.0 170.0\nangle_coeff 2 1.0 100.0\nfix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
     log = str(tmp_path / "log.thermo")
     kws = ("step elapsed dt time cpu atoms temp press pe ke etotal enthalpy evdwl ecoul epair ebond eangle edihed eimp emol elong "
-           "etail vol density lx ly lz xlo xhi ylo yhi zlo zhi bonds angles nbuild ndanger")
+           "etail vol density lx ly lz xlo xhi ylo yhi zlo zhi bonds angles nbuild ndanger pxx pyy pzz pxy pxz pyz")
     script = (ANGLE_SCRIPT + body + "log %s\nthermo 10\nthermo_style custom %s\nrun 20\ntimestep 0.002\nrun 10\n"
               "thermo_style multi\nrun 10\n" % (log, kws))
     o = run_oracle(ANGLE_SCRIPT + body + "thermo 10\nrun 20\ntimestep 0.002\nrun 10\nrun 10\n", s)
@@ -161,7 +161,7 @@ def test_thermo_keywords_and_multi_style(tmp_path):
     p.command("log none")
     text = open(log).read()
     head = ("Step Elapsed Dt Time CPU Atoms Temp Press PotEng KinEng TotEng Enthalpy E_vdwl E_coul E_pair E_bond E_angle E_dihed "
-            "E_impro E_mol E_long E_tail Volume Density Lx Ly Lz Xlo Xhi Ylo Yhi Zlo Zhi Bonds Angles Nbuild Ndanger")
+            "E_impro E_mol E_long E_tail Volume Density Lx Ly Lz Xlo Xhi Ylo Yhi Zlo Zhi Bonds Angles Nbuild Ndanger Pxx Pyy Pzz Pxy Pxz Pyz")
     assert text.count(head) == 2
     names = kws.split()
     rows = [dict(zip(names, [float(v) for v in ln.split()])) for ln in text.split("\n")
@@ -177,6 +177,7 @@ def test_thermo_keywords_and_multi_style(tmp_path):
         assert abs(r["ebond"] + r["eangle"] - r["emol"]) < 5e-6 and r["eangle"] > 0.0 and r["evdwl"] == r["epair"]
         assert abs(r["pe"] - (r["epair"] + r["emol"])) < 5e-6 and abs(r["etotal"] - (r["pe"] + r["ke"])) < 5e-6    # (8 digits each)
         assert abs(r["enthalpy"] - (r["etotal"] + r["press"] * L ** 3 / n)) < 5e-5
+        assert abs((r["pxx"] + r["pyy"] + r["pzz"]) / 3.0 - r["press"]) < 5e-6 * max(1.0, abs(r["press"]))
         assert r["ecoul"] == r["elong"] == r["etail"] == r["edihed"] == r["eimp"] == 0.0
         assert r["atoms"] == n and r["bonds"] == len(s["bonds"]) and r["angles"] == len(s["angles"])
         assert abs(r["vol"] - L ** 3) < 1e-3 and abs(r["density"] - 1.5 * n / L ** 3) < 1e-7 and abs(r["lx"] - L) < 1e-6
@@ -185,6 +186,13 @@ def test_thermo_keywords_and_multi_style(tmp_path):
     assert rows[0]["cpu"] == 0.0 and rows[3]["cpu"] == 0.0 and rows[2]["cpu"] > rows[1]["cpu"] > 0.0
     assert rows[2]["nbuild"] >= rows[1]["nbuild"] >= rows[0]["nbuild"] == 0
     assert abs(p.get_thermo("eangle") * 1.0 - o.angle_energy() / n) <= 1e-9 * max(1.0, abs(o.angle_energy() / n))
+    # the pressure tensor of the last step: (sum m v_i v_j + W_ij) / V with the oracle's velocities and virials
+    v = o.v()
+    ke6 = 1.5 * np.array([(v[:, a] * v[:, b]).sum() for a, b in ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))])
+    w6 = np.asarray(o.pair_virial()) + np.asarray(o.bond_virial()) + np.asarray(o.angle_virial())
+    for k, key in enumerate(("pxx", "pyy", "pzz", "pxy", "pxz", "pyz")):
+        ref = (ke6[k] + w6[k]) / L ** 3
+        assert abs(p.get_thermo(key) - ref) <= 1e-8 * max(1.0, abs(ref)), key
     # the multi style of the third run
     blocks = re.findall(r"-{16} Step +(\d+) -{5} CPU = +([0-9.]+) \(sec\) -{16}\n((?:.+\n){4})", text)
     assert [int(b[0]) for b in blocks] == [30, 40] and float(blocks[0][1]) == 0.0
