@@ -706,10 +706,10 @@ static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
   rng_langevin_consumed(*e->dev);
 }
 
-ThermoRow Engine::eval_thermo() {
+ThermoRow Engine::eval_thermo(bool ke_summed) {
   DeviceState &d = *dev;
   TypeTables tt = make_tables(this, nullptr);
-  launch_ke(d, tt);
+  if (!ke_summed) launch_ke(d, tt);       // (the energy variant of the step kernel has summed the kinetic energy as well)
   double s[16];
   reduce_partials(d, s);
   if (world > 1) comm->allreduce_host_sum(s, 16);
@@ -993,7 +993,7 @@ void Engine::iterate(long nsteps) {
       if (lg) rng_langevin_consumed(d);
       pre_integrated = false;
       stamp(T_PAIR);
-      last_thermo = eval_thermo();
+      last_thermo = eval_thermo(true);
       thermo_log.push_back(last_thermo);
       print_thermo(last_thermo);
       stamp(T_OUTPUT);

@@ -279,7 +279,7 @@ class Engine {
   void respa_recurse(int ilevel, bool last);   // Respa::recurse
   void respa_level_forces(int ilevel);
   void compute_forces(bool eflag);
-  ThermoRow eval_thermo();
+  ThermoRow eval_thermo(bool ke_summed = false);
   void print_thermo_header();
   // one thermo keyword (src/thermo.cpp:1572-2110 compute_*): false when the keyword is unknown.  `r` = the row the energies
   // come from; `isint` = printed with the integer format (BIGINT fields)

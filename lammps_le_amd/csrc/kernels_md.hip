@@ -149,6 +149,25 @@ __device__ __forceinline__ void block_reduce_store(double (&val)[NV], double *__
   }
 }
 
+// column sums of a [nb][W] table of block partials in ONE workgroup, the same order on every run: thread (g, c) adds rows
+// g, g + G, g + 2G .. of column c (G = BLOCK / W row groups), then the G group sums are added in group order.  A thermo step
+// used to copy the table to the host and add it there (0.5 MB + 65k additions at 1M beads: most of the 190 us a thermo step
+// spent outside kernels); now 16 doubles cross
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_colsum(int nb, const double *__restrict__ in, double *__restrict__ out) {
+  constexpr int G = BLOCK / W;
+  __shared__ double part[G][W];
+  const int c = threadIdx.x % W, g = threadIdx.x / W;
+  double s = 0.0;
+  for (int b = g; b < nb; b += G) s += in[(size_t)b * W + c];
+  part[g][c] = s;
+  __syncthreads();
+  if (threadIdx.x < W) {
+    double t = 0.0;
+    for (int k = 0; k < G; k++) t += part[k][threadIdx.x];
+    out[threadIdx.x] = t;
+  }
+}
 __global__ __launch_bounds__(BLOCK) void k_ke(int n, const double4 *__restrict__ pos, const double *__restrict__ vx,
                                               const double *__restrict__ vy, const double *__restrict__ vz,
                                               TypeTables tt, double *__restrict__ partial) {
@@ -587,7 +606,7 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
                                           double *__restrict__ fz, double4 *__restrict__ pos_next,
                                           const double4 *__restrict__ xhold, double dtv, double triggersq,
                                           int check, int *__restrict__ flags,
-                                          const unsigned char *__restrict__ phase, int which, double (&e)[14]) {
+                                          const unsigned char *__restrict__ phase, int which, double (&e)[14], double &ke) {
   int lb = logical_block(A.nblocks);
   const int sub = (LPB == 1) ? 0 : (int)(threadIdx.x % LPB);
   int p = lb * (BLOCK / LPB) + threadIdx.x / LPB;
@@ -641,6 +660,7 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
   if (poisoned) return;
   const double dtfm = tt.dtfm[type];
   a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;          // final_integrate of this step
+  if (EF) ke = (a * a + b * b + c * c) * tt.mass[type];    // the kinetic energy thermo reads (k_ke's term, column 14)
   if (NEXT) {
     a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;        // initial_integrate of the next step
     ri.x += dtv * a; ri.y += dtv * b; ri.z += dtv * c;
@@ -706,15 +726,19 @@ __global__ __launch_bounds__(BLOCK, ((AHEAD || EF) ? 1 : STEP_WAVES_PER_SIMD)) v
     for (int k = threadIdx.x; k < 6 * A.nt * A.nt; k += BLOCK) s_tab[k] = A.pairtab[k];
   __syncthreads();
   double e[14];
+  double kev[1] = {0.0};
   if (EF) {
 #pragma unroll
     for (int k = 0; k < 14; k++) e[k] = 0.0;
   }
   step_body<LANGEVIN, NEXT, IDENT, HAS_PAIR, LPB, DIAG, AHEAD, ANG, EF>(A, bt, box, tt, s_tab, s_bt, tag, crank, draws, vx, vy, vz, fx, fy, fz,
-                                                                        pos_next, xhold, dtv, triggersq, check, flags, phase, which, e);
+                                                                        pos_next, xhold, dtv, triggersq, check, flags, phase, which, e, kev[0]);
   if (EF) {
     const int lb = logical_block(A.nblocks);
-    if (lb < A.nblocks) block_reduce_store<14>(e, reinterpret_cast<double *>(pos_next), lb, 0);
+    if (lb < A.nblocks) {
+      block_reduce_store<14>(e, reinterpret_cast<double *>(pos_next), lb, 0);
+      block_reduce_store<1>(kev, reinterpret_cast<double *>(pos_next), lb, 14);
+    }
   }
 }
 
@@ -830,11 +854,10 @@ __global__ __launch_bounds__(BLOCK) void k_ke_tensor(int n, const double4 *__res
 void ke_tensor(DeviceState &d, const TypeTables &tt, double *out6) {
   const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
   hipLaunchKernelGGL(k_ke_tensor, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.v[0], d.v[1], d.v[2], tt, d.lgsum);
-  std::vector<double> h((size_t)nb * 16);
-  HIP_CHECK(hipMemcpyAsync(h.data(), d.lgsum, h.size() * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  hipLaunchKernelGGL((k_colsum<16>), dim3(1), dim3(BLOCK), 0, d.stream, nb, d.lgsum, d.lgsum + (size_t)nb * 16);
+  HIP_CHECK(hipMemcpyAsync(d.partial_h, d.lgsum + (size_t)nb * 16, 16 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
   stream_sync(d);
-  for (int k = 0; k < 6; k++) out6[k] = 0.0;
-  for (int b = 0; b < nb; b++) for (int k = 0; k < 6; k++) out6[k] += h[(size_t)b * 16 + k];
+  for (int k = 0; k < 6; k++) out6[k] = d.partial_h[k];
 }
 void launch_ke(DeviceState &d, const TypeTables &tt) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
@@ -1155,25 +1178,22 @@ void launch_angle(DeviceState &d, const AngleTable &at, bool eflag, bool overwri
 }
 void reduce_angle_partials(DeviceState &d, double *out8) {
   const int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
-  std::vector<double> h((size_t)nb * 8);
-  HIP_CHECK(hipMemcpyAsync(h.data(), d.partial_a, h.size() * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+  hipLaunchKernelGGL((k_colsum<8>), dim3(1), dim3(BLOCK), 0, d.stream, nb, d.partial_a, d.partial_a + (size_t)nb * 8);
+  HIP_CHECK(hipMemcpyAsync(d.partial_h, d.partial_a + (size_t)nb * 8, 8 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
   stream_sync(d);
-  for (int k = 0; k < 8; k++) out8[k] = 0.0;
-  for (int b = 0; b < nb; b++) for (int k = 0; k < 8; k++) out8[k] += h[(size_t)b * 8 + k];
+  for (int k = 0; k < 8; k++) out8[k] = d.partial_h[k];
 }
 
 // can the fused step kernel take the angle forces of a run (launch_step's angle_forces)?  Needs the pair-style instantiations
 bool step_fuses_angles(const DeviceState &d, bool has_pair) { (void)d; return has_pair; }
 
-// sum the per-block partials on the host in block order (deterministic)
+// sum the per-block partials in a fixed order (deterministic); the totals land in the table's spare row nb
 void reduce_partials(DeviceState &d, double *out16) {
   int nb = (d.n + BLOCK - 1) / BLOCK;
-  HIP_CHECK(hipMemcpyAsync(d.partial_h, d.partial, (size_t)nb * 16 * sizeof(double), hipMemcpyDeviceToHost,
-                           d.stream));
+  hipLaunchKernelGGL((k_colsum<16>), dim3(1), dim3(BLOCK), 0, d.stream, nb, d.partial, d.partial + (size_t)nb * 16);
+  HIP_CHECK(hipMemcpyAsync(d.partial_h, d.partial + (size_t)nb * 16, 16 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
   stream_sync(d);
-  for (int k = 0; k < 16; k++) out16[k] = 0.0;
-  for (int b = 0; b < nb; b++)
-    for (int k = 0; k < 16; k++) out16[k] += d.partial_h[(size_t)b * 16 + k];
+  for (int k = 0; k < 16; k++) out16[k] = d.partial_h[k];
 }
 
 }  // namespace lmp_le
