@@ -786,7 +786,7 @@ bool Engine::thermo_keyword(const ThermoRow &r, const std::string &k, double &va
     val = 0.0;
     for (int c = 0; c < 6; c++) if (k == names[c]) val = r.ptensor[c];
   }
-  else if (k == "bonds") { val = (double)r.nbonds; isint = true; }
+  else if (k == "bonds") { val = (double)nbonds; isint = true; }     // (atom->nbonds at the time of the call, src/thermo.cpp:1996-1999)
   else if (k == "angles") { val = (double)nangles; isint = true; }
   else if (k == "dihedrals" || k == "impropers") { val = 0.0; isint = true; }
   else if (k == "nbuild") { val = (double)neigh_builds; isint = true; }             // :2099-2110
