@@ -262,6 +262,7 @@ void Engine::upload() {
       up(d.gmask, gm.data(), nt * sizeof(int));
       up(d.lgrank, lr.data(), nt * sizeof(int));
     }
+    d.lg_grouped = grouped && lgbit != 1;
   }
   if (langevin_members != members_before)       // the stream is cut into calls of 3 * members draws
     for (auto &f : fixes)
@@ -1172,8 +1173,8 @@ void Engine::run(long nsteps) {
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
   if (fixes_on_groups(this)) {
-    if ((world > 1 || respa_levels > 0) && md_fixes_on_groups(this))
-      throw LammpsError("MI355X engine: fix nve / fix langevin on a group other than all run on one GPU with run_style verlet");
+    if (respa_levels > 0 && md_fixes_on_groups(this))
+      throw LammpsError("MI355X engine: fix nve / fix langevin on a group other than all run with run_style verlet");
     for (auto &f : fixes)
       if (dynamic_cast<FixLangevin *>(f.get()) && f->groupbit != 1 && sortfreq > 0)
         throw LammpsError("MI355X engine: fix langevin on a group needs atom_modify sort 0 0 (its draws follow the local order)");

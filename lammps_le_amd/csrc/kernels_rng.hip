@@ -171,6 +171,12 @@ __global__ __launch_bounds__(256) void k_rng_validate(int n, const int *__restri
   rng_validate_bead(RngValidateArgs{crank, seglen, nseg, gen0, gen1, live0, live1, late}, tag[p], flags);
 }
 
+// the table a bead's draws are addressed by: canonical rank (nullptr: tag - 1), or - fix langevin on a group - the rank among
+// the group's members (non-members hold 0 there: they mark / check the first segment, which costs nothing but that segment)
+static const int *rng_rank_table(const DeviceState &d) {
+  if (d.lg_grouped) return d.lgrank;
+  return d.ident_order ? (const int *)nullptr : d.crank;
+}
 static void rng_free_batch(DeviceState &d) {
   for (int k = 0; k < 2; k++) if (d.rng_pool[k]) { (void)hipFree(d.rng_pool[k]); d.rng_pool[k] = nullptr; }
   if (d.rng_wstate) { (void)hipFree(d.rng_wstate); d.rng_wstate = nullptr; }
@@ -307,7 +313,7 @@ static void rng_gen_batch(DeviceState &d, int pool, uint64_t base_raw, bool wait
     const bool owned_only = getenv("LAMMPS_LE_TEST_RNG_NO_GHOST_MARK") != nullptr;      // (read per batch: tests share a process)
     const int m = d.n + (owned_only ? 0 : d.nghost);
     hipLaunchKernelGGL(k_rng_mark, dim3(std::max(1, (m + 255) / 256)), dim3(256), 0, d.stream, m, d.tag,
-                       d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, need);
+                       rng_rank_table(d), d.rng_seglen, need);
     HIP_CHECK(hipMemcpyAsync(d.rng_gen[pool], need, (size_t)d.rng_nseg * sizeof(int), hipMemcpyDeviceToDevice, d.stream));
     HIP_CHECK(hipEventRecord(rng_mark_event(), d.stream));
     HIP_CHECK(hipStreamWaitEvent(d.rng_stream, rng_mark_event(), 0));
@@ -333,13 +339,13 @@ int rng_segments_held(DeviceState &d) {     // segments of a call the current po
 void rng_validate_owned(DeviceState &d) {
   if (!d.rng_skip || d.rng_mode != 1 || !d.rng_gen[0] || (!d.rng_batch_raw[0] && !d.rng_batch_raw[1])) return;
   hipLaunchKernelGGL(k_rng_validate, dim3(std::max(1, (d.n + 255) / 256)), dim3(256), 0, d.stream, d.n, d.tag,
-                     d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, d.rng_nseg, d.rng_gen[0], d.rng_gen[1],
+                     rng_rank_table(d), d.rng_seglen, d.rng_nseg, d.rng_gen[0], d.rng_gen[1],
                      d.rng_batch_raw[0] ? 1 : 0, d.rng_batch_raw[1] ? 1 : 0, d.rng_late, d.flags);
 }
 RngValidateArgs rng_validate_args(DeviceState &d) {
   if (!d.rng_skip || d.rng_mode != 1 || !d.rng_gen[0] || (!d.rng_batch_raw[0] && !d.rng_batch_raw[1]))
     return RngValidateArgs{nullptr, 1, 0, nullptr, nullptr, 0, 0, nullptr};
-  return RngValidateArgs{d.ident_order ? (const int *)nullptr : d.crank, d.rng_seglen, d.rng_nseg, d.rng_gen[0], d.rng_gen[1],
+  return RngValidateArgs{rng_rank_table(d), d.rng_seglen, d.rng_nseg, d.rng_gen[0], d.rng_gen[1],
                          d.rng_batch_raw[0] ? 1 : 0, d.rng_batch_raw[1] ? 1 : 0, d.rng_late};
 }
 void rng_late_generate(DeviceState &d) {

@@ -236,6 +236,41 @@ def test_le_fixes_across_slabs_under_atom_sort(tmp_path):
     assert o0.bond_set() != o.bond_set()
 
 
+@pytest.mark.parametrize("world,case", [(2, "frozen-type"), (3, "langevin-subset"), (4, "two-nve"), (3, "zero-refused")])
+def test_md_fixes_on_groups_across_slabs(tmp_path, world, case):
+    """fix nve / fix langevin on a group in a decomposed run (unfused kernels; the thermostat's draws go by the bead's rank among
+    the members in the reference's local order, the stream segments a rank generates follow that rank table): anchors that
+    never move, a thermostat on a subset, two integrators - against the oracle on 2-4 slabs."""
+    n = 20000 if world <= 3 else 40000
+    types = 1 + (np.arange(n) % 7 == 0).astype(np.int32)
+    s = lattice_chain(n, nchains=2, seed=29, jitter=0.03, types=types)
+    s["mass"] = [1.0, 1.0]
+    head = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0")
+    if case == "frozen-type":
+        body = "group mobile type 1\nfix 1 mobile nve\nfix 2 mobile langevin 1.0 1.0 1.0 5544\n"
+    elif case == "langevin-subset":
+        body = "group hot id 1:%d:3 %d:%d\nfix 1 all nve\nfix 2 hot langevin 1.2 0.8 2.0 91 scale 2 2.5\n" % (n // 2, n // 2 + 100, n)
+    elif case == "two-nve":
+        body = "group lo id 1:%d\ngroup hi subtract all lo\nfix 1 lo nve\nfix 3 hi nve\nfix 2 hi langevin 0.8 0.8 1.0 313\n" % (n // 3)
+    else:
+        body = "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 99 zero yes\n"
+    script = head + body + "thermo 20\nrun 45\nrun 25\n"
+    if case == "zero-refused":
+        with pytest.raises(AssertionError, match="zero yes runs on one GPU"):
+            run_ranks_local(world, s, script, tmp_path)
+        return
+    o = run_oracle(script, s)
+    r = run_ranks_local(world, s, script, tmp_path)
+    assert np.abs(r["x"] - o.x()).max() < 1e-9
+    assert np.abs(r["v"] - o.v()).max() < 1e-8
+    assert (r["image"] == o.image()).all()
+    assert np.abs(r["thermo"][:5] - o.thermo()[:5]).max() < 1e-9
+    assert r["builds"][0] == o.neigh_builds()
+    if case == "frozen-type":
+        frozen = types == 2
+        assert np.array_equal(r["x"].reshape(n, 3)[frozen], o.x()[frozen])
+
+
 def test_respa_is_refused_when_decomposed(tmp_path):
     """run_style respa is the one-GPU slow path of unfused kernels: a decomposed run refuses it on every rank."""
     s = lattice_chain(6000, nchains=2, seed=21)
@@ -470,8 +505,8 @@ def test_aborted_communicator_refuses_further_collectives(tmp_path, monkeypatch)
         assert later[r] is not None and later[r].count("communicator aborted") == 2, later
 
 
-@pytest.mark.parametrize("ghost_margin", [True, False])
-def test_langevin_stream_segments_are_skipped_not_lost(tmp_path, monkeypatch, ghost_margin):
+@pytest.mark.parametrize("ghost_margin,grouped", [(True, False), (False, False), (False, True)])
+def test_langevin_stream_segments_are_skipped_not_lost(tmp_path, monkeypatch, ghost_margin, grouped):
     """Decomposed runs generate only the segments of the Langevin stream that hold draws of owned or ghost beads and jump
     over the rest (VERDICT r02 #2a).  Three slabs of a lattice-start chain (tags follow z, so each rank really skips most
     segments), 64 segments per call, 400 steps with ~40 rebuilds and migration: the trajectory must stay the oracle's -
@@ -480,7 +515,7 @@ def test_langevin_stream_segments_are_skipped_not_lost(tmp_path, monkeypatch, gh
     import threading
     from lammps_le_amd import lammps
     from systems import write_data
-    monkeypatch.setenv("LAMMPS_LE_RNG_SEGMENTS", "64" if ghost_margin else "200")
+    monkeypatch.setenv("LAMMPS_LE_RNG_SEGMENTS", "64" if ghost_margin else "100" if grouped else "200")   # (>= 256 draws each)
     monkeypatch.setenv("LAMMPS_LE_RNG_W", "32")          # short batches: many pool switches, markings and validations
     if not ghost_margin:
         # test hook: a batch marks the segments of OWNED beads only, so a bead that migrates in finds its draws missing and the
@@ -490,6 +525,8 @@ def test_langevin_stream_segments_are_skipped_not_lost(tmp_path, monkeypatch, gh
     s = lattice_chain(20000, nchains=2, seed=21)
     script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
         "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\nthermo 100\nrun 400\n"
+    if grouped:      # the thermostat on every other bead: segments are addressed by the rank among the group's members
+        script = script.replace("fix 2 all langevin", "group hot id 1:20000:2\nfix 2 hot langevin")
     o = run_oracle(script, s)
     world = 3
     path = os.path.join(str(tmp_path), "data.local")
@@ -517,7 +554,7 @@ def test_langevin_stream_segments_are_skipped_not_lost(tmp_path, monkeypatch, gh
         t.join()
     assert not errs, errs
     assert np.abs(out[0][0] - o.x()).max() < 1e-7 and np.abs(out[0][1] - o.v()).max() < 1e-6
-    nseg = 64 if ghost_margin else 200
+    nseg = 64 if ghost_margin else 100 if grouped else 200
     for r in range(world):
         assert out[r][3] == nseg and 0 < out[r][2] < nseg, out[r][2:]
     if not ghost_margin:

@@ -74,6 +74,9 @@ def dd_scenario(seed):
         lo = int(rng3.randint(1, n // 2))
         fixes = ["group g id %d:%d" % (lo, int(rng3.randint(lo + n // 4, n + 1)))] + [f.replace(" all ", " g ", 1) if k >= 2 else f for k, f in enumerate(fixes)]
         flavour += "+group"
+        if "sort" not in flavour and rng3.rand() < 0.5:      # the integrator and the thermostat on the group too (beads outside
+            fixes = [f.replace(" all ", " g ", 1) for f in fixes]   # it stay put; fix langevin on a group wants sort 0 0)
+            flavour += "+mdgroup"
     total = int(rng.randint(25, 60))
     cuts = sorted(set(int(c) for c in rng.randint(1, total, size=int(rng.randint(0, 3)))))
     runs, last = [], 0
