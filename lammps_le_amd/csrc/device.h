@@ -82,6 +82,7 @@ struct DeviceState {
   int apa = 0;
   int *num_angle = nullptr, *angle_type = nullptr, *angle_a1 = nullptr, *angle_a2 = nullptr, *angle_a3 = nullptr;
   double *partial_a = nullptr;     // [nblocks][8] angle energy + virial block sums
+  int lg_bit = 1;                  // the group bit of fix langevin (DeviceState::gmask)
   bool lg_grouped = false;         // fix langevin acts on a group: its draws go by lgrank (rank among the members), not crank
   double *lgsum = nullptr;         // fix langevin `zero yes`: [nred_blocks + 1][16] block sums of the random forces + their mean
   // the angle LIST of the last reneighbor as every bead sees it (NTopoAngleAll::build, src/ntopo_angle_all.cpp:37-93): an

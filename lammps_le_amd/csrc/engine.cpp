@@ -263,6 +263,7 @@ void Engine::upload() {
       up(d.lgrank, lr.data(), nt * sizeof(int));
     }
     d.lg_grouped = grouped && lgbit != 1;
+    d.lg_bit = lgbit;
   }
   if (langevin_members != members_before)       // the stream is cut into calls of 3 * members draws
     for (auto &f : fixes)
@@ -1175,9 +1176,6 @@ void Engine::run(long nsteps) {
   if (fixes_on_groups(this)) {
     if (respa_levels > 0 && md_fixes_on_groups(this))
       throw LammpsError("MI355X engine: fix nve / fix langevin on a group other than all run with run_style verlet");
-    for (auto &f : fixes)
-      if (dynamic_cast<FixLangevin *>(f.get()) && f->groupbit != 1 && sortfreq > 0)
-        throw LammpsError("MI355X engine: fix langevin on a group needs atom_modify sort 0 0 (its draws follow the local order)");
   }
   if (angles_active() && respa_levels > 0)
     throw LammpsError("MI355X engine: angle styles run with run_style verlet only");

@@ -38,6 +38,19 @@ __global__ __launch_bounds__(BLOCK) void k_sort_ranks(int n, const int *__restri
   if (r < n) crank[sorted_tags[r]] = r;
 }
 
+// fix langevin on a group: the rank of every member among the members in the new local order (its draws are handed out in
+// that order, src/fix_langevin.cpp:660-674).  flag[r] = is the bead at local rank r a member -> exclusive scan -> lgrank[tag]
+__global__ __launch_bounds__(BLOCK) void k_sort_member_flags(int n, const int *__restrict__ sorted_tags, const int *__restrict__ gmask,
+                                                             int bit, int *__restrict__ flag) {
+  int r = blockIdx.x * BLOCK + threadIdx.x;
+  if (r < n) flag[r] = (gmask[sorted_tags[r]] & bit) ? 1 : 0;
+}
+__global__ __launch_bounds__(BLOCK) void k_sort_member_ranks(int n, const int *__restrict__ sorted_tags, const int *__restrict__ flag,
+                                                             const int *__restrict__ scan, int *__restrict__ lgrank) {
+  int r = blockIdx.x * BLOCK + threadIdx.x;
+  if (r < n) lgrank[sorted_tags[r]] = flag[r] ? scan[r] : 0;
+}
+
 struct SortScratch {
   unsigned long long *keys[2] = {nullptr, nullptr};
   int *vals[2] = {nullptr, nullptr};
@@ -92,6 +105,19 @@ void launch_atom_sort(DeviceState &d, const int nb[3], const double binv[3], boo
   }
   HIP_CHECK(rocprim::radix_sort_pairs(s.temp, need, s.keys[0], s.keys[1], s.vals[0], s.vals[1], (size_t)n, 0u, (unsigned)bits, d.stream));
   hipLaunchKernelGGL(k_sort_ranks, dim3(grid), dim3(BLOCK), 0, d.stream, n, s.vals[1], d.crank);
+  if (d.lg_grouped) {      // (keys[0] / vals[0] are free again: flags and their scan)
+    int *flag = s.vals[0], *scan = reinterpret_cast<int *>(s.keys[0]);
+    hipLaunchKernelGGL(k_sort_member_flags, dim3(grid), dim3(BLOCK), 0, d.stream, n, s.vals[1], d.gmask, d.lg_bit, flag);
+    size_t need2 = 0;
+    HIP_CHECK(rocprim::exclusive_scan(nullptr, need2, flag, scan, 0, (size_t)n, rocprim::plus<int>(), d.stream));
+    if (need2 > s.temp_bytes) {
+      if (s.temp) (void)hipFree(s.temp);
+      HIP_CHECK(hipMalloc(&s.temp, need2));
+      s.temp_bytes = need2;
+    }
+    HIP_CHECK(rocprim::exclusive_scan(s.temp, need2, flag, scan, 0, (size_t)n, rocprim::plus<int>(), d.stream));
+    hipLaunchKernelGGL(k_sort_member_ranks, dim3(grid), dim3(BLOCK), 0, d.stream, n, s.vals[1], flag, scan, d.lgrank);
+  }
 }
 
 }  // namespace lmp_le

@@ -236,7 +236,8 @@ def test_le_fixes_across_slabs_under_atom_sort(tmp_path):
     assert o0.bond_set() != o.bond_set()
 
 
-@pytest.mark.parametrize("world,case", [(2, "frozen-type"), (3, "langevin-subset"), (4, "two-nve"), (3, "zero-refused")])
+@pytest.mark.parametrize("world,case", [(2, "frozen-type"), (3, "langevin-subset"), (4, "two-nve"), (3, "zero-refused"),
+                                        (3, "langevin-subset+sort")])
 def test_md_fixes_on_groups_across_slabs(tmp_path, world, case):
     """fix nve / fix langevin on a group in a decomposed run (unfused kernels; the thermostat's draws go by the bead's rank among
     the members in the reference's local order, the stream segments a rank generates follow that rank table): anchors that
@@ -248,7 +249,9 @@ def test_md_fixes_on_groups_across_slabs(tmp_path, world, case):
     head = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0")
     if case == "frozen-type":
         body = "group mobile type 1\nfix 1 mobile nve\nfix 2 mobile langevin 1.0 1.0 1.0 5544\n"
-    elif case == "langevin-subset":
+    elif case.startswith("langevin-subset"):
+        if case.endswith("sort"):
+            head = head.replace("atom_modify sort 0 0", "atom_modify sort 7 0")
         body = "group hot id 1:%d:3 %d:%d\nfix 1 all nve\nfix 2 hot langevin 1.2 0.8 2.0 91 scale 2 2.5\n" % (n // 2, n // 2 + 100, n)
     elif case == "two-nve":
         body = "group lo id 1:%d\ngroup hi subtract all lo\nfix 1 lo nve\nfix 3 hi nve\nfix 2 hi langevin 0.8 0.8 1.0 313\n" % (n // 3)

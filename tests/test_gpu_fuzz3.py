@@ -74,8 +74,8 @@ def dd_scenario(seed):
         lo = int(rng3.randint(1, n // 2))
         fixes = ["group g id %d:%d" % (lo, int(rng3.randint(lo + n // 4, n + 1)))] + [f.replace(" all ", " g ", 1) if k >= 2 else f for k, f in enumerate(fixes)]
         flavour += "+group"
-        if "sort" not in flavour and rng3.rand() < 0.5:      # the integrator and the thermostat on the group too (beads outside
-            fixes = [f.replace(" all ", " g ", 1) for f in fixes]   # it stay put; fix langevin on a group wants sort 0 0)
+        if rng3.rand() < 0.5:                                # the integrator and the thermostat on the group too (beads outside
+            fixes = [f.replace(" all ", " g ", 1) for f in fixes]   # it stay put)
             flavour += "+mdgroup"
     total = int(rng.randint(25, 60))
     cuts = sorted(set(int(c) for c in rng.randint(1, total, size=int(rng.randint(0, 3)))))
@@ -158,7 +158,7 @@ def md_scenario(seed):
     lines.append("timestep %g" % float(rng.choice([0.003, 0.005, 0.008])))
     rng4 = np.random.RandomState(41000 + seed)          # (drawn apart: the scenarios of the first MD sweep keep their seeds)
     gn = gl = "all"
-    if rng4.rand() < 0.3 and "sort 0 0" in lines[3]:    # fixes on groups (fix langevin on a group wants atom_modify sort 0 0)
+    if rng4.rand() < 0.3:                               # fixes on groups (under any atom_modify sort: the members' ranks follow it)
         kind = str(rng4.choice(["type", "id", "molecule"]))
         if kind == "type":
             lines.append("group g type %d" % int(rng4.randint(1, ntypes + 1)))

@@ -253,7 +253,7 @@ def test_fourmol_bond_known_answers(tmp_path, style, fixture):
     lmp.close()
 
 
-@pytest.mark.parametrize("case", ["frozen-type", "id-stride", "langevin-all", "two-nve", "molecule+LE"])
+@pytest.mark.parametrize("case", ["frozen-type", "id-stride", "langevin-all", "two-nve", "molecule+LE", "id-stride+sort"])
 def test_fixes_on_groups(tmp_path, case):
     """`group` (type / id ranges with stride / molecule / union / subtract) and fix nve / fix langevin on a group other than all
     (src/fix_nve.cpp:82, src/fix_langevin.cpp:661): atoms outside fix nve's group stay where they are, only the members of fix
@@ -265,7 +265,9 @@ def test_fixes_on_groups(tmp_path, case):
     head = CHAIN_SCRIPT
     if case == "frozen-type":        # every seventh bead is an anchor: neither integrated nor thermostatted
         body = "group mobile type 1\nfix 1 mobile nve\nfix 2 mobile langevin 1.0 1.0 1.0 5544\n"
-    elif case == "id-stride":
+    elif case.startswith("id-stride"):      # (+sort: Atom::sort every 5 steps - the members' ranks, which address their draws, follow it)
+        if case.endswith("sort"):
+            head = head.replace("atom_modify sort 0 0", "atom_modify sort 5 0")
         body = "group a id 1:3000:2 4000 4500:5000\ngroup b id 3001:3999\ngroup ab union a b\nfix 1 ab nve\nfix 2 ab langevin 1.0 1.2 2.0 91\n"
     elif case == "langevin-all":     # thermostat on everything, integration on a subset (forces on the others are simply unused)
         body = "group anchors type 2\ngroup mobile subtract all anchors\nfix 1 mobile nve\nfix 2 all langevin 1.0 1.0 1.0 77\n"
