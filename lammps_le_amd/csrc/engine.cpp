@@ -1080,6 +1080,7 @@ void Engine::respa_recurse(int l, bool last) {
   const int nnve = count_nve(this);
   const double triggersq = 0.25 * skin * skin;
   FixLangevin *lg = the_langevin(this);
+  const std::vector<int> nbits = nve_bits(this);                              // (fix nve on a group: the respa variants use the same mask)
   launch_flevel_copy(d, respa_flevel[l], false, false);                       // copy_flevel_f
   const TypeTables ttl = level_tables(this, respa_step[l]);
   for (int iloop = 0; iloop < respa_loop[l]; iloop++) {
@@ -1088,8 +1089,8 @@ void Engine::respa_recurse(int l, bool last) {
     for (int k = 0; k < nnve; k++) {                                         // initial_integrate_respa (src/fix_nve.cpp:145-155)
       if (l == 0) {
         const bool will_check = last_here && k == nnve - 1 && neigh_check && (ago + 1 >= neigh_delay) && ((ago + 1) % neigh_every == 0);
-        launch_initial_integrate(d, ttl, respa_step[0], triggersq, will_check);
-      } else launch_final_integrate(d, ttl);
+        launch_initial_integrate(d, ttl, respa_step[0], triggersq, will_check, nbits[k]);
+      } else launch_final_integrate(d, ttl, nbits[k]);
     }
     if (l == top)                                                            // post_integrate_respa: outermost level only
       for (auto &f : fixes) if (f->has_post_integrate) f->post_integrate();
@@ -1105,7 +1106,7 @@ void Engine::respa_recurse(int l, bool last) {
     respa_level_forces(l);
     stamp(T_PAIR);
     if (l == top && lg) langevin_post_force(this, lg, false);                // post_force_respa (src/fix_langevin.cpp:576-579)
-    for (int k = 0; k < nnve; k++) launch_final_integrate(d, ttl);           // final_integrate_respa (src/fix_nve.cpp:159-163)
+    for (int k = 0; k < nnve; k++) launch_final_integrate(d, ttl, nbits[k]); // final_integrate_respa (src/fix_nve.cpp:159-163)
     stamp(T_MODIFY);
   }
   launch_flevel_copy(d, respa_flevel[l], true, false);                        // copy_f_flevel
@@ -1173,10 +1174,6 @@ void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
-  if (fixes_on_groups(this)) {
-    if (respa_levels > 0 && md_fixes_on_groups(this))
-      throw LammpsError("MI355X engine: fix nve / fix langevin on a group other than all run with run_style verlet");
-  }
   if (angles_active() && respa_levels > 0)
     throw LammpsError("MI355X engine: angle styles run with run_style verlet only");
   for (auto &f : fixes)

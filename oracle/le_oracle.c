@@ -1696,9 +1696,10 @@ static void sum_flevel_f(leo_t *s) {                               /* :817-843: 
 }
 /* FixNVE::initial_integrate_respa / final_integrate_respa (src/fix_nve.cpp:145-163): the innermost level moves x and v,
    every other level only kicks v, each with its own level's step */
-static void nve_kick(leo_t *s, double step, int drift) {
+static void nve_kick(leo_t *s, const leo_fix *fx, double step, int drift) {
   double dtv = step, dtf = 0.5 * step * s->ftm2v;
   for (int i = 0; i < s->n; i++) {
+    if (fx->gmask && !fx->gmask[s->tag[i]]) continue;          /* (the respa variants call the plain ones: same group mask) */
     double dtfm = dtf / s->mass[s->type[i]];
     for (int d = 0; d < 3; d++) {
       s->v[3 * i + d] += dtfm * s->f[3 * i + d];
@@ -1746,7 +1747,7 @@ static int respa_recurse(leo_t *s, int l, int eflag) {              /* Respa::re
   copy_flevel_f(s, l);
   for (int iloop = 0; iloop < s->respa_loop[l]; iloop++) {
     double t0 = now();
-    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_kick(s, s->respa_step[l], l == 0);
+    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_kick(s, &s->fix[k], s->respa_step[l], l == 0);
     /* post_integrate_respa: the LE fixes act at the outermost level only (fix_extrusion.cpp:1139-1143, fix_ex_load.cpp:1283-1286,
        fix_ex_unload.cpp:694-697, MC/fix_bond_create.cpp:1249-1252, MC/fix_bond_break.cpp:693-696:
        `if (ilevel == nlevels_respa-1) post_integrate()`) */
@@ -1771,7 +1772,7 @@ static int respa_recurse(leo_t *s, int l, int eflag) {              /* Respa::re
     t0 = now();
     if (l == top)                                                   /* FixLangevin::post_force_respa (src/fix_langevin.cpp:576-579) */
       for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_LANGEVIN) langevin_post_force(s, &s->fix[k]);
-    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_kick(s, s->respa_step[l], 0);
+    for (int k = 0; k < s->nfix; k++) if (s->fix[k].kind == FIX_NVE) nve_kick(s, &s->fix[k], s->respa_step[l], 0);
     s->t_modify += now() - t0;
   }
   copy_f_flevel(s, l);

@@ -253,7 +253,7 @@ def test_fourmol_bond_known_answers(tmp_path, style, fixture):
     lmp.close()
 
 
-@pytest.mark.parametrize("case", ["frozen-type", "id-stride", "langevin-all", "two-nve", "molecule+LE", "id-stride+sort"])
+@pytest.mark.parametrize("case", ["frozen-type", "id-stride", "langevin-all", "two-nve", "molecule+LE", "id-stride+sort", "frozen-type+respa"])
 def test_fixes_on_groups(tmp_path, case):
     """`group` (type / id ranges with stride / molecule / union / subtract) and fix nve / fix langevin on a group other than all
     (src/fix_nve.cpp:82, src/fix_langevin.cpp:661): atoms outside fix nve's group stay where they are, only the members of fix
@@ -263,8 +263,10 @@ def test_fixes_on_groups(tmp_path, case):
     s = lattice_chain(n, nchains=3, seed=23, jitter=0.04, types=types)
     s["mass"] = [1.0, 1.0]
     head = CHAIN_SCRIPT
-    if case == "frozen-type":        # every seventh bead is an anchor: neither integrated nor thermostatted
+    if case.startswith("frozen-type"):   # every seventh bead is an anchor: neither integrated nor thermostatted
         body = "group mobile type 1\nfix 1 mobile nve\nfix 2 mobile langevin 1.0 1.0 1.0 5544\n"
+        if case.endswith("respa"):       # (the respa variants of fix nve use the same group mask)
+            body = "run_style respa 2 3 bond 1 pair 2\n" + body
     elif case.startswith("id-stride"):      # (+sort: Atom::sort every 5 steps - the members' ranks, which address their draws, follow it)
         if case.endswith("sort"):
             head = head.replace("atom_modify sort 0 0", "atom_modify sort 5 0")
@@ -287,7 +289,7 @@ def test_fixes_on_groups(tmp_path, case):
     for k, key in enumerate(("temp", "epair", "emol", "etotal", "press")):
         assert abs(p.get_thermo(key) - to[k]) <= 1e-9 * max(1.0, abs(to[k])), key
     assert p.stat("neigh_builds") == o.neigh_builds()
-    if case == "frozen-type":
+    if case.startswith("frozen-type"):
         frozen = types == 2
         assert np.array_equal(p.gather("x")[frozen], s["x"][frozen])
     if case == "molecule+LE":
