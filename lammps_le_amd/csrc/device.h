@@ -253,7 +253,9 @@ void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4]
 bool step_fuses_energy(const DeviceState &d, bool has_pair);   // a thermo step can be one launch of the step kernel's energy variant
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final, int groupbit = 1);
 // `zero yes`: after launch_langevin and before the draws are released - the members' mean random force off every member
-void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool identity_rank, int groupbit, long members);
+void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool identity_rank, int groupbit, long members,
+                          double *host_sum3 = nullptr);
+void launch_langevin_zero_apply(DeviceState &d, int groupbit, const double *mean3);
 void launch_final_integrate(DeviceState &d, const TypeTables &tt, int groupbit = 1);
 void launch_ke(DeviceState &d, const TypeTables &tt);
 // sum(m v_i v_j) over the owned beads, order xx yy zz xy xz yz (the kinetic part of the pressure tensor); synchronous

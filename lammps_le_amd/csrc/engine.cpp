@@ -704,7 +704,13 @@ static void langevin_post_force(Engine *e, FixLangevin *lg, bool fuse_final) {
   }
   launch_langevin(*e->dev, tt, e->dev->ident_order, fuse_final && !lg->zeroflag, lg->groupbit);
   // `zero yes`: the members' mean random force comes off every member (:752-772); block sums in block order, one total
-  if (lg->zeroflag) launch_langevin_zero(*e->dev, tt, e->dev->ident_order, lg->groupbit, e->langevin_members);
+  if (lg->zeroflag && e->world > 1) {        // decomposed: the ranks' sums are added on the host (MPI_Allreduce of fsum, :755)
+    double s3[3];
+    launch_langevin_zero(*e->dev, tt, e->dev->ident_order, lg->groupbit, e->langevin_members, s3);
+    e->comm->allreduce_host_sum(s3, 3);
+    for (int k = 0; k < 3; k++) s3[k] /= (double)e->langevin_members;
+    launch_langevin_zero_apply(*e->dev, lg->groupbit, s3);
+  } else if (lg->zeroflag) launch_langevin_zero(*e->dev, tt, e->dev->ident_order, lg->groupbit, e->langevin_members);
   rng_langevin_consumed(*e->dev);
 }
 
@@ -1176,9 +1182,6 @@ void Engine::run(long nsteps) {
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
   if (angles_active() && respa_levels > 0)
     throw LammpsError("MI355X engine: angle styles run with run_style verlet only");
-  for (auto &f : fixes)
-    if (auto *l = dynamic_cast<FixLangevin *>(f.get()))
-      if (l->zeroflag && world > 1) throw LammpsError("MI355X engine: fix langevin zero yes runs on one GPU");
   for (int a = 1; a <= nangletypes && apa > 0 && nangles > 0 && !angle_style_name.empty() && angle_style_name != "none" && angle_style_name != "zero"; a++)
     if (!angtab.style[a]) throw LammpsError("All angle coeffs are not set");
   // a run that ended in an error tore the communicator down (below); halo sequence numbers and arrival counters of the

@@ -793,8 +793,10 @@ __global__ __launch_bounds__(BLOCK) void k_langevin_zero(int n, const int *__res
   if (gmask && !(gmask[tag[p]] & groupbit)) return;
   fx[p] -= mean[0]; fy[p] -= mean[1]; fz[p] -= mean[2];
 }
-void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool ident, int groupbit, long members) {
-  int nb = (d.n + BLOCK - 1) / BLOCK;
+// `host_sum3` (decomposed runs): this rank's three sums come back to the host instead, nothing is applied; the caller adds
+// the ranks' sums and hands the mean to launch_langevin_zero_apply
+void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool ident, int groupbit, long members, double *host_sum3) {
+  int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
   const int *gm = groupbit != 1 ? d.gmask : (const int *)nullptr;
   const int *rk = groupbit != 1 ? d.lgrank : d.crank;
   if (groupbit != 1) ident = false;
@@ -804,9 +806,24 @@ void launch_langevin_zero(DeviceState &d, const TypeTables &tt, bool ident, int 
   else
     hipLaunchKernelGGL((k_langevin_fsum<false>), dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.pos, d.tag, rk, d.rng_out, tt, gm,
                        groupbit, d.lgsum);
-  hipLaunchKernelGGL(k_langevin_fsum_total, dim3(1), dim3(BLOCK), 0, d.stream, nb, 1.0 / (double)members, d.lgsum);
+  hipLaunchKernelGGL(k_langevin_fsum_total, dim3(1), dim3(BLOCK), 0, d.stream, nb, host_sum3 ? 1.0 : 1.0 / (double)members, d.lgsum);
+  if (host_sum3) {
+    HIP_CHECK(hipMemcpyAsync(d.partial_h, d.lgsum + (size_t)nb * 16, 3 * sizeof(double), hipMemcpyDeviceToHost, d.stream));
+    stream_sync(d);
+    for (int k = 0; k < 3; k++) host_sum3[k] = d.partial_h[k];
+    return;
+  }
   hipLaunchKernelGGL(k_langevin_zero, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.tag, gm, groupbit,
                      d.lgsum + (size_t)nb * 16, d.f[0], d.f[1], d.f[2]);
+}
+void launch_langevin_zero_apply(DeviceState &d, int groupbit, const double *mean3) {
+  int nb = std::max(1, (d.n + BLOCK - 1) / BLOCK);
+  const int *gm = groupbit != 1 ? d.gmask : (const int *)nullptr;
+  for (int k = 0; k < 3; k++) d.partial_h[k] = mean3[k];
+  HIP_CHECK(hipMemcpyAsync(d.lgsum + (size_t)nb * 16, d.partial_h, 3 * sizeof(double), hipMemcpyHostToDevice, d.stream));
+  hipLaunchKernelGGL(k_langevin_zero, dim3(nb), dim3(BLOCK), 0, d.stream, d.n, d.tag, gm, groupbit,
+                     d.lgsum + (size_t)nb * 16, d.f[0], d.f[1], d.f[2]);
+  stream_sync(d);          // (partial_h is reused by the next reduction)
 }
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool ident, bool fuse_final, int groupbit) {
   int nb = (d.n + BLOCK - 1) / BLOCK;

@@ -236,7 +236,7 @@ def test_le_fixes_across_slabs_under_atom_sort(tmp_path):
     assert o0.bond_set() != o.bond_set()
 
 
-@pytest.mark.parametrize("world,case", [(2, "frozen-type"), (3, "langevin-subset"), (4, "two-nve"), (3, "zero-refused"),
+@pytest.mark.parametrize("world,case", [(2, "frozen-type"), (3, "langevin-subset"), (4, "two-nve"), (3, "zero"),
                                         (3, "langevin-subset+sort")])
 def test_md_fixes_on_groups_across_slabs(tmp_path, world, case):
     """fix nve / fix langevin on a group in a decomposed run (unfused kernels; the thermostat's draws go by the bead's rank among
@@ -255,13 +255,9 @@ def test_md_fixes_on_groups_across_slabs(tmp_path, world, case):
         body = "group hot id 1:%d:3 %d:%d\nfix 1 all nve\nfix 2 hot langevin 1.2 0.8 2.0 91 scale 2 2.5\n" % (n // 2, n // 2 + 100, n)
     elif case == "two-nve":
         body = "group lo id 1:%d\ngroup hi subtract all lo\nfix 1 lo nve\nfix 3 hi nve\nfix 2 hi langevin 0.8 0.8 1.0 313\n" % (n // 3)
-    else:
-        body = "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 99 zero yes\n"
+    else:                # `zero yes`: the ranks' summed random forces are added across the slabs every step
+        body = "group hot id 1:%d:2\nfix 1 all nve\nfix 2 hot langevin 1.0 1.0 1.0 99 zero yes\n" % n
     script = head + body + "thermo 20\nrun 45\nrun 25\n"
-    if case == "zero-refused":
-        with pytest.raises(AssertionError, match="zero yes runs on one GPU"):
-            run_ranks_local(world, s, script, tmp_path)
-        return
     o = run_oracle(script, s)
     r = run_ranks_local(world, s, script, tmp_path)
     assert np.abs(r["x"] - o.x()).max() < 1e-9
