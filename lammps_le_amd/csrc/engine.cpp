@@ -1044,6 +1044,7 @@ static TypeTables level_tables(Engine *e, double step) {      // FixNVE::*_integ
 void Engine::respa_level_forces(int l) {                       // Respa::recurse, force part (:664-713): pair, then bond
   const int parts = (respa_level_pair == l ? 1 : 0) | (respa_level_bond == l ? 2 : 0);
   launch_force(*dev, bondtab, special_lj, false, pair_lj, parts);
+  if (respa_level_angle == l && angles_active()) launch_angle(*dev, angtab, false);      // (:707-710: behind the level's bonds)
 }
 void Engine::respa_setup() {                                   // Respa::setup (:369-468)
   DeviceState &d = *dev;
@@ -1180,8 +1181,6 @@ void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
   if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
-  if (angles_active() && respa_levels > 0)
-    throw LammpsError("MI355X engine: angle styles run with run_style verlet only");
   for (int a = 1; a <= nangletypes && apa > 0 && nangles > 0 && !angle_style_name.empty() && angle_style_name != "none" && angle_style_name != "zero"; a++)
     if (!angtab.style[a]) throw LammpsError("All angle coeffs are not set");
   // a run that ended in an error tore the communicator down (below); halo sequence numbers and arrival counters of the

@@ -779,6 +779,7 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
       respa_loop[nl - 1] = 1;
       respa_level_bond = lb;
       respa_level_pair = lp;
+      respa_level_angle = la;
       std::string msg = "Respa levels:\n";     // :198-214
       for (int k = 0; k < nl; k++) {
         msg += "  " + std::to_string(k + 1) + " =";

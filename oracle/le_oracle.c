@@ -86,7 +86,7 @@ struct leo {
   /* sort */
   int sortfreq; long nextsort;
   /* run_style respa (src/respa.cpp): 0 levels = run_style verlet */
-  int respa_levels, respa_loop[8], respa_level_bond, respa_level_pair;
+  int respa_levels, respa_loop[8], respa_level_bond, respa_level_pair, respa_level_angle;
   double respa_step[8];
   double *flevel[8];      /* FixRespa's per-level force arrays (src/fix_respa.cpp), kept BY TAG: immune to pbc / sort permutations */
   /* run state */
@@ -443,6 +443,14 @@ int leo_run_style_respa(leo_t *s, int nlevels, const int *loops, int level_bond,
   s->respa_level_bond = level_bond > 0 ? level_bond - 1 : 0;                      /* :169 */
   s->respa_level_pair = level_pair > 0 ? level_pair - 1 : nlevels - 1;             /* :174-175 */
   if (nlevels && s->respa_level_pair < s->respa_level_bond) return seterr(s, "Invalid order of forces within respa levels");   /* :221-224 */
+  s->respa_level_angle = s->respa_level_bond;                                      /* :172 */
+  return 0;
+}
+/* keyword `angle L` (1-based; 0 = the default, the bond level): after leo_run_style_respa.  src/respa.cpp:85-88, 172, 217-224 */
+int leo_run_style_respa_angle(leo_t *s, int level_angle) {
+  s->respa_level_angle = level_angle > 0 ? level_angle - 1 : s->respa_level_bond;
+  if (s->respa_levels && (s->respa_level_angle < s->respa_level_bond || s->respa_level_pair < s->respa_level_angle))
+    return seterr(s, "Invalid order of forces within respa levels");
   return 0;
 }
 void leo_newton_pair(leo_t *s, int on) { s->newton_pair = on; }
@@ -1713,6 +1721,7 @@ static int respa_level_forces(leo_t *s, int l, int eflag) {          /* :673-713
   if (s->respa_level_pair == l) pair_compute(s, eflag);
   s->t_pair += now() - t0; t0 = now();
   if (s->respa_level_bond == l && bond_compute(s, eflag)) return 1;
+  if (s->respa_level_angle == l && angle_compute(s, eflag)) return 1;      /* :707-710 */
   s->t_bond += now() - t0;
   return 0;
 }

@@ -89,6 +89,7 @@ void   leo_angle_virial(leo_t *s, double *out6);
 void   leo_timestep(leo_t *s, double dt);
 void   leo_neighbor(leo_t *s, double skin, int every, int delay, int check);
 void   leo_atom_sort(leo_t *s, int sortfreq);        /* atom_modify sort N 0 */
+int    leo_run_style_respa_angle(leo_t *s, int level_angle);     /* keyword `angle L` (0 = default: the bond level) */
 int    leo_run_style_respa(leo_t *s, int nlevels, const int *loops, int level_bond, int level_pair);   /* 0 levels = verlet; level args 1-based, 0 = default */
 void   leo_newton_pair(leo_t *s, int on);            /* newton on|off for pairs: which end stores a pair (visit order of ex_load) */
 void   leo_reset_timestep(leo_t *s, long step);

@@ -178,12 +178,15 @@ class Oracle:
     def newton_pair(self, on):
         self.L.leo_newton_pair(self.h, C.c_int(1 if on else 0))
 
-    def run_style_respa(self, loops, level_bond=0, level_pair=0):
+    def run_style_respa(self, loops, level_bond=0, level_pair=0, level_angle=0):
         """run_style respa N loop_1 .. loop_{N-1} [bond L] [pair L]; loops = [] selects run_style verlet again"""
         n = len(loops) + 1 if loops is not None else 0
         arr = (C.c_int * max(n, 1))(*(list(loops) + [1])) if n else (C.c_int * 1)(1)
         self.L.leo_run_style_respa.restype = C.c_int
         if self.L.leo_run_style_respa(self.h, C.c_int(n), arr, C.c_int(level_bond), C.c_int(level_pair)):
+            raise RuntimeError(self.L.leo_error(self.h).decode())
+        self.L.leo_run_style_respa_angle.restype = C.c_int
+        if n and self.L.leo_run_style_respa_angle(self.h, C.c_int(level_angle)):
             raise RuntimeError(self.L.leo_error(self.h).decode())
 
     def atom_sort(self, freq):

@@ -196,7 +196,7 @@ class OracleScript:
                 loops = [int(v) for v in a[2:1 + n]]
                 kw, k = {}, 1 + n
                 while k < len(a):
-                    if a[k] not in ("bond", "pair"):
+                    if a[k] not in ("bond", "pair", "angle"):
                         raise ValueError("oracle script: run_style respa keyword " + a[k])
                     kw["level_" + a[k]] = int(a[k + 1])
                     k += 2

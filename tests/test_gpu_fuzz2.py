@@ -97,6 +97,11 @@ def scenario(seed):
     tail = "thermo 10\n"
     if flavour == "respa":
         tail += str(rng.choice(RESPA)) + "\n"
+    rng6 = np.random.RandomState(61000 + seed)      # (drawn apart, as above)
+    if flavour == "angles" and rng6.rand() < 0.3:    # semiflexible chains under r-RESPA: the angles at the bonds' level or their own
+        tail += str(rng6.choice(["run_style respa 2 3", "run_style respa 3 2 2 bond 1 angle 2 pair 3",
+                                 "run_style respa 2 2 bond 1 angle 2 pair 2"])) + "\n"
+        flavour = "angles+respa"
     total = int(rng.randint(40, 110))
     cuts = sorted(set(int(c) for c in rng.randint(1, total, size=int(rng.randint(0, 3)))))
     runs, last = [], 0
@@ -143,7 +148,7 @@ def test_random_le_scenarios_mixed(tmp_path, seed):
         assert rp[0] == ro[0] and rp[6] == ro[15], (flavour, int(rp[0]))
         for k in range(1, 6):
             assert abs(rp[k] - ro[k]) <= 1e-6 * max(1.0, abs(ro[k])), (flavour, int(rp[0]), k)
-    if flavour == "angles":
+    if flavour.startswith("angles"):
         na, at, a1, a2, a3 = o.angle_table()
         assert (p.gather("num_angle") == na).all()
         for name, ref in (("angle_type", at), ("angle_atom1", a1), ("angle_atom2", a2), ("angle_atom3", a3)):
