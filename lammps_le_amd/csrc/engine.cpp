@@ -895,9 +895,18 @@ void Engine::iterate(long nsteps) {
   int nnve = count_nve(this);
   double triggersq = 0.25 * skin * skin;
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
-  // fix nve / fix langevin on a group other than all: the unfused kernels, which test the bead's group bits
+  // fix nve / fix langevin on a group other than all: the group variant of the fused step kernel (one fix nve, a pair style,
+  // no angle style; thermo steps and everything else take the unfused kernels, which test the bead's group bits)
   const std::vector<int> nbits = nve_bits(this);
-  if (md_fixes_on_groups(this)) fusable = false;
+  const bool grouped = md_fixes_on_groups(this);
+  int gnve = 1, glg = 1;
+  if (grouped) {
+    if (nnve == 1 && pair_lj && !angles_active() && !(lg && langevin_members == 0) && !getenv("LAMMPS_LE_NO_FUSED_GROUPS")) {
+      gnve = nbits[0];
+      glg = lg ? lg->groupbit : 1;
+    }
+    else fusable = false;
+  }
   if (lg && lg->zeroflag) fusable = false;         // (`zero yes` needs the group's summed random force before final_integrate)
   // bond morse (the reference's unit-test partner of bond hybrid, not a style of the chromatin model) lives in the
   // unfused force kernel only: its exp() would cost the fused step kernel registers every run pays for
@@ -960,10 +969,10 @@ void Engine::iterate(long nsteps) {
         // phase 1 = beads that are sent to a neighbour or read a ghost; their new positions start travelling on
         // comm_stream (ghost slots of the NEXT step) while phase 0 - the interior - is still being computed
         launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next, nullptr,
-                    nullptr, 1, false);
+                    nullptr, 1, false, false, false, gnve, glg);
         HIP_CHECK(hipEventRecord(d.ev_phase1, d.stream));
         launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
-                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, 0, false);
+                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, 0, false, false, false, gnve, glg);
         HIP_CHECK(hipStreamWaitEvent(d.comm_stream, d.ev_phase1, 0));
         dd_halo(d, *comm, d.comm_stream, d.pos_tmp, d.pos_tmp);
         HIP_CHECK(hipEventRecord(d.ev_halo, d.comm_stream));
@@ -975,7 +984,7 @@ void Engine::iterate(long nsteps) {
         //  takes them from the angle kernel)
         if (ang && !next) launch_angle(d, angtab, false, true);
         launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
-                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang);
+                    timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang, false, gnve, glg);
         if (!finish_reneighbor()) {
           // a list of the build that preceded this launch overflowed: the kernel saw the flag and stored nothing.
           // Undo the launch on the host side, grow the table, rebuild, launch again.
@@ -983,14 +992,14 @@ void Engine::iterate(long nsteps) {
           regrow_lists();
           if (ang && !next) launch_angle(d, angtab, false, true);
           launch_step(d, bondtab, special_lj, tt, lg != nullptr, next, ident, pair_lj, dt, triggersq, check_next,
-                      timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang);
+                      timed ? d.ev0[d.ev_used] : nullptr, timed ? d.ev1[d.ev_used] : nullptr, -1, true, ang, false, gnve, glg);
         }
       }
       if (timed) d.ev_used++;
       if (lg) rng_langevin_consumed(d);
       pre_integrated = next;
       stamp(T_PAIR);          // the fused kernel: pair + bond + post_force + final_integrate (+ next initial_integrate)
-    } else if (fusable && eflag && !dump_now && !ang && step_fuses_energy(d, pair_lj)) {
+    } else if (fusable && eflag && !dump_now && !ang && !grouped && step_fuses_energy(d, pair_lj)) {
       // a thermo step without dumps: the step kernel's energy variant - forces, energies, virial, post_force and
       // final_integrate in one pass; the next step starts with its own initial_integrate (thermo reads the velocities
       // of the END of this step)

@@ -596,7 +596,11 @@ __device__ __forceinline__ void bead_angles(int p, const double4 &rp, int na, co
 // (rows of 16 per block, as k_force<EFLAG> writes them), so that a step with thermo output is not a pass of k_force
 // plus a Langevin / integrate kernel.  Only for NEXT = false, one lane per bead (the velocities thermo reads are those
 // after final_integrate); the block totals travel in through `pos_next`, which a NEXT = false launch does not use.
-template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG, bool EF>
+// GRP: fix nve and / or fix langevin act on a group (`mask[i] & groupbit`, src/fix_nve.cpp:82, src/fix_langevin.cpp:661): a bead
+// outside fix nve's group keeps its position and velocity (its force is still computed - others feel it), a bead outside fix
+// langevin's group gets neither drag nor noise and draws nothing; `crank` is then the rank table the draws go by (the rank among
+// the members when the thermostat is on a group)
+template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG, bool EF, bool GRP>
 __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &bt, const Box &box, const TypeTables &tt,
                                           const double *s_tab, const double *s_bt,
                                           const int *__restrict__ tag, const int *__restrict__ crank,
@@ -606,7 +610,8 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
                                           double *__restrict__ fz, double4 *__restrict__ pos_next,
                                           const double4 *__restrict__ xhold, double dtv, double triggersq,
                                           int check, int *__restrict__ flags,
-                                          const unsigned char *__restrict__ phase, int which, double (&e)[14], double &ke) {
+                                          const unsigned char *__restrict__ phase, int which, double (&e)[14], double &ke,
+                                          const int *__restrict__ gmask, int nvebit, int lgbit) {
   int lb = logical_block(A.nblocks);
   const int sub = (LPB == 1) ? 0 : (int)(threadIdx.x % LPB);
   int p = lb * (BLOCK / LPB) + threadIdx.x / LPB;
@@ -618,14 +623,20 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
   double4 ri = A.pos[p];
   double a = vx[p], b = vy[p], c = vz[p];
   int t = 0;
-  if (LANGEVIN) t = tag[p];
+  if (LANGEVIN || GRP) t = tag[p];
   const BeadPre L = bead_preload<HAS_PAIR, LPB, AHEAD>(A, p, sub);
   double4 hold = ri;
   if (AHEAD && NEXT && check) hold = xhold[p];
   const int poisoned = flags[FLAG_NEIGH_OVERFLOW];
   // ---- level 1: the draws (by canonical rank), then - inside bead_force - the partners' positions ----
   uint32_t d0 = 0, d1 = 0, d2 = 0;
-  if (LANGEVIN && !(DIAG && (A.diag & 4))) {
+  bool m_nve = true, m_lg = true;
+  if (GRP) {
+    const int gm = gmask[t];
+    m_nve = nvebit == 1 || (gm & nvebit);
+    m_lg = lgbit == 1 || (gm & lgbit);
+  }
+  if (LANGEVIN && !(DIAG && (A.diag & 4)) && (!GRP || m_lg)) {
     int rank = IDENT ? (t - 1) : crank[t];
     d0 = draws[3 * (size_t)rank]; d1 = draws[3 * (size_t)rank + 1]; d2 = draws[3 * (size_t)rank + 2];
   }
@@ -645,7 +656,7 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
     bead_angles<false>(p, ri, reinterpret_cast<const int *>(fy)[p], reinterpret_cast<const int4 *>(fx), A.npad, A.pos, box, at, f0, f1, f2, acc8);
   }
   const int type = (int)ri.w;
-  if (LANGEVIN) {
+  if (LANGEVIN && (!GRP || m_lg)) {
     double gamma1 = tt.g1[type], gamma2 = tt.g2[type];
     const double inv = 1.0 / 16777216.0;
     double r0 = (double)d0 * inv;
@@ -659,11 +670,13 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
   }
   if (poisoned) return;
   const double dtfm = tt.dtfm[type];
-  a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;          // final_integrate of this step
+  if (!GRP || m_nve) { a += dtfm * f0; b += dtfm * f1; c += dtfm * f2; }          // final_integrate of this step
   if (EF) ke = (a * a + b * b + c * c) * tt.mass[type];    // the kinetic energy thermo reads (k_ke's term, column 14)
   if (NEXT) {
-    a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;        // initial_integrate of the next step
-    ri.x += dtv * a; ri.y += dtv * b; ri.z += dtv * c;
+    if (!GRP || m_nve) {
+      a += dtfm * f0; b += dtfm * f1; c += dtfm * f2;        // initial_integrate of the next step
+      ri.x += dtv * a; ri.y += dtv * b; ri.z += dtv * c;
+    }
     pos_next[p] = ri;
     if (A.sendslot) {
       const int sl = A.sendslot[p];
@@ -708,7 +721,8 @@ __device__ __forceinline__ void step_body(const ForceArgs &A, const BondTable &b
   if (DIAG && (A.diag & 64)) { if (a == 1.2345e300) vx[p] = a; return; }   // diagnostic launch: v is left alone (the value is still computed)
   vx[p] = a; vy[p] = b; vz[p] = c;
 }
-template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG = false, bool EF = false>
+template <bool LANGEVIN, bool NEXT, bool IDENT, bool HAS_PAIR, int LPB, bool DIAG, bool AHEAD, bool ANG = false, bool EF = false,
+          bool GRP = false>
 __global__ __launch_bounds__(BLOCK, ((AHEAD || EF) ? 1 : STEP_WAVES_PER_SIMD)) void k_step(ForceArgs A, BondTable bt, Box box, TypeTables tt,
                                                 const int *__restrict__ tag, const int *__restrict__ crank,
                                                 const uint32_t *__restrict__ draws, double *__restrict__ vx,
@@ -717,8 +731,11 @@ __global__ __launch_bounds__(BLOCK, ((AHEAD || EF) ? 1 : STEP_WAVES_PER_SIMD)) v
                                                 double *__restrict__ fz, double4 *__restrict__ pos_next,
                                                 const double4 *__restrict__ xhold, double dtv, double triggersq,
                                                 int check, int *__restrict__ flags,
-                                                const unsigned char *__restrict__ phase, int which) {
+                                                const unsigned char *__restrict__ phase, int which,
+                                                const int *__restrict__ gmask, int nvebit, int lgbit) {
+  // (the three group arguments trail the list: instantiations without GRP never load them, their code is the one it was)
   static_assert(!EF || (!NEXT && LPB == 1), "energy variant: NEXT = false, one lane per bead");
+  static_assert(!GRP || (!IDENT && !EF && !ANG && !AHEAD && LPB == 1), "group variant: plain shape, ranks from a table");
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
   __shared__ double s_bt[(MAXTYPES + 1) * BT_W];
   fill_bond_table(bt, s_bt);
@@ -731,8 +748,9 @@ __global__ __launch_bounds__(BLOCK, ((AHEAD || EF) ? 1 : STEP_WAVES_PER_SIMD)) v
 #pragma unroll
     for (int k = 0; k < 14; k++) e[k] = 0.0;
   }
-  step_body<LANGEVIN, NEXT, IDENT, HAS_PAIR, LPB, DIAG, AHEAD, ANG, EF>(A, bt, box, tt, s_tab, s_bt, tag, crank, draws, vx, vy, vz, fx, fy, fz,
-                                                                        pos_next, xhold, dtv, triggersq, check, flags, phase, which, e, kev[0]);
+  step_body<LANGEVIN, NEXT, IDENT, HAS_PAIR, LPB, DIAG, AHEAD, ANG, EF, GRP>(A, bt, box, tt, s_tab, s_bt, tag, crank, draws, vx, vy, vz, fx, fy, fz,
+                                                                             pos_next, xhold, dtv, triggersq, check, flags, phase, which, e, kev[0],
+                                                                             gmask, nvebit, lgbit);
   if (EF) {
     const int lb = logical_block(A.nblocks);
     if (lb < A.nblocks) {
@@ -952,8 +970,10 @@ bool step_fuses_energy(const DeviceState &d, bool has_pair) {
 // fused force + Langevin + final_integrate [+ next initial_integrate]; swaps the position buffers when `next`
 void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
-                 hipEvent_t ev_stop, int which, bool swap_buffers, bool angle_forces, bool eflag) {
+                 hipEvent_t ev_stop, int which, bool swap_buffers, bool angle_forces, bool eflag, int nvebit, int lgbit) {
   ForceArgs A = force_args(d, sl);
+  const bool grp = nvebit != 1 || lgbit != 1;        // fix nve / fix langevin on a group: the GRP instantiations
+  if (grp && (angle_forces || eflag || !has_pair || !d.gmask)) throw LammpsError("internal: group variant of the fused step asked for a launch it does not cover");
   if (d.dd && next && d.sendslot && !d.sendslot_fallback) {
     A.sendslot = d.sendslot;
     if (d.fast_halo && d.direct_recv && which < 0) {
@@ -970,9 +990,9 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
     }
   }
   // lanes per bead: 4 while the launch is latency-bound (few wavefronts per SIMD), 1 once it is throughput-bound
-  const bool lpb4 = step_lpb4(d) && !angle_forces;     // (angle runs: one lane per bead, see step_fuses_angles)
+  const bool lpb4 = step_lpb4(d) && !angle_forces && !grp;     // (angle / group runs: one lane per bead, see step_fuses_angles)
   if (angle_forces && !has_pair) throw LammpsError("internal: fused angle step without a pair style");
-  const bool ahead = step_ahead(d);
+  const bool ahead = step_ahead(d) && !grp;
   if (eflag && (next || angle_forces || which >= 0 || !step_fuses_energy(d, has_pair)))
     throw LammpsError("internal: energy variant of the fused step asked for a launch it does not cover");
   // diagnostics only (LAMMPS_LE_STEP_LDS_PAD=bytes): unused dynamic LDS per workgroup, to lower the occupancy on purpose
@@ -1003,7 +1023,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 #define STPA(L, N, I, P, W, D, H, G)                                                                         \
   hipExtLaunchKernelGGL((k_step<L, N, I, P, W, D, H, G>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, ev_start, ev_stop, 0, A, bt, \
                         d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], pf0, pf1, pf2,    \
-                        d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which)
+                        d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which, (const int *)nullptr, 1, 1)
 #define STP(L, N, I, P) do { if (angle_forces) { if (ahead) STPA(L, N, I, true, 1, false, true, true); else STPA(L, N, I, true, 1, false, false, true); } \
     else if (lpb4) STPL(L, N, I, P, 4, false, true); else if (ahead) STPL(L, N, I, P, 1, false, true); else STPL(L, N, I, P, 1, false, false); } while (0)
   int key = (langevin ? 8 : 0) | (next ? 4 : 0) | (ident ? 2 : 0) | (has_pair ? 1 : 0);
@@ -1011,7 +1031,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 #define STPE(L, I)                                                                                              \
   hipExtLaunchKernelGGL((k_step<L, false, I, true, 1, false, false, false, true>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, ev_start, \
                         ev_stop, 0, A, bt, d.box, tt, d.tag, d.crank, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], d.f[2],  \
-                        reinterpret_cast<double4 *>(d.partial), d.xhold, dtv, triggersq, 0, d.flags, d.phase, which)
+                        reinterpret_cast<double4 *>(d.partial), d.xhold, dtv, triggersq, 0, d.flags, d.phase, which, (const int *)nullptr, 1, 1)
     if (langevin) { if (ident) STPE(true, true); else STPE(true, false); }
     else { if (ident) STPE(false, true); else STPE(false, false); }
 #undef STPE
@@ -1028,6 +1048,18 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
     ev_start = ev_stop = nullptr;
     STPL(true, true, true, true, 1, true, false);
     A = R; ev_start = e0; ev_stop = e1;
+  }
+  if (grp) {      // one lane per bead, ranks from a table: the draws of a thermostat on a group go by the rank among its members
+    const int *ranks = d.lg_grouped ? d.lgrank : d.crank;
+#define STPG(L, N)                                                                                              \
+  hipExtLaunchKernelGGL((k_step<L, N, false, true, 1, false, false, false, false, true>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, \
+                        ev_start, ev_stop, 0, A, bt, d.box, tt, d.tag, ranks, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], \
+                        d.f[2], d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which, d.gmask, nvebit, lgbit)
+    if (langevin) { if (next) STPG(true, true); else STPG(true, false); }
+    else { if (next) STPG(false, true); else STPG(false, false); }
+#undef STPG
+    if (next && swap_buffers) std::swap(d.pos, d.pos_tmp);
+    return;
   }
   switch (key) {
     case 0: STP(false, false, false, false); break;  case 1: STP(false, false, false, true); break;

@@ -253,8 +253,8 @@ def test_fourmol_bond_known_answers(tmp_path, style, fixture):
     lmp.close()
 
 
-@pytest.mark.parametrize("case", ["frozen-type", "id-stride", "langevin-all", "two-nve", "molecule+LE", "id-stride+sort", "frozen-type+respa"])
-def test_fixes_on_groups(tmp_path, case):
+@pytest.mark.parametrize("case", ["frozen-type", "id-stride", "langevin-all", "two-nve", "molecule+LE", "id-stride+sort", "frozen-type+respa", "frozen-type+unfused", "langevin-all+unfused"])
+def test_fixes_on_groups(tmp_path, case, monkeypatch):
     """`group` (type / id ranges with stride / molecule / union / subtract) and fix nve / fix langevin on a group other than all
     (src/fix_nve.cpp:82, src/fix_langevin.cpp:661): atoms outside fix nve's group stay where they are, only the members of fix
     langevin's group draw - three draws per member and call, handed out in local order.  Against the oracle."""
@@ -263,6 +263,9 @@ def test_fixes_on_groups(tmp_path, case):
     s = lattice_chain(n, nchains=3, seed=23, jitter=0.04, types=types)
     s["mass"] = [1.0, 1.0]
     head = CHAIN_SCRIPT
+    if case.endswith("+unfused"):        # (one fix nve + a pair style: the group variant of the fused step kernel unless switched off)
+        monkeypatch.setenv("LAMMPS_LE_NO_FUSED_GROUPS", "1")
+        case = case[:-len("+unfused")]
     if case.startswith("frozen-type"):   # every seventh bead is an anchor: neither integrated nor thermostatted
         body = "group mobile type 1\nfix 1 mobile nve\nfix 2 mobile langevin 1.0 1.0 1.0 5544\n"
         if case.endswith("respa"):       # (the respa variants of fix nve use the same group mask)
