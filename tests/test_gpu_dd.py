@@ -237,8 +237,8 @@ def test_le_fixes_across_slabs_under_atom_sort(tmp_path):
 
 
 @pytest.mark.parametrize("world,case", [(2, "frozen-type"), (3, "langevin-subset"), (4, "two-nve"), (3, "zero"),
-                                        (3, "langevin-subset+sort")])
-def test_md_fixes_on_groups_across_slabs(tmp_path, world, case):
+                                        (3, "langevin-subset+sort"), (3, "frozen-type+overlap"), (2, "frozen-type+unfused")])
+def test_md_fixes_on_groups_across_slabs(tmp_path, world, case, monkeypatch):
     """fix nve / fix langevin on a group in a decomposed run (unfused kernels; the thermostat's draws go by the bead's rank among
     the members in the reference's local order, the stream segments a rank generates follow that rank table): anchors that
     never move, a thermostat on a subset, two integrators - against the oracle on 2-4 slabs."""
@@ -247,6 +247,12 @@ def test_md_fixes_on_groups_across_slabs(tmp_path, world, case):
     s = lattice_chain(n, nchains=2, seed=29, jitter=0.03, types=types)
     s["mass"] = [1.0, 1.0]
     head = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0")
+    if case.endswith("+overlap"):        # (the group variant of the step kernel in its two-phase launches)
+        monkeypatch.setenv("LAMMPS_LE_OVERLAP", "1")
+        case = case[:-len("+overlap")]
+    if case.endswith("+unfused"):
+        monkeypatch.setenv("LAMMPS_LE_NO_FUSED_GROUPS", "1")
+        case = case[:-len("+unfused")]
     if case == "frozen-type":
         body = "group mobile type 1\nfix 1 mobile nve\nfix 2 mobile langevin 1.0 1.0 1.0 5544\n"
     elif case.startswith("langevin-subset"):
