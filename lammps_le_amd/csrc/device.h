@@ -250,6 +250,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double special_lj[4]
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start = nullptr,
                  hipEvent_t ev_stop = nullptr, int which = -1, bool swap_buffers = true, bool angle_forces = false,
                  bool eflag = false, int nvebit = 1, int lgbit = 1);    // group bits != 1: fix nve / fix langevin on a group (GRP variant)
+bool step_fuses_groups(const DeviceState &d, bool has_pair, bool angles);   // fix nve / fix langevin on groups inside the step kernel
 bool step_fuses_energy(const DeviceState &d, bool has_pair);   // a thermo step can be one launch of the step kernel's energy variant
 void launch_langevin(DeviceState &d, const TypeTables &tt, bool identity_rank, bool fuse_final, int groupbit = 1);
 // `zero yes`: after launch_langevin and before the draws are released - the members' mean random force off every member

@@ -901,7 +901,7 @@ void Engine::iterate(long nsteps) {
   const bool grouped = md_fixes_on_groups(this);
   int gnve = 1, glg = 1;
   if (grouped) {
-    if (nnve == 1 && pair_lj && !angles_active() && !(lg && langevin_members == 0) && !getenv("LAMMPS_LE_NO_FUSED_GROUPS")) {
+    if (nnve == 1 && step_fuses_groups(d, pair_lj, angles_active()) && !(lg && langevin_members == 0)) {
       gnve = nbits[0];
       glg = lg ? lg->groupbit : 1;
     }

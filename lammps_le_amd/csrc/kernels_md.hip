@@ -735,7 +735,7 @@ __global__ __launch_bounds__(BLOCK, ((AHEAD || EF) ? 1 : STEP_WAVES_PER_SIMD)) v
                                                 const int *__restrict__ gmask, int nvebit, int lgbit) {
   // (the three group arguments trail the list: instantiations without GRP never load them, their code is the one it was)
   static_assert(!EF || (!NEXT && LPB == 1), "energy variant: NEXT = false, one lane per bead");
-  static_assert(!GRP || (!IDENT && !EF && !ANG && !AHEAD && LPB == 1), "group variant: plain shape, ranks from a table");
+  static_assert(!GRP || (!IDENT && !EF && !AHEAD && LPB == 1), "group variant: plain shape, ranks from a table");
   __shared__ double s_tab[6 * (MAXTYPES + 1) * (MAXTYPES + 1)];
   __shared__ double s_bt[(MAXTYPES + 1) * BT_W];
   fill_bond_table(bt, s_bt);
@@ -967,13 +967,19 @@ bool step_fuses_energy(const DeviceState &d, bool has_pair) {
   static const bool off = getenv("LAMMPS_LE_NO_FUSED_THERMO") != nullptr;
   return has_pair && !d.dd && !step_lpb4(d) && !step_ahead(d) && !off;
 }
+// fix nve / fix langevin on groups inside the step kernel (GRP instantiations): a pair style; with an angle style only the
+// throughput shape (the look-ahead shape of small systems has no group + angle instantiation)
+bool step_fuses_groups(const DeviceState &d, bool has_pair, bool angles) {
+  static const bool off = getenv("LAMMPS_LE_NO_FUSED_GROUPS") != nullptr;
+  return has_pair && !off && !(angles && step_ahead(d));
+}
 // fused force + Langevin + final_integrate [+ next initial_integrate]; swaps the position buffers when `next`
 void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const TypeTables &tt, bool langevin,
                  bool next, bool ident, bool has_pair, double dtv, double triggersq, bool check, hipEvent_t ev_start,
                  hipEvent_t ev_stop, int which, bool swap_buffers, bool angle_forces, bool eflag, int nvebit, int lgbit) {
   ForceArgs A = force_args(d, sl);
   const bool grp = nvebit != 1 || lgbit != 1;        // fix nve / fix langevin on a group: the GRP instantiations
-  if (grp && (angle_forces || eflag || !has_pair || !d.gmask)) throw LammpsError("internal: group variant of the fused step asked for a launch it does not cover");
+  if (grp && (eflag || !has_pair || !d.gmask)) throw LammpsError("internal: group variant of the fused step asked for a launch it does not cover");
   if (d.dd && next && d.sendslot && !d.sendslot_fallback) {
     A.sendslot = d.sendslot;
     if (d.fast_halo && d.direct_recv && which < 0) {
@@ -991,6 +997,7 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   }
   // lanes per bead: 4 while the launch is latency-bound (few wavefronts per SIMD), 1 once it is throughput-bound
   const bool lpb4 = step_lpb4(d) && !angle_forces && !grp;     // (angle / group runs: one lane per bead, see step_fuses_angles)
+  if (grp && angle_forces && step_ahead(d)) throw LammpsError("internal: group variant with angles covers the throughput shape only");
   if (angle_forces && !has_pair) throw LammpsError("internal: fused angle step without a pair style");
   const bool ahead = step_ahead(d) && !grp;
   if (eflag && (next || angle_forces || which >= 0 || !step_fuses_energy(d, has_pair)))
@@ -1051,12 +1058,14 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
   }
   if (grp) {      // one lane per bead, ranks from a table: the draws of a thermostat on a group go by the rank among its members
     const int *ranks = d.lg_grouped ? d.lgrank : d.crank;
-#define STPG(L, N)                                                                                              \
-  hipExtLaunchKernelGGL((k_step<L, N, false, true, 1, false, false, false, false, true>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, \
-                        ev_start, ev_stop, 0, A, bt, d.box, tt, d.tag, ranks, d.rng_out, d.v[0], d.v[1], d.v[2], d.f[0], d.f[1], \
-                        d.f[2], d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which, d.gmask, nvebit, lgbit)
-    if (langevin) { if (next) STPG(true, true); else STPG(true, false); }
-    else { if (next) STPG(false, true); else STPG(false, false); }
+#define STPG(L, N, G)                                                                                           \
+  hipExtLaunchKernelGGL((k_step<L, N, false, true, 1, false, false, G, false, true>), dim3(grid), dim3(BLOCK), lds_pad, d.stream, \
+                        ev_start, ev_stop, 0, A, bt, d.box, tt, d.tag, ranks, d.rng_out, d.v[0], d.v[1], d.v[2], pf0, pf1, \
+                        pf2, d.pos_tmp, d.xhold, dtv, triggersq, check ? 1 : 0, d.flags, d.phase, which, d.gmask, nvebit, lgbit)
+#define STPGA(L, N) do { if (angle_forces) STPG(L, N, true); else STPG(L, N, false); } while (0)
+    if (langevin) { if (next) STPGA(true, true); else STPGA(true, false); }
+    else { if (next) STPGA(false, true); else STPGA(false, false); }
+#undef STPGA
 #undef STPG
     if (next && swap_buffers) std::swap(d.pos, d.pos_tmp);
     return;

@@ -238,3 +238,25 @@ thermo 10
     from lammps_le_amd import LammpsError
     with pytest.raises(LammpsError, match="Invalid order of forces within respa levels"):
         p.command("run_style respa 2 2 bond 2 angle 1")
+
+
+def test_semiflexible_chains_with_anchors(tmp_path):
+    """Semiflexible chains (angle cosine) with anchored beads - fix nve and fix langevin on `group mobile` - at a size that takes
+    the throughput shape of the step kernel: its group + angle instantiation (bead's group bits by tag, listed angles evaluated
+    in the kernel) against the oracle, thermo steps through the unfused kernels."""
+    n = 70000
+    s = semiflexible(n, 2, seed=12, steps=0)
+    types = 1 + (np.arange(n) % 50 == 0).astype(np.int32)
+    s["type"], s["ntypes"], s["mass"] = types, 2, [1.0, 1.0]
+    script = ANGLE_SCRIPT + ("angle_style cosine\nangle_coeff * 2.0\ngroup mobile type 1\nfix 1 mobile nve\n"
+                             "fix 2 mobile langevin 1.0 1.0 1.0 4711\nthermo 25\nrun 50\n")
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    assert relerr(p.gather("x"), o.x()) < 1e-9 and relerr(p.gather("v"), o.v()) < 1e-8
+    frozen = types == 2
+    assert np.array_equal(p.gather("x").reshape(n, 3)[frozen], o.x()[frozen])
+    hp, ho = p.thermo_history(), o.thermo_history()
+    assert len(hp) == len(ho) == 3
+    for rp, ro in zip(hp, ho):
+        for k in range(1, 6):
+            assert abs(rp[k] - ro[k]) <= 1e-8 * max(1.0, abs(ro[k])), (int(rp[0]), k)
