@@ -895,8 +895,8 @@ void Engine::iterate(long nsteps) {
   int nnve = count_nve(this);
   double triggersq = 0.25 * skin * skin;
   bool fusable = (nnve == 1) && !getenv("LAMMPS_LE_NO_FUSE");
-  // fix nve / fix langevin on a group other than all: the group variant of the fused step kernel (one fix nve, a pair style,
-  // no angle style; thermo steps and everything else take the unfused kernels, which test the bead's group bits)
+  // fix nve / fix langevin on a group other than all: the group variant of the fused step kernel (one fix nve, a pair style;
+  // thermo steps and everything else take the unfused kernels, which test the bead's group bits)
   const std::vector<int> nbits = nve_bits(this);
   const bool grouped = md_fixes_on_groups(this);
   int gnve = 1, glg = 1;
