@@ -24,11 +24,21 @@ os.environ["LAMMPS_LE_KERNEL_TIMING"] = "1"
 lmp = lammps(cmdargs=["-screen", "none"])
 for ln in script.split("\n"):
     lmp.command(ln)
+if len(sys.argv) > 3 and sys.argv[3] == "nole":          # anchors only: no loop extrusion pulling on pinned beads
+    for fid in ("loop", "loading", "unloading"):
+        lmp.command("unfix " + fid)
+    lmp.command("thermo_style one")
 lmp.command("run 3010")
 lmp.command("run 500")
-lmp.command("run %d" % steps)
+try:
+    lmp.command("run %d" % steps)
+except Exception as e:                                   # (an extruder bond stretched between pinned beads ends the run, as in the reference)
+    print(json.dumps(dict(error=str(e), step=int(lmp.get_thermo("step")), bonds=int(lmp.get_thermo("bonds")))))
+    sys.exit(1)
 loop = lmp.stat("loop_time")
 print(json.dumps(dict(beads=nbeads, steps=steps, fused=os.environ.get("LAMMPS_LE_NO_FUSED_GROUPS") is None,
                       timesteps_per_s=round(steps / loop, 1), us_per_step=round(1e6 * loop / steps, 2),
-                      k_step_us=round(1e3 * lmp.stat("pair_kernel_ms"), 2), builds=int(lmp.stat("neigh_builds")))))
+                      k_step_us=round(1e3 * lmp.stat("pair_kernel_ms"), 2), builds=int(lmp.stat("neigh_builds")),
+                      temp_all_atoms=round(lmp.get_thermo("temp"), 4), mobile_fraction=round(float((sysd["type"] == 1).mean()), 4),
+                      bonds=int(lmp.get_thermo("bonds")), fene_warnings=int(lmp.stat("fene_warnings")))))
 lmp.close()
