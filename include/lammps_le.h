@@ -32,6 +32,7 @@ double lammps_get_thermo(void *handle, const char *keyword);
 void   lammps_extract_box(void *handle, double *boxlo, double *boxhi, double *xy, double *yz, double *xz,
                           int *pflags, int *boxflag);
 int    lammps_extract_setting(void *handle, const char *keyword);
+/* names: dt ntimestep atime atimestep boxlo boxhi natoms nbonds ntypes boltz units (src/library.cpp:1230-1420) */
 void  *lammps_extract_global(void *handle, const char *name);
 
 /* per-atom data — library.h:135.  Borrowed pointers into engine memory in TAG order (row t-1 is

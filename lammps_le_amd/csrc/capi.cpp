@@ -136,7 +136,8 @@ void *lammps_extract_atom(void *handle, const char *name) {
       for (int i = 0; i < e->natoms; i++) a[i] = i + 1;
       result = a.data();
     } else if (k == "mask") {
-      auto &a = e->scratch_i["mask"]; a.assign(e->natoms, 1);
+      auto &a = e->scratch_i["mask"]; a.assign(e->natoms, 1);       // bit 0 = all; further bits = the groups in definition order
+      if ((int)e->gmask.size() == e->natoms) for (int i = 0; i < e->natoms; i++) a[i] = e->gmask[i] | 1;
       result = a.data();
     } else if (k == "image") {
       auto &a = e->scratch_i["image"]; a.resize(e->natoms);
@@ -183,7 +184,7 @@ void lammps_gather_atoms(void *handle, char *name, int type, int count, void *da
       int *out = (int *)data;
       if (k == "type" && count == 1) memcpy(out, e->type.data(), n * sizeof(int));
       else if (k == "id" && count == 1) for (int i = 0; i < n; i++) out[i] = i + 1;
-      else if (k == "mask" && count == 1) for (int i = 0; i < n; i++) out[i] = 1;
+      else if (k == "mask" && count == 1) for (int i = 0; i < n; i++) out[i] = (int)e->gmask.size() == n ? (e->gmask[i] | 1) : 1;
       else if (k == "molecule" && count == 1) memcpy(out, e->molecule.data(), n * sizeof(int));
       else if (k == "image" && count == 3) memcpy(out, e->image.data(), 3 * (size_t)n * sizeof(int));
       else if (k == "image" && count == 1)

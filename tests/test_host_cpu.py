@@ -290,6 +290,10 @@ def test_velocity_on_a_group(tmp_path, opts):
     lmp.command("velocity heavy zero linear")
     v4 = lmp.gather("v").reshape(n, 3)
     assert np.abs((m[heavy][:, None] * v4[heavy]).sum(axis=0)).max() < 1e-10 and np.array_equal(v4[~heavy], v3[~heavy])
+    # the group bits as `mask` (bit 0 = all, then the groups in definition order: heavy, odd, sel)
+    mask = lmp.gather("mask")
+    assert (mask & 1).all() and np.array_equal((mask & 2) != 0, heavy) and np.array_equal((mask & 4) != 0, odd)
+    assert np.array_equal((mask & 8) != 0, member)
     with pytest.raises(LammpsError, match="Could not find velocity group ID"):     # src/velocity.cpp:65
         lmp.command("velocity nobody create 1.0 5")
     lmp.command("group none empty")
