@@ -19,6 +19,7 @@ void dd_fast_halo_setup(DeviceState &d, Comm &comm);
 void dd_fast_halo_switch(DeviceState &d);
 unsigned dd_halo_mismatches(DeviceState &d);
 void dd_gather_positions(DeviceState &d, Comm &comm);
+void dd_gather_rows3(DeviceState &d, Comm &comm, double *table_by_tag);   // respa, decomposed: complete a by-tag [T][3] table
 void dd_gather_all(DeviceState &d, Comm &comm, std::vector<double> &rows, int &stride);
 
 static double wall() {
@@ -1114,8 +1115,15 @@ void Engine::respa_recurse(int l, bool last) {
     if (l == top && decide()) {
       const bool sort_due = sortfreq > 0 && ntimestep >= nextsort;
       stamp();
+      // decomposed: beads may change owner in this rebuild - the level tables are completed on every rank first
+      if (world > 1) for (int q = 0; q <= top; q++) dd_gather_rows3(d, *comm, respa_flevel[q]);
       reneighbor(false, sort_due);
       stamp(T_NEIGH);
+    } else if (l == 0 && world > 1) {
+      stamp();
+      halo_exchange();          // the innermost level moved the positions: ghosts follow before this level's forces
+      dd_halo_wait(d);
+      stamp(T_COMM);
     }
     if (l) respa_recurse(l - 1, last_here);
     stamp();
@@ -1189,7 +1197,6 @@ void Engine::print_timing_breakdown(long nsteps) {
 void Engine::run(long nsteps) {
   if (nsteps < 0) throw LammpsError("Invalid run command N value");
   // checks every rank fails identically are made before anything collective starts: they must not cost the communicator
-  if (respa_levels > 0 && world > 1) throw LammpsError("MI355X engine: run_style respa runs on one GPU only");
   for (int a = 1; a <= nangletypes && apa > 0 && nangles > 0 && !angle_style_name.empty() && angle_style_name != "none" && angle_style_name != "zero"; a++)
     if (!angtab.style[a]) throw LammpsError("All angle coeffs are not set");
   // a run that ended in an error tore the communicator down (below); halo sequence numbers and arrival counters of the

@@ -783,6 +783,42 @@ void dd_gather_positions(DeviceState &d, Comm &comm) {
                      d.gather_recv, d.xt, d.xht);
 }
 
+// ---- run_style respa in a decomposed run: the per-level force tables (kept by tag, engine.cpp respa_*) follow their beads ----
+// A bead that migrates at a rebuild needs its rows on the new owner.  The slow path's answer: before the rebuild every rank
+// packs (tag, f[3]) of the beads it owns, the lists are all-gathered (padded to the longest, tag 0 = padding) and every rank
+// writes all rows into its table - the table is then complete on every rank, whoever owns a bead next.
+__global__ __launch_bounds__(BLOCK) void k_dd_rows_pack(int n, int stride, const int *__restrict__ tag,
+                                                        const double *__restrict__ table, double *__restrict__ out) {
+  int p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= stride) return;
+  double *b = out + (size_t)p * 4;
+  if (p < n) {
+    const int t = tag[p];
+    const double *row = table + 3 * (size_t)t;
+    b[0] = (double)t; b[1] = row[0]; b[2] = row[1]; b[3] = row[2];
+  } else b[0] = 0.0;
+}
+__global__ __launch_bounds__(BLOCK) void k_dd_rows_scatter(long total, const double *__restrict__ in, double *__restrict__ table) {
+  long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const double *b = in + (size_t)i * 4;
+  const int t = (int)b[0];
+  if (t <= 0) return;
+  double *row = table + 3 * (size_t)t;
+  row[0] = b[1]; row[1] = b[2]; row[2] = b[3];
+}
+void dd_gather_rows3(DeviceState &d, Comm &comm, double *table_by_tag) {
+  dd_halo_wait(d);
+  const int stride = (int)comm.allreduce_host_max(d.n);
+  ensure_gather(d, (size_t)stride * 4, comm.world);
+  hipLaunchKernelGGL(k_dd_rows_pack, dim3((stride + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, d.stream, d.n, stride, d.tag, table_by_tag,
+                     d.gather_send);
+  comm.allgather(d.stream, d.gather_send, d.gather_recv, (size_t)stride * 4 * sizeof(double));
+  const long total = (long)stride * comm.world;
+  hipLaunchKernelGGL(k_dd_rows_scatter, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, total, d.gather_recv,
+                     table_by_tag);
+}
+
 // ---- what a firing of fix extrusion / ex_unload needs instead of every bead's position (canonical visit order) ----
 // The replicated kernels of these two fixes read stored coordinates only at the ends of the extruder bonds of the last
 // bond list (table 0) and, for extrusion, at their chain neighbours t - 1 / t + 1 (the beads an end can step to,

@@ -276,13 +276,35 @@ def test_md_fixes_on_groups_across_slabs(tmp_path, world, case, monkeypatch):
         assert np.array_equal(r["x"].reshape(n, 3)[frozen], o.x()[frozen])
 
 
-def test_respa_is_refused_when_decomposed(tmp_path):
-    """run_style respa is the one-GPU slow path of unfused kernels: a decomposed run refuses it on every rank."""
-    s = lattice_chain(6000, nchains=2, seed=21)
-    script = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0") + \
-        "fix 1 all nve\nrun_style respa 2 2\nrun 5\n"
-    with pytest.raises(AssertionError, match="respa runs on one GPU only"):
-        run_ranks_local(2, s, script, tmp_path)
+@pytest.mark.parametrize("world,style,le", [(2, "run_style respa 2 4", False), (3, "run_style respa 3 2 3 bond 1 pair 2", False),
+                                            (3, "run_style respa 2 3", True)])
+def test_respa_across_slabs(tmp_path, world, style, le):
+    """run_style respa in a decomposed run (the slow path of unfused kernels): ghosts follow every move of the innermost level,
+    the per-level force tables (by tag) are completed on every rank before a rebuild so that a migrating bead finds its rows
+    on the new owner; trajectory, thermo, rebuild count - and with the three LE fixes the topology - against the oracle."""
+    n = 20000 if world == 2 else 27000
+    if le:
+        n = 60000      # slab width 13.8 >= two ghost shells of 6.2
+        s = melted(n, nchains=3, seed=9, types=barrier_types(n, 17))
+        base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 6.2") \
+            .replace("bond_coeff 2 30.0 4.0 1.0 1.0", "bond_coeff 2 10.0 6.0 1.0 1.0")
+        body = LE.format(n1=20, nl=10, nu=10, neutral=1, left=2, right=3, tp=0.5, lr="4", lprob="prob 0.5 684474",
+                         uprob="prob 0.3 456456", rmax=0.5)
+    else:
+        s = lattice_chain(n, nchains=2, seed=21, jitter=0.03)
+        base = CHAIN_SCRIPT.replace("comm_modify cutoff 5.0", "comm_modify cutoff 2.0")
+        body = "fix 1 all nve\nfix 2 all langevin 1.0 1.0 1.0 904297\n"
+    script = base + body + style + "\nthermo 20\nrun 40\nrun 20\n"
+    o = run_oracle(script, s)
+    r = run_ranks_local(world, s, script, tmp_path)
+    assert np.abs(r["x"] - o.x()).max() < 1e-8
+    assert np.abs(r["v"] - o.v()).max() < 1e-7
+    assert (r["image"] == o.image()).all()
+    assert np.abs(r["thermo"][:5] - o.thermo()[:5]).max() < 1e-8
+    assert r["builds"][0] == o.neigh_builds()
+    if le:
+        assert bond_set(r["num_bond"], r["bond_type"], r["bond_atom"]) == o.bond_set()
+        assert len([b for b in o.bond_set() if b[0] == 2]) > 5
 
 
 def test_script_commands_between_runs_when_decomposed(tmp_path):
