@@ -83,7 +83,13 @@ def dd_scenario(seed):
     for c in cuts + [total]:
         runs.append(c - last)
         last = c
-    script = base + angle_lines + "\n".join(fixes) + "\nthermo 10\n" + "".join("run %d\n" % r for r in runs if r > 0)
+    respa = ""
+    if rng3.rand() < 0.15:                           # r-RESPA across slabs (with angles: at the bonds' level or their own)
+        respa = str(rng3.choice(["run_style respa 2 3", "run_style respa 3 2 2 bond 1 pair 3", "run_style respa 2 2 bond 1 pair 2"])) + "\n"
+        if "angles" in flavour and rng3.rand() < 0.5:
+            respa = "run_style respa 3 2 2 bond 1 angle 2 pair 3\n"
+        flavour += "+respa"
+    script = base + angle_lines + "\n".join(fixes) + "\nthermo 10\n" + respa + "".join("run %d\n" % r for r in runs if r > 0)
     return s, script, world, flavour
 
 
@@ -293,4 +299,5 @@ def test_random_le_scenarios_mixed_decomposed_processes(tmp_path, seed, monkeypa
         assert r["f_" + fid][0] == o.fix_vector(fid)[0] and r["f_" + fid][1] == o.fix_vector(fid)[1], (fid, flavour)
     assert np.abs(r["x"] - o.x()).max() < 1e-6, flavour
     assert r["builds"][0] == o.neigh_builds()
-    assert int(r["window_exchanges"][0]) > 0 and int(r["window_mismatches"][0]) == 0
+    assert int(r["window_mismatches"][0]) == 0
+    assert int(r["window_exchanges"][0]) > 0 or "respa" in flavour      # (r-RESPA: every halo goes through the transport)
