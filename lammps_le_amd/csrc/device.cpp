@@ -105,8 +105,8 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   for (int k = 0; k < 16; k++) dalloc(d.le_i[k], nt);
   for (int k = 0; k < 2; k++) dalloc(d.le_d[k], nt);
   dalloc(d.le_bits, 3 * (nt / 64 + 16));     // three masks: base / accepted pairs, partner below, partner above
-  dalloc(d.le_rng_state, LE_MAX_FIXES * 100);
-  dalloc(d.le_draws, nt);
+  dalloc(d.le_rng_state, (LE_MAX_FIXES + 1) * 100);      // (+ a scratch copy: chained barrier draws of fix extrusion, kernels_le.hip)
+  dalloc(d.le_draws, 2 * nt);      // (fix extrusion with chained barrier draws: up to four per listing, a listing per two beads)
   dalloc(d.le_list, 4 * nt);
   dalloc(d.le_scan, std::max(nt, (size_t)d.ncells + 2) / 1024 + 16);
 }

@@ -93,8 +93,6 @@ FixExtrusion::FixExtrusion(Engine *e, const std::vector<std::string> &arg) {
   e->say("Amount of args in loop extrusion is " + std::to_string(arg.size()) + "\n");
   if (ctcf_lr > e->ntypes) throw LammpsError("Invalid atom type in fix extrusion command");
   if (e->atom_style == "atomic") throw LammpsError("Cannot use fix extrusion with non-molecular systems");
-  if (ctcf_lr == ctcf_left || ctcf_lr == ctcf_right)
-    throw LammpsError("MI355X engine: bidirectional CTCF type must differ from the left/right CTCF types");
   need_newton_bond_off(e, style);
   rng.seed(12345);   // hard-coded 12345 + me (:98-99)
   e->say("Attention! maxspecial = " + std::to_string(e->maxspecial) + "\n");

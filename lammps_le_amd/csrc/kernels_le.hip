@@ -852,7 +852,7 @@ void launch_ex_unload(DeviceState &d, const ExUnloadParams &P, int slot) {
 }
 
 // ========================================= extrusion ==========================================
-enum { LF_VALID = 1, LF_SL = 2, LF_SR = 4, LF_DL = 8, LF_DR = 16 };
+enum { LF_VALID = 1, LF_SL = 2, LF_SR = 4, LF_DL = 8, LF_DR = 16, LF_DL2 = 32, LF_DR2 = 64 };
 enum { CASE_NONE = 0, CASE_BOTH = 1, CASE_LEFT = 2, CASE_RIGHT = 3 };
 
 // which beads head a bond-list entry of type btype (ntopo_bond_all.cpp:52-73 with newton_bond off):
@@ -900,8 +900,21 @@ __global__ __launch_bounds__(BLOCK) void k_ext_prepare(Topo tp, ExtrusionParams 
               (tyL == P.ctcf_left || tyL == P.ctcf_right || tyL == P.ctcf_lr || tyL == P.neutral);
     bool sR = (tp.num_bond[R] - bc[R] == 2) && bc[R] == 0 &&
               (tyR == P.ctcf_left || tyR == P.ctcf_right || tyR == P.ctcf_lr || tyR == P.neutral);
-    if (sL) { f |= LF_SL; if (tyL == P.ctcf_left || tyL == P.ctcf_lr) { f |= LF_DL; nd++; } }
-    if (sR) { f |= LF_SR; if (tyR == P.ctcf_right || tyR == P.ctcf_lr) { f |= LF_DR; nd++; } }
+    // can(X, blk) = .. && (type != blk || p > U()) && (type != ctcf_lr || p > U())  (fix_extrusion.cpp:413-429): one draw per
+    // true type test; a roadblock type that EQUALS the side's barrier type makes two chained draws, the second only when the
+    // first lets the extruder through (LF_D?2; the offsets of such a firing are walked serially, k_ext_chain_offsets)
+    if (sL) {
+      f |= LF_SL;
+      const int nt = (tyL == P.ctcf_left ? 1 : 0) + (tyL == P.ctcf_lr ? 1 : 0);
+      if (nt >= 1) { f |= LF_DL; nd++; }
+      if (nt == 2) { f |= LF_DL2; nd++; }
+    }
+    if (sR) {
+      f |= LF_SR;
+      const int nt = (tyR == P.ctcf_right ? 1 : 0) + (tyR == P.ctcf_lr ? 1 : 0);
+      if (nt >= 1) { f |= LF_DR; nd++; }
+      if (nt == 2) { f |= LF_DR2; nd++; }
+    }
   }
   list_l[k] = l; list_r[k] = r; list_f[k] = f; ndraw[k] = nd;
 }
@@ -921,8 +934,16 @@ __global__ __launch_bounds__(BLOCK) void k_ext_claims(int T, ExtrusionParams P, 
     int l = list_l[k], r = list_r[k], L = l - 1, R = r + 1, o = doff[k];
     const double inv = 1.0 / 16777216.0;
     bool canL = (f & LF_SL) != 0, canR = (f & LF_SR) != 0;
-    if (f & LF_DL) { if (!(P.through_prob > (double)draws[o] * inv)) canL = false; o++; }
-    if (f & LF_DR) { if (!(P.through_prob > (double)draws[o] * inv)) canR = false; }
+    if (f & LF_DL) {
+      bool pass = P.through_prob > (double)draws[o] * inv; o++;
+      if (pass && (f & LF_DL2)) { pass = P.through_prob > (double)draws[o] * inv; o++; }
+      if (!pass) canL = false;
+    }
+    if (f & LF_DR) {
+      bool pass = P.through_prob > (double)draws[o] * inv; o++;
+      if (pass && (f & LF_DR2)) { pass = P.through_prob > (double)draws[o] * inv; o++; }
+      if (!pass) canR = false;
+    }
     if (canL && canR) { c = CASE_BOTH; q = d2(xt[L], xt[R]); }
     else if (canL) { c = CASE_LEFT; q = d2(xt[L], xt[r]); }
     else if (canR) { c = CASE_RIGHT; q = d2(xt[l], xt[R]); }
@@ -931,6 +952,24 @@ __global__ __launch_bounds__(BLOCK) void k_ext_claims(int T, ExtrusionParams P, 
   }
   kcase[k] = c;
   kq[k] = q;
+}
+// chained draws (roadblock type == a side's barrier type): how many draws a listing consumes depends on its own first draw,
+// so the stream offsets are one serial walk over the listings in bond-list order - a single lane; a firing has as many
+// listings as there are extruders.  doff[k] = the listing's first draw, *total = what the firing consumed
+__global__ void k_ext_chain_offsets(ExtrusionParams P, const int *__restrict__ nlist_ptr, const int *__restrict__ list_f,
+                                    const uint32_t *__restrict__ draws, int *__restrict__ doff, int *__restrict__ total) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const double inv = 1.0 / 16777216.0;
+  const int n = *nlist_ptr;
+  int o = 0;
+  for (int k = 0; k < n; k++) {
+    const int f = list_f[k];
+    doff[k] = o;
+    if (!(f & LF_VALID)) continue;
+    if (f & LF_DL) { const bool pass = P.through_prob > (double)draws[o] * inv; o++; if (pass && (f & LF_DL2)) o++; }
+    if (f & LF_DR) { const bool pass = P.through_prob > (double)draws[o] * inv; o++; if (pass && (f & LF_DR2)) o++; }
+  }
+  *total = o;
 }
 // dc[X] as listing k saw it = min q over earlier claim events on X (strict '<' updates, fix_extrusion.cpp:436-515)
 __device__ __forceinline__ double dc_before(int T, int X, int k, const int *ev_cnt, const int *ev_k, const double *kq) {
@@ -1070,7 +1109,16 @@ void launch_extrusion(DeviceState &d, const ExtrusionParams &P, int slot) {
   hipLaunchKernelGGL(k_ext_prepare, dim3(nb), dim3(BLOCK), 0, st, tp, P, lflag, lidx, lpart, bc, list_l, list_r, list_f,
                      ndraw);
   scan_ex(d, ndraw, doff, nt, FLAG_NDRAW);    // ndraw is zero beyond the number of listings
-  launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, nt);
+  if (P.ctcf_lr == P.ctcf_left || P.ctcf_lr == P.ctcf_right) {
+    // chained draws: generate the upper bound from a COPY of the stream state, walk the listings serially for the offsets
+    // and the consumed total, then advance the real state by exactly that (the same values again)
+    uint32_t *real = d.le_rng_state + slot * 100, *scratch = d.le_rng_state + LE_MAX_FIXES * 100;
+    HIP_CHECK(hipMemcpyAsync(scratch, real, 100 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    launch_ranmars_gen(d, LE_MAX_FIXES, d.flags + FLAG_NDRAW, d.le_draws, 2 * nt);
+    hipLaunchKernelGGL(k_ext_chain_offsets, dim3(1), dim3(64), 0, st, P, d.flags + FLAG_NLIST, list_f, d.le_draws, doff,
+                       d.flags + FLAG_NDRAW);
+  }
+  launch_ranmars_gen(d, slot, d.flags + FLAG_NDRAW, d.le_draws, 2 * nt);
   hipLaunchKernelGGL(k_ext_claims, dim3(nb), dim3(BLOCK), 0, st, T, P, d.flags + FLAG_NLIST, list_l, list_r, list_f, doff,
                      d.le_draws, d.xt, kcase, kq, ev_cnt, ev_k);
   hipLaunchKernelGGL(k_ext_resolve, dim3(nb), dim3(BLOCK), 0, st, T, d.flags + FLAG_NLIST, list_l, list_r, kcase, kq,

@@ -98,6 +98,8 @@ def scenario(seed):
     if flavour == "respa":
         tail += str(rng.choice(RESPA)) + "\n"
     rng6 = np.random.RandomState(61000 + seed)      # (drawn apart, as above)
+    if lr and rng6.rand() < 0.15:                    # roadblock type = a barrier type: chained barrier draws (fix_extrusion.cpp:413-429)
+        fixes = [f.replace(" 2 4", " 2 %d" % int(rng6.choice([2, 3])), 1) if f.startswith("fix loop ") else f for f in fixes]
     if flavour == "angles" and rng6.rand() < 0.3:    # semiflexible chains under r-RESPA: the angles at the bonds' level or their own
         tail += str(rng6.choice(["run_style respa 2 3", "run_style respa 3 2 2 bond 1 angle 2 pair 3",
                                  "run_style respa 2 2 bond 1 angle 2 pair 2"])) + "\n"

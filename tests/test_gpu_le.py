@@ -96,6 +96,21 @@ def test_le_cycle_with_barriers(tmp_path, tp):
     assert len([b for b in o.bond_set() if b[0] == 2]) > 5
 
 
+@pytest.mark.parametrize("lr,tp,frac", [("2", 0.5, 0.3), ("3", 0.7, 0.3), ("2", 0.3, 0.6), ("3", 1.0, 0.15)])
+def test_roadblock_type_equal_to_a_barrier_type(tmp_path, lr, tp, frac):
+    """`ctcf_left_right` = the left (or right) barrier type: `can()` tests such a bead twice on that side - `type != blk ||
+    p > U()` and `type != ctcf_left_right || p > U()`, the second draw only when the first let the extruder through
+    (fix_extrusion.cpp:413-429) - so the number of draws a listing consumes depends on its own first draw.  Topology,
+    counters and - through the later firings of the same stream - the stream position against the oracle."""
+    n = 3000
+    s = melted(n, types=barrier_types(n, 11, frac=frac))
+    script = le_script(n1=4, nl=5, nu=9, tp=tp, lr=lr) + "run 90\n"
+    o = run_oracle(script, s)
+    p = run_product(script, s, tmp_path)
+    compare(p, o, ("loop", "loading", "unloading"))
+    assert len([b for b in o.bond_set() if b[0] == 2]) > 5
+
+
 def test_stock_bond_break_in_place_of_ex_unload(tmp_path):
     """`fix bond/break` (src/MC) = the ex_unload text firing at step % N == 0: it then acts BEFORE the extrusion step
     (N+1) and the loading (N+3) of the same cycle, on the bond list of the last reneighboring."""
