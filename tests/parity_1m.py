@@ -18,6 +18,8 @@ else:
 data = os.path.join(tempfile.mkdtemp(), "data")
 write_data(data, sysd)
 script = CHAIN_INPUT.format(data=data, n1=period, left=2, right=3, tp=0.5, lr="4", nload=period, pload=0.01, punload=0.01)
+if len(sys.argv) > 5 and sys.argv[5] == "anchors":       # the barrier beads (every 200th) neither move nor are thermostatted:
+    script = script.replace("fix 1 all nve", "group mobile type 1\nfix 1 mobile nve").replace("fix 2 all langevin", "fix 2 mobile langevin")   # k_step<.., GRP>
 lmp = lammps(cmdargs=["-screen", "none"])
 for ln in script.split("\n"):
     lmp.command(ln)
