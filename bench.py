@@ -78,6 +78,9 @@ WORKLOADS = {
     # semiflexible chain: walk1m + angle_style cosine on every backbone triple, ex_load ... atype 2 (the angle
     # kernel writes its forces right before the fused step kernel, which adds them: `roofline` is that variant of k_step)
     "walk1m_angles": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
+    # anchored beads: walk1m with fix nve / fix langevin on `group mobile type 1` - the barrier beads (every 200th) neither move
+    # nor are thermostatted; the step kernel's group variant (`roofline` is that variant; LAMMPS_LE_NO_FUSED_GROUPS=1: unfused)
+    "walk1m_anchors": (1000000, 1, 200, 1000, 1000, 0.002, 0.5, "walk", 0.05),
 }
 
 
@@ -196,6 +199,9 @@ def main():
         script = script.replace("atom_style bond", "atom_style molecular") \
             .replace("pair_style lj/cut", "angle_style cosine\nangle_coeff * 2.0\npair_style lj/cut") \
             .replace("iparam 1 1 jparam 1 1", "iparam 1 1 jparam 1 1 atype 2")
+
+    if args.workload.endswith("_anchors"):
+        script = script.replace("fix 1 all nve", "group mobile type 1\nfix 1 mobile nve").replace("fix 2 all langevin", "fix 2 mobile langevin")
 
     lmp = lammps(cmdargs=["-screen", "none"])
     rccl_nranks = 1
