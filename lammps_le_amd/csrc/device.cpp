@@ -56,6 +56,8 @@ void dev_alloc(DeviceState &d, int n, int maxtag, int ntypes, int bpa, int maxsp
   dalloc(d.nspecial, nt * 3); dalloc(d.special, nt * (size_t)maxspecial);
   dalloc(d.num_bond0, nt); dalloc(d.bond_type0, nt * bpa); dalloc(d.bond_atom0, nt * bpa);
   if (d.apa > 0) {
+    dalloc(d.angle_pack, (size_t)ANGLE_PACK_COLS * nt * 4);
+    d.angle_pack_dirty = true;
     dalloc(d.num_angle, nt); dalloc(d.angle_type, nt * d.apa); dalloc(d.angle_a1, nt * d.apa); dalloc(d.angle_a2, nt * d.apa);
     dalloc(d.angle_a3, nt * d.apa);
     d.ecap = d.apa + 8;
@@ -130,7 +132,7 @@ void dev_free(DeviceState &d) {
   dfree(d.gmask); dfree(d.lgrank);
   dfree(d.cell_of); dfree(d.cell_count); dfree(d.cell_start); dfree(d.cell_fill); dfree(d.scan_tmp); dfree(d.perm);
   dfree(d.neigh); dfree(d.numneigh); dfree(d.bpart); dfree(d.bshift); dfree(d.pairtab); dfree(d.partial); dfree(d.partial_a); dfree(d.lgsum);
-  dfree(d.num_angle); dfree(d.angle_type); dfree(d.angle_a1); dfree(d.angle_a2); dfree(d.angle_a3); dfree(d.eff_n); dfree(d.eff_rec);
+  dfree(d.angle_pack); dfree(d.num_angle); dfree(d.angle_type); dfree(d.angle_a1); dfree(d.angle_a2); dfree(d.angle_a3); dfree(d.eff_n); dfree(d.eff_rec);
   if (d.partial_h) (void)hipHostFree(d.partial_h);
   d.partial_h = nullptr;
   dfree(d.flags);

@@ -54,6 +54,7 @@ enum DevErr {
 // cover 2.25 instead of 3 cutoffs -> 25 % fewer candidates in the list build.
 constexpr int CELL_XSPLIT = 4;
 
+constexpr int ANGLE_PACK_COLS = 4;
 constexpr int LE_MAX_FIXES = 16;   // extrusion / ex_load / ex_unload / bond/create / bond/break instances with a device RanMars state each
 
 struct DeviceState {
@@ -101,6 +102,10 @@ struct DeviceState {
   int *bond_pack = nullptr;
   int bond_pack_stride = 0;
   bool bond_pack_dirty = true;
+  // the first ANGLE_PACK_COLS stored angles of every atom as (type, a1, a2, a3) records, column-major by tag: what the angle
+  // listing of every rebuild reads instead of three tables of stride apa (rebuilt after the angle tables changed)
+  int *angle_pack = nullptr;
+  bool angle_pack_dirty = true;
   // the same records by PHYSICAL index (one GPU, permute pass writes the bond-partner table): moved with the beads by
   // k_permute, so that the table pass reads them next to the bead's other data instead of gathering them by tag
   int *bond_pack_p[2] = {nullptr, nullptr};

@@ -1239,6 +1239,7 @@ void Engine::run(long nsteps) {
   for (auto &f : fixes) if (f->force_reneighbor) dev->le_snapshot = 1;
   dev->topo_dirty = true;     // bond tables may have been edited between runs
   dev->bond_pack_dirty = true;
+  dev->angle_pack_dirty = true;
   beginstep = ntimestep;
   endstep = ntimestep + nsteps;
   atimestep = ntimestep;            // Integrate::init (src/integrate.cpp:48)

@@ -259,6 +259,7 @@ void FixExtrusion::post_integrate() {
   launch_extrusion(d, p, slot);
   d.topo_dirty = true;
   d.bond_pack_dirty = true;
+  d.angle_pack_dirty = true;
   sync_flags(d);
   check_le_error(d, "extrusion");
   last_break = d.flags_h[FLAG_COUNT_A];
@@ -289,6 +290,7 @@ void FixExLoad::post_integrate() {
   }
   d.topo_dirty = true;
   d.bond_pack_dirty = true;
+  d.angle_pack_dirty = true;
   sync_flags(d);
   check_le_error(d, style.c_str());
   last_create = d.flags_h[FLAG_COUNT_A];
@@ -312,6 +314,7 @@ void FixExUnload::post_integrate() {
   launch_ex_unload(d, p, slot);
   d.topo_dirty = true;
   d.bond_pack_dirty = true;
+  d.angle_pack_dirty = true;
   sync_flags(d);
   check_le_error(d, style.c_str());
   last_break = d.flags_h[FLAG_COUNT_A];

@@ -1104,19 +1104,74 @@ void launch_step(DeviceState &d, const BondTable &bt, const double sl[4], const 
 // its record goes to those atoms only; the atoms on the other side are moved by the listings of their own copies.  With all
 // copies in place that adds up to one evaluation per atom, with copies out of step it is what the reference computes
 // (found by the mixed sweep, tests/test_gpu_fuzz2.py seeds 17, 74, 125).
+// (type, a1, a2, a3) of the first ANGLE_PACK_COLS stored angles of every atom, column-major by tag (empty slots: type 0)
+__global__ __launch_bounds__(BLOCK) void k_angle_pack(int T, int apa, int stride, const int *__restrict__ num_angle,
+                                                      const int *__restrict__ angle_type, const int *__restrict__ a1,
+                                                      const int *__restrict__ a2, const int *__restrict__ a3, int4 *__restrict__ pack) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x + 1;
+  if (i > T) return;
+  const int na = num_angle[i];
+  for (int m = 0; m < ANGLE_PACK_COLS; m++) {
+    const size_t c = (size_t)i * apa + m;
+    pack[(size_t)m * stride + i] = m < na ? make_int4(angle_type[c], a1[c], a2[c], a3[c]) : make_int4(0, 0, 0, 0);
+  }
+}
 __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, int npad, const int *__restrict__ crank,
                                                       const int *__restrict__ map, const float4 *__restrict__ pos, Box box, int n_owned,
                                                       const int *__restrict__ num_angle, const int *__restrict__ angle_type,
                                                       const int *__restrict__ a1, const int *__restrict__ a2,
                                                       const int *__restrict__ a3, int *__restrict__ eff_n,
-                                                      int4 *__restrict__ eff_rec, int *__restrict__ flags) {
+                                                      int4 *__restrict__ eff_rec, int *__restrict__ flags,
+                                                      const int4 *__restrict__ pack, int pack_stride) {
   const int i = blockIdx.x * BLOCK + threadIdx.x + 1;
   if (i > T) return;
   const int na = num_angle[i];
   const int li = crank ? crank[i] : i;
   for (int m = 0; m < na; m++) {
     const size_t c = (size_t)i * apa + m;
-    const int t[3] = {a1[c], a2[c], a3[c]};
+    // (the first columns come from the packed records - coalesced 16-byte loads -, the tables of stride apa only beyond them)
+    int4 src;
+    if (m < ANGLE_PACK_COLS) src = pack[(size_t)m * pack_stride + i];
+    else src = make_int4(angle_type[c], a1[c], a2[c], a3[c]);
+    const int t[3] = {src.y, src.z, src.w};
+    if (n_owned < 0) {
+      // one GPU: two of an angle's three stored copies are not listed (the listing atom must have the lowest local index among
+      // the atoms on its side), and which ones is known from the ranks alone unless an atom with a lower rank sits across a
+      // periodic face - so only those atoms are looked up before the copy is dropped (the kernel is bound by its gathers)
+      int rk[3];
+      bool lower = false;
+      for (int q = 0; q < 3; q++) { rk[q] = crank ? crank[t[q]] : t[q]; lower = lower || li > rk[q]; }
+      const int pi = map[i];
+      if (pi < 0) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
+      const float4 ri = pos[pi];
+      int p[3] = {-1, -1, -1};
+      bool ghost[3] = {false, false, false}, known[3] = {false, false, false}, listed = true;
+      auto look = [&](int q) {
+        p[q] = (t[q] == i) ? pi : map[t[q]];
+        known[q] = true;
+        if (p[q] < 0) return false;
+        const float4 rq = pos[p[q]];
+        ghost[q] = fabs((double)ri.x - (double)rq.x) > box.half[0] || fabs((double)ri.y - (double)rq.y) > box.half[1] ||
+                   fabs((double)ri.z - (double)rq.z) > box.half[2];
+        return true;
+      };
+      bool missing = false;
+      if (lower)
+        for (int q = 0; q < 3 && listed; q++)
+          if (li > rk[q]) { if (!look(q)) { missing = true; break; } listed = ghost[q]; }
+      if (missing) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
+      if (!listed) continue;
+      for (int q = 0; q < 3; q++) if (!known[q] && !look(q)) missing = true;
+      if (missing) { flags[FLAG_ERROR] = ERR_BOND_MISSING; continue; }
+      const int4 rec = make_int4(src.x, p[0], p[1], p[2]);
+      for (int q = 0; q < 3; q++) {
+        if (ghost[q]) continue;
+        const int slot = atomicAdd(&eff_n[p[q]], 1);
+        if (slot >= ecap) { flags[FLAG_ERROR] = ERR_ANGLES; continue; }
+        eff_rec[(size_t)slot * npad + p[q]] = rec;
+      }
+      continue;
+    }
     // records hold PHYSICAL indices (this list lives until the next reneighbor, like the indices) and sit column-major by
     // the bead's own index: the force kernel reads them coalesced and gathers positions without a tag -> index lookup
     const int p[3] = {map[t[0]], map[t[1]], map[t[2]]};
@@ -1136,7 +1191,7 @@ __global__ __launch_bounds__(BLOCK) void k_angle_list(int T, int apa, int ecap, 
       listed = listed && (ghost[q] || li <= (crank ? crank[t[q]] : t[q]));
     }
     if (!listed) continue;
-    const int4 rec = make_int4(angle_type[c], p[0], p[1], p[2]);
+    const int4 rec = make_int4(src.x, p[0], p[1], p[2]);
     for (int q = 0; q < 3; q++) {
       if (ghost[q] || (n_owned >= 0 && p[q] >= n_owned)) continue;
       const int slot = atomicAdd(&eff_n[p[q]], 1);
@@ -1174,8 +1229,15 @@ void launch_angle_list(DeviceState &d) {
   if (d.apa <= 0) return;
   const int T = d.maxtag, nb = std::max(1, (T + BLOCK - 1) / BLOCK);
   HIP_CHECK(hipMemsetAsync(d.eff_n, 0, (size_t)d.npad * sizeof(int), d.stream));
+  const int pack_stride = T + 2;
+  if (d.angle_pack_dirty) {       // (the angle tables change at an LE firing with `atype` / angle breaking, not at a rebuild)
+    hipLaunchKernelGGL(k_angle_pack, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, pack_stride, d.num_angle, d.angle_type, d.angle_a1,
+                       d.angle_a2, d.angle_a3, (int4 *)d.angle_pack);
+    d.angle_pack_dirty = false;
+  }
   hipLaunchKernelGGL(k_angle_list, dim3(nb), dim3(BLOCK), 0, d.stream, T, d.apa, d.ecap, d.npad, d.ident_order ? (const int *)nullptr : d.crank,
-                     d.map, d.posf, d.box, d.dd ? d.n : -1, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags);
+                     d.map, d.posf, d.box, d.dd ? d.n : -1, d.num_angle, d.angle_type, d.angle_a1, d.angle_a2, d.angle_a3, d.eff_n, (int4 *)d.eff_rec, d.flags,
+                     (const int4 *)d.angle_pack, pack_stride);
   hipLaunchKernelGGL(k_angle_sort, dim3(std::max(1, (d.n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, d.stream, d.n, d.ecap, d.npad, d.eff_n,
                      (int4 *)d.eff_rec);
 }
