@@ -327,6 +327,18 @@ class Engine {
   int langevin_members = 0;                        // atoms in fix langevin's group (its draws per call / 3); set by upload()
   int group_bit(const std::string &name) const;    // 1 << index, or 0 if there is no such group
   void group_command(std::vector<std::string> &arg);
+  // `region ID block | sphere | cylinder | union | intersect ... [side in|out] [units box|lattice]` (src/region*.cpp): static
+  // regions, for `group ID region R` and `set region R ...`.  match = !(inside ^ interior), closed boundaries
+  struct Region {
+    std::string style;
+    bool interior = true;
+    double p[6] = {0, 0, 0, 0, 0, 0};      // block: xlo xhi ylo yhi zlo zhi; sphere: x y z r; cylinder: c1 c2 r lo hi
+    char axis = 'z';
+    std::vector<std::string> sub;          // union / intersect
+  };
+  std::map<std::string, Region> regions;
+  void region_command(std::vector<std::string> &arg);
+  bool region_match(const Region &r, double x, double y, double z) const;
   void set_command(std::vector<std::string> &arg);   // set atom|type|mol|group ... (src/set.cpp)   // velocity all create|set|scale|zero (src/velocity.cpp)
   // ---- dumps (src/dump_custom.cpp, dump_atom.cpp, dump_local.cpp; compute_property_local.cpp) ----
   struct Dump {

@@ -871,6 +871,8 @@ void Engine::execute(const std::string &cmd, std::vector<std::string> &arg) {
              cmd == "suffix" || cmd == "velocity_zero") {
   } else if (cmd == "group") {
     group_command(arg);
+  } else if (cmd == "region") {
+    region_command(arg);
   } else if (cmd == "clear") {
     throw LammpsError("MI355X engine: clear is not supported; open a new instance");
   } else {
@@ -1354,13 +1356,110 @@ int Engine::group_bit(const std::string &name) const {
   for (size_t k = 0; k < group_names.size(); k++) if (group_names[k] == name) return 1 << k;
   return 0;
 }
+// region ID style args [side in|out] [units box|lattice]   (src/region.cpp:305-420 options, region_block.cpp:29-100,
+// region_sphere.cpp:29-75, region_cylinder.cpp:31-140, region_union.cpp, region_intersect.cpp).  Static regions only: `move`,
+// `rotate`, `open` and variable parameters are refused.  `units lattice` (the default) scales by the lattice spacing, which is
+// 1.0 without a `lattice` command (this engine has none): the numbers are box units either way.
+void Engine::region_command(std::vector<std::string> &arg) {
+  if (arg.size() < 2) throw LammpsError("Illegal region command");
+  const std::string &id = arg[0];
+  if (arg[1] == "delete") {
+    if (arg.size() != 2) throw LammpsError("Illegal region command");
+    if (!regions.erase(id)) throw LammpsError("Delete region ID does not exist");
+    return;
+  }
+  if (regions.count(id)) throw LammpsError("Reuse of region ID");
+  Region r;
+  r.style = arg[1];
+  const double BIG = 1.0e20;
+  auto bound = [&](const std::string &t, int dim, bool upper) {      // INF / EDGE (region_block.cpp:35-90)
+    if (t == "INF" || t == "EDGE") {
+      if (!box_exist) throw LammpsError("Cannot use region INF or EDGE when box does not exist");
+      if (t == "INF") return upper ? BIG : -BIG;
+      return upper ? box.hi[dim] : box.lo[dim];
+    }
+    if (t.rfind("v_", 0) == 0) throw LammpsError("MI355X engine: region parameters as variables are not supported");
+    return numeric(t);
+  };
+  size_t k = 2;
+  auto need = [&](size_t n) { if (k + n > arg.size()) throw LammpsError("Illegal region " + r.style + " command"); };
+  if (r.style == "block") {
+    need(6);
+    for (int q = 0; q < 6; q++) r.p[q] = bound(arg[k + q], q / 2, q & 1);
+    k += 6;
+    if (r.p[0] > r.p[1] || r.p[2] > r.p[3] || r.p[4] > r.p[5]) throw LammpsError("Illegal region block command");
+  } else if (r.style == "sphere") {
+    need(4);
+    for (int q = 0; q < 4; q++) { if (arg[k + q].rfind("v_", 0) == 0) throw LammpsError("MI355X engine: region parameters as variables are not supported"); r.p[q] = numeric(arg[k + q]); }
+    k += 4;
+    if (r.p[3] < 0.0) throw LammpsError("Illegal region sphere command");
+  } else if (r.style == "cylinder") {
+    need(6);
+    if (arg[k] != "x" && arg[k] != "y" && arg[k] != "z") throw LammpsError("Illegal region cylinder command");
+    r.axis = arg[k][0];
+    for (int q = 0; q < 3; q++) { if (arg[k + 1 + q].rfind("v_", 0) == 0) throw LammpsError("MI355X engine: region parameters as variables are not supported"); r.p[q] = numeric(arg[k + 1 + q]); }
+    const int dim = r.axis - 'x';
+    r.p[3] = bound(arg[k + 4], dim, false);
+    r.p[4] = bound(arg[k + 5], dim, true);
+    k += 6;
+    if (r.p[2] <= 0.0) throw LammpsError("Illegal region cylinder command");
+    if (r.p[3] > r.p[4]) throw LammpsError("Illegal region cylinder command");
+  } else if (r.style == "union" || r.style == "intersect") {
+    need(1);
+    const int n = inumeric(arg[k]);
+    if (n < 2) throw LammpsError("Illegal region command");
+    k++;
+    need((size_t)n);
+    for (int q = 0; q < n; q++) {
+      if (!regions.count(arg[k + q])) throw LammpsError("Region " + r.style + " region ID does not exist");
+      r.sub.push_back(arg[k + q]);
+    }
+    k += n;
+  } else throw LammpsError("Unknown region style " + r.style);
+  while (k < arg.size()) {
+    if (k + 2 > arg.size()) throw LammpsError("Illegal region command");
+    if (arg[k] == "side") {
+      if (arg[k + 1] == "in") r.interior = true;
+      else if (arg[k + 1] == "out") r.interior = false;
+      else throw LammpsError("Illegal region command");
+    } else if (arg[k] == "units") {
+      if (arg[k + 1] != "box" && arg[k + 1] != "lattice") throw LammpsError("Illegal region command");
+    } else if (arg[k] == "move" || arg[k] == "rotate" || arg[k] == "open")
+      throw LammpsError("MI355X engine: region keyword " + arg[k] + " is not supported (static regions only)");
+    else throw LammpsError("Illegal region command");
+    k += 2;
+  }
+  regions[id] = r;
+}
+bool Engine::region_match(const Region &r, double px, double py, double pz) const {
+  bool inside;
+  if (r.style == "block") inside = px >= r.p[0] && px <= r.p[1] && py >= r.p[2] && py <= r.p[3] && pz >= r.p[4] && pz <= r.p[5];
+  else if (r.style == "sphere") {
+    const double dx = px - r.p[0], dy = py - r.p[1], dz = pz - r.p[2];
+    inside = sqrt(dx * dx + dy * dy + dz * dz) <= r.p[3];                      // region_sphere.cpp:134-143
+  } else if (r.style == "cylinder") {
+    const double a = r.axis == 'x' ? px : r.axis == 'y' ? py : pz;
+    const double d1 = (r.axis == 'x' ? py : px) - r.p[0], d2 = (r.axis == 'z' ? py : pz) - r.p[1];
+    inside = sqrt(d1 * d1 + d2 * d2) <= r.p[2] && a >= r.p[3] && a <= r.p[4];  // region_cylinder.cpp:251-277
+  } else {
+    // union: inside any sub-region's match; intersect: all of them (region_union.cpp / region_intersect.cpp ::inside)
+    inside = r.style == "intersect";
+    for (auto &name : r.sub) {
+      auto it = regions.find(name);
+      if (it == regions.end()) throw LammpsError("Region " + r.style + " region ID does not exist");      // (deleted since)
+      const bool m = region_match(it->second, px, py, pz);
+      if (r.style == "union") inside = inside || m; else inside = inside && m;
+    }
+  }
+  return !(inside ^ r.interior);
+}
+
 void Engine::group_command(std::vector<std::string> &arg) {
   if (!box_exist) throw LammpsError("Group command before simulation box is defined");
   if (arg.size() < 2) throw LammpsError("Illegal group command");
   const std::string &name = arg[0], &style = arg[1];
   if (name == "all") throw LammpsError("Cannot change the group all");     // (src/group.cpp: "all" is fixed)
-  if (style == "delete" || style == "clear" || style == "region" || style == "variable" || style == "dynamic" || style == "static" ||
-      style == "include")
+  if (style == "delete" || style == "clear" || style == "variable" || style == "dynamic" || style == "static" || style == "include")
     throw LammpsError("MI355X engine: group style " + style + " is not supported");
   download();
   if (gmask.empty()) gmask.assign(natoms, 1);
@@ -1412,6 +1511,12 @@ void Engine::group_command(std::vector<std::string> &arg) {
       else { in = gmask[i] & bits[0]; for (size_t k = 1; k < bits.size(); k++) in = in && !(gmask[i] & bits[k]); }
       if (in) gmask[i] |= bit;       // (an existing group is added to, as in the reference)
     }
+  } else if (style == "region") {      // the atoms inside the region NOW (stored coordinates): src/group.cpp:174-186
+    if (arg.size() != 3) throw LammpsError("Illegal group command");
+    auto it = regions.find(arg[2]);
+    if (it == regions.end()) throw LammpsError("Group region ID does not exist");
+    for (int i = 0; i < natoms; i++)
+      if (region_match(it->second, x[3 * (size_t)i], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2])) gmask[i] |= bit;
   } else if (style == "empty") {
   } else throw LammpsError("Illegal group command");
   dev_current = false;               // the masks travel with the next upload
@@ -1442,8 +1547,11 @@ void Engine::set_command(std::vector<std::string> &arg) {
     const int bit = group_bit(id);
     if (!bit) throw LammpsError("Could not find set group ID");
     for (int i = 0; i < natoms; i++) select[i] = bit == 1 || (!gmask.empty() && (gmask[i] & bit));
-  } else if (style == "region") throw LammpsError("MI355X engine: set region is not supported");
-  else throw LammpsError("Illegal set command");
+  } else if (style == "region") {      // src/set.cpp:671-678
+    auto it = regions.find(id);
+    if (it == regions.end()) throw LammpsError("Set region ID does not exist");
+    for (int i = 0; i < natoms; i++) select[i] = region_match(it->second, x[3 * (size_t)i], x[3 * (size_t)i + 1], x[3 * (size_t)i + 2]);
+  } else throw LammpsError("Illegal set command");
   auto need = [&](size_t k, size_t n) { if (k + n > arg.size()) throw LammpsError("Illegal set command"); };
   auto fnum = [&](const std::string &t) {
     if (t.rfind("v_", 0) == 0) return variable_value(t.substr(2));

@@ -301,6 +301,44 @@ def test_velocity_on_a_group(tmp_path, opts):
         lmp.command("velocity none zero linear")
 
 
+def test_regions_select_atoms(tmp_path):
+    """`region ID block | sphere | cylinder | union | intersect ... [side in|out]` (src/region*.cpp: closed boundaries, match =
+    !(inside ^ interior)), `group ID region R` (the atoms inside NOW, src/group.cpp:174-186) and `set region R ...`
+    (src/set.cpp:671-678) against numpy."""
+    from lammps_le_amd import LammpsError
+    n = 900
+    lmp, s, m = _velocity_case(tmp_path, n, "region b block 2.0 6.0 INF INF EDGE 5.5")
+    x = lmp.gather("x").reshape(n, 3)
+    lo, hi = s["box"][:, 0], s["box"][:, 1]
+    c = 0.5 * (lo + hi)
+    lmp.command("region s sphere %g %g %g 3.5 units box" % tuple(c))
+    lmp.command("region so sphere %g %g %g 3.5 side out" % tuple(c))
+    lmp.command("region cy cylinder y %g %g 2.5 %g EDGE" % (c[0], c[2], c[1]))
+    lmp.command("region u union 2 b s")
+    lmp.command("region it intersect 3 b s cy")
+    in_b = (x[:, 0] >= 2.0) & (x[:, 0] <= 6.0) & (x[:, 2] >= lo[2]) & (x[:, 2] <= 5.5)
+    in_s = np.sqrt(((x - c) ** 2).sum(axis=1)) <= 3.5
+    in_cy = (np.sqrt((x[:, 0] - c[0]) ** 2 + (x[:, 2] - c[2]) ** 2) <= 2.5) & (x[:, 1] >= c[1]) & (x[:, 1] <= hi[1])
+    want = dict(b=in_b, s=in_s, so=~in_s, cy=in_cy, u=in_b | in_s, it=in_b & in_s & in_cy)
+    for k, (name, sel) in enumerate(want.items()):
+        assert 0 < sel.sum() < n, name
+        lmp.command("group g_%s region %s" % (name, name))
+        mask = lmp.gather("mask")
+        assert np.array_equal((mask & (2 << k)) != 0, sel), name
+    types0 = lmp.gather("type").copy()
+    lmp.command("set region it type 2")
+    t = lmp.gather("type")
+    assert (t[want["it"]] == 2).all() and np.array_equal(t[~want["it"]], types0[~want["it"]])
+    lmp.command("region b delete")
+    for bad, msg in (("region s sphere 0 0 0 1", "Reuse of region ID"), ("region q block 1 0 0 1 0 1", "Illegal region block command"),
+                     ("region q cone z 0 0 1 2 0 1", "Unknown region style"), ("group h region b", "Group region ID does not exist"),
+                     ("set region nowhere type 1", "Set region ID does not exist"), ("region q sphere 0 0 0 1 move v_a NULL NULL", "not supported"),
+                     ("region q union 2 s nowhere", "region ID does not exist"), ("region b delete", "Delete region ID does not exist"),
+                     ("group h region u", "region ID does not exist")):
+        with pytest.raises(LammpsError, match=msg):
+            lmp.command(bad)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # script control flow: variable index / loop / equal, next, label, jump, if, include, $(...) (src/input.cpp, variable.cpp)
 def test_script_control_flow(tmp_path):
