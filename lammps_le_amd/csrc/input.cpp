@@ -1459,15 +1459,33 @@ void Engine::group_command(std::vector<std::string> &arg) {
   if (arg.size() < 2) throw LammpsError("Illegal group command");
   const std::string &name = arg[0], &style = arg[1];
   if (name == "all") throw LammpsError("Cannot change the group all");     // (src/group.cpp: "all" is fixed)
-  if (style == "delete" || style == "clear" || style == "variable" || style == "dynamic" || style == "static" || style == "include")
+  if (style == "variable" || style == "dynamic" || style == "static" || style == "include")
     throw LammpsError("MI355X engine: group style " + style + " is not supported");
   download();
   if (gmask.empty()) gmask.assign(natoms, 1);
   int bit = group_bit(name);
+  if (style == "delete" || style == "clear") {        // src/group.cpp:103-150
+    if (!bit) throw LammpsError("Could not find group " + style + " group ID");
+    if (style == "delete") {
+      for (auto &f : fixes) if (f->groupbit == bit) throw LammpsError("Cannot delete group currently used by a fix");
+      for (auto &c : computes_local_bit) if (c.second == bit) throw LammpsError("Cannot delete group currently used by a compute");
+      for (auto &dp : dumps) if (dp.groupbit == bit) throw LammpsError("Cannot delete group currently used by a dump");
+    }
+    for (int i = 0; i < natoms; i++) gmask[i] &= ~bit;
+    if (style == "delete")                               // (the slot is free for the next new group: Group::find_unused)
+      for (size_t k = 1; k < group_names.size(); k++) if ((1 << k) == bit) group_names[k].clear();
+    dev_current = false;
+    return;
+  }
   if (!bit) {
-    if (group_names.size() >= 31) throw LammpsError("Too many groups");
-    group_names.push_back(name);
-    bit = 1 << (group_names.size() - 1);
+    size_t slot = 0;
+    for (size_t k = 1; k < group_names.size() && !slot; k++) if (group_names[k].empty()) slot = k;
+    if (!slot) {
+      if (group_names.size() >= 31) throw LammpsError("Too many groups");
+      group_names.push_back(name);
+      slot = group_names.size() - 1;
+    } else group_names[slot] = name;
+    bit = 1 << slot;
   }
   auto inum = [&](const std::string &t) {
     char *end; long v = strtol(t.c_str(), &end, 10);
@@ -1477,8 +1495,20 @@ void Engine::group_command(std::vector<std::string> &arg) {
   if (style == "type" || style == "id" || style == "molecule") {
     if (arg.size() < 3) throw LammpsError("Illegal group command");
     if (style == "molecule" && molecule.empty()) throw LammpsError("Group molecule command requires atom attribute molecule");
-    if (arg[2] == "<" || arg[2] == ">" || arg[2] == "<=" || arg[2] == ">=" || arg[2] == "==" || arg[2] == "!=" || arg[2] == "<>")
-      throw LammpsError("MI355X engine: group " + style + " with a comparison operator is not supported");
+    if (arg[2] == "<" || arg[2] == ">" || arg[2] == "<=" || arg[2] == ">=" || arg[2] == "==" || arg[2] == "!=" || arg[2] == "<>") {
+      // one comparison against a bound, `<>` = between two bounds, inclusive (src/group.cpp:200-280)
+      const std::string &op = arg[2];
+      if (arg.size() != (op == "<>" ? 5u : 4u)) throw LammpsError("Illegal group command");
+      const long b1 = inum(arg[3]), b2 = op == "<>" ? inum(arg[4]) : 0;
+      for (int i = 0; i < natoms; i++) {
+        const long v = style == "type" ? type[i] : style == "id" ? i + 1 : molecule[i];
+        const bool in = op == "<" ? v < b1 : op == ">" ? v > b1 : op == "<=" ? v <= b1 : op == ">=" ? v >= b1 : op == "==" ? v == b1 :
+                        op == "!=" ? v != b1 : (v >= b1 && v <= b2);
+        if (in) gmask[i] |= bit;
+      }
+      dev_current = false;
+      return;
+    }
     for (size_t k = 2; k < arg.size(); k++) {
       long lo, hi, stride = 1;
       const std::string &t = arg[k];

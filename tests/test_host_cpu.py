@@ -301,6 +301,43 @@ def test_velocity_on_a_group(tmp_path, opts):
         lmp.command("velocity none zero linear")
 
 
+def test_group_operators_clear_and_delete(tmp_path):
+    """`group ID type|id|molecule <op> value` (`<>` = between two bounds), `group ID clear`, `group ID delete` (a deleted
+    group's bit is reused by the next new group; a group a fix / dump / compute uses cannot be deleted): src/group.cpp:103-280."""
+    from lammps_le_amd import LammpsError
+    n = 600
+    lmp, s, m = _velocity_case(tmp_path, n, "group a id <= 100")
+    ids = np.arange(1, n + 1)
+    types = lmp.gather("type")
+    lmp.command("group b id <> 250 300")
+    lmp.command("group c type != 1")
+    lmp.command("group d id > 590")
+    mask = lmp.gather("mask")
+    assert np.array_equal((mask & 2) != 0, ids <= 100) and np.array_equal((mask & 4) != 0, (ids >= 250) & (ids <= 300))
+    assert np.array_equal((mask & 8) != 0, types != 1) and np.array_equal((mask & 16) != 0, ids > 590)
+    lmp.command("group b clear")
+    assert not (lmp.gather("mask") & 4).any()
+    lmp.command("group b id 7 8 9")                       # the cleared group is still there
+    assert np.array_equal((lmp.gather("mask") & 4) != 0, np.isin(ids, [7, 8, 9]))
+    lmp.command("fix 1 c nve")
+    with pytest.raises(LammpsError, match="Cannot delete group currently used by a fix"):
+        lmp.command("group c delete")
+    lmp.command("dump 1 d atom 10 %s" % (tmp_path / "d.dump"))
+    with pytest.raises(LammpsError, match="Cannot delete group currently used by a dump"):
+        lmp.command("group d delete")
+    lmp.command("group a delete")
+    assert not (lmp.gather("mask") & 2).any()
+    with pytest.raises(LammpsError, match="Could not find fix group ID"):
+        lmp.command("fix 2 a nve")
+    lmp.command("group e id == 42")                       # takes the freed bit
+    assert np.array_equal((lmp.gather("mask") & 2) != 0, ids == 42)
+    for bad, msg in (("group all delete", "Cannot change the group all"), ("group nosuch clear", "Could not find group clear group ID"),
+                     ("group nosuch delete", "Could not find group delete group ID"), ("group f id <> 5", "Illegal group command"),
+                     ("group f id < 5 6", "Illegal group command")):
+        with pytest.raises(LammpsError, match=msg):
+            lmp.command(bad)
+
+
 def test_regions_select_atoms(tmp_path):
     """`region ID block | sphere | cylinder | union | intersect ... [side in|out]` (src/region*.cpp: closed boundaries, match =
     !(inside ^ interior)), `group ID region R` (the atoms inside NOW, src/group.cpp:174-186) and `set region R ...`
