@@ -348,7 +348,7 @@ def test_group_command_errors(tmp_path):
     from lammps_le_amd import LammpsError
     s = lattice_chain(3000, seed=3)
     for bad, msg in (("group all type 1\n", "Cannot change the group all"), ("fix 1 nosuch nve\n", "Could not find fix group ID"),
-                     ("group g region box\n", "not supported"), ("group g union nosuch\n", "Group ID does not exist"),
+                     ("group g region box\n", "Group region ID does not exist"), ("group g dynamic all every 10\n", "not supported"), ("group g union nosuch\n", "Group ID does not exist"),
                      ("fix loop nosuch extrusion 7 1 1 1 1.0 2\n", "Could not find fix group ID")):
         with pytest.raises(LammpsError, match=msg):
             run_product(CHAIN_SCRIPT + bad + "run 1\n", s, tmp_path)
