@@ -301,6 +301,48 @@ def test_velocity_on_a_group(tmp_path, opts):
         lmp.command("velocity none zero linear")
 
 
+def test_round3_commands_are_parsed(tmp_path):
+    """Parse-time behaviour of what round 3 added to the script layer (no device needed): thermo keywords are checked when the
+    style is set (src/thermo.cpp:884-1040), fix langevin keywords (src/fix_langevin.cpp:105-155), the `angle` level of
+    run_style respa (src/respa.cpp:85-88, 217-224), dumps / computes / velocity on groups, chained barrier types."""
+    from lammps_le_amd import LammpsError
+    lmp, _ = _open(tmp_path)
+    lmp.command("thermo_style custom step elapsed time cpu temp press pe ke etotal enthalpy evdwl ecoul epair ebond eangle emol vol "
+                "density lx ylo zhi bonds angles nbuild ndanger pxx pyz")
+    lmp.command("thermo_style multi")
+    lmp.command("thermo_modify line one norm no")
+    with pytest.raises(LammpsError, match="Unknown keyword in thermo_style custom command: colour"):
+        lmp.command("thermo_style custom step colour")
+    with pytest.raises(LammpsError, match="Illegal thermo_modify command"):
+        lmp.command("thermo_modify line diagonal")
+    assert lmp.get_thermo("vol") > 0.0 and lmp.get_thermo("atoms") == lmp.get_natoms() and lmp.get_thermo("dt") == 0.005
+    lmp.command("group odd id 1:1000:2")
+    lmp.command("fix t1 odd langevin 1.0 1.0 1.0 77 scale 1 2.5 zero yes tally no gjf no omega no angmom no")
+    for bad, msg in (("fix t2 all langevin 1.0 1.0 1.0 77 scale 9 1.0", "Illegal fix langevin command"),
+                     ("fix t2 all langevin 1.0 1.0 1.0 77 zero", "Illegal fix langevin command"),
+                     ("fix t2 all langevin 1.0 1.0 1.0 77 gjf vfull", "not supported"),
+                     ("fix t2 all langevin 1.0 1.0 1.0 77 tally yes", "not supported"),
+                     ("fix t2 nobody langevin 1.0 1.0 1.0 77", "Could not find fix group ID")):
+        with pytest.raises(LammpsError, match=msg):
+            lmp.command(bad)
+    lmp.command("run_style respa 3 2 2 bond 1 angle 2 pair 3")
+    with pytest.raises(LammpsError, match="Invalid order of forces within respa levels"):
+        lmp.command("run_style respa 3 2 2 bond 2 angle 1 pair 3")
+    lmp.command("run_style verlet")
+    lmp.command("compute pg odd property/local btype batom1")
+    lmp.command("dump d1 odd custom 10 %s id type x" % (tmp_path / "g.dump"))
+    lmp.command("dump d2 odd dcd 10 %s" % (tmp_path / "g.dcd"))
+    lmp.command("velocity odd create 1.0 4711 loop local")
+    lmp.command("velocity odd zero linear")
+    for bad, msg in (("dump d3 nobody atom 10 x.dump", "Could not find dump group ID"),
+                     ("compute c3 nobody property/local btype", "Could not find compute group ID"),
+                     ("velocity nobody set 0 0 0", "Could not find velocity group ID")):
+        with pytest.raises(LammpsError, match=msg):
+            lmp.command(bad)
+    # a roadblock type equal to a barrier type is a legal fix extrusion (chained barrier draws)
+    lmp.command("fix loop all extrusion 1000 1 1 1 0.5 2 1")
+
+
 def test_group_operators_clear_and_delete(tmp_path):
     """`group ID type|id|molecule <op> value` (`<>` = between two bounds), `group ID clear`, `group ID delete` (a deleted
     group's bit is reused by the next new group; a group a fix / dump / compute uses cannot be deleted): src/group.cpp:103-280."""
