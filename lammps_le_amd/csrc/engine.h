@@ -269,7 +269,7 @@ class Engine {
   void setup();         // Verlet::setup
   void iterate(long n); // Verlet::run
   // run_style respa N loop_1 .. loop_{N-1} [bond L] [pair L] (src/respa.cpp); respa_levels = 0: run_style verlet.  A slow
-  // path of unfused kernels, one GPU only: what the LE fixes' post_integrate_respa hooks need
+  // path of unfused kernels (round 3: also decomposed): what the LE fixes' post_integrate_respa hooks need
   int respa_levels = 0, respa_loop[8] = {1, 1, 1, 1, 1, 1, 1, 1}, respa_level_bond = 0, respa_level_pair = 0, respa_level_angle = 0;
   double respa_step[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   double *respa_flevel[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device, by tag
